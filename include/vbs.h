@@ -1,0 +1,146 @@
+/* vbs.h — C-ABI of libvbs.so: MI355X (gfx950) marker tracking -> 3-D displacement.
+ *
+ * Drop-in boundary for the hot path of UPM-ROB-Lab/Vision-basedSensor.  The reference has no
+ * FFI layer; its boundary is the Python call signatures of
+ *   code/Marker_Tracking/marker_detection.py   (class MarkerTracker)
+ *   code/Marker_Calibration/3d_reconstruction.py (class MarkerAnalysis)
+ * and each entry point below names the reference function it replaces (file:line).  The Python
+ * shims in `vision-basedsensor_amd/` bind these with ctypes and pass torch device pointers
+ * (`tensor.data_ptr()`); nothing here depends on torch.
+ *
+ * Conventions
+ *  - every pointer marked [dev] is device memory of the handle's GPU, owned by the caller;
+ *    the library owns only the workspace inside `vbs_handle` (no allocation on a hot call);
+ *  - calls are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream);
+ *    the caller synchronises before reading results;
+ *  - return value: VBS_OK or a negative status; `vbs_last_error` gives the text.  Per-frame
+ *    conditions found on the device (capacity overflow) are reported in `counts[i]` as a negative
+ *    status, because the host cannot see them without a synchronisation;
+ *  - one handle per (device, stream); a handle is not thread-safe; one process per GPU.
+ *  - images: uint8, pixel (frame i, row y, col x, channel c) at
+ *        base + i*stride_n + y*stride_row + x*channels + c        (bytes)
+ *    so a crop (marker_detection.py:78-85) is a pointer offset plus the original strides.
+ */
+#ifndef VBS_H
+#define VBS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VBS_OK          0
+#define VBS_EINVAL     -1   /* bad argument (ValueError in the shim)                          */
+#define VBS_ECAPACITY  -2   /* more runs / components in a frame than the handle was sized for */
+#define VBS_EHIP       -3   /* a HIP runtime call failed                                      */
+#define VBS_ENOMEM     -4   /* workspace allocation failed                                    */
+
+#define VBS_DET_COLS    6   /* x, y, major_axis, minor_axis, angle, label(band component, 1-based) */
+#define VBS_TABLE_COLS 10   /* flags, Cx, Cy, major, minor, angle, X, Y, Z, det_index            */
+#define VBS_FLAG_TRACKED 1  /* table col 0 bit: the reference ID matched a detection (2-D row)    */
+#define VBS_FLAG_XYZ     2  /* table col 0 bit: the 3-D solve succeeded                           */
+#define VBS_DISP_COLS   5   /* flag, dX, dY, dZ, |d|                                              */
+#define VBS_PLANE_COLS  5   /* n_used, a, b, c, tilt_deg                                          */
+
+typedef struct vbs_handle vbs_handle;
+
+/* Camera of MarkerAnalysis.load_parameters (3d_reconstruction.py:70-130): every field is the
+ * float32 value the reference stores; arithmetic on them is float64 as in the reference. */
+typedef struct vbs_camera {
+    float K[9];      /* row-major camera matrix            (:87-91)   */
+    float dist[5];   /* k1 k2 p1 p2 k3                     (:98-102)  */
+    float R[9];      /* row-major R_world_to_cam           (:109-112) */
+    float T[3];      /* T_world_to_cam                     (:120-124) */
+    float marker_diameter_mm;   /* Config.marker_diameter_mm (:21)   */
+} vbs_camera;
+
+/* Workspace for frames of `height` x `width` (after cropping).  `max_markers` bounds the connected
+ * components per mask per frame, `max_batch` the frames processed per internal pass (larger
+ * batches are looped).  height <= 480 selects the reference's small-image parameter set
+ * (marker_detection.py:117-126,170). */
+int vbs_create(int device, int height, int width, int max_markers, int max_batch, vbs_handle** out);
+int vbs_destroy(vbs_handle* h);
+const char* vbs_last_error(const vbs_handle* h);
+int vbs_version(void);
+/* host-only helper: the 256-entry table that classifies a border pixel's 8-neighbourhood into the
+ * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain
+ * direction d is foreground; 0=E,1=NE,2=N,...,7=SE). */
+int vbs_contour_lut(uint8_t out[256]);
+/* host-only helpers exposing the constant tables the kernels use, so they can be checked without a
+ * GPU: the fixed-point GaussianBlur taps (sum 256; marker_detection.py:118-124 via cv2) and the 1-D
+ * factor g of the NCC template with stats = {mean(t), sum((t-mean)^2), l*l, 0.1^2}
+ * (_gkern :138-143, _normxcorr2 :152,162). */
+int vbs_gaussian_taps_q8(int ksize, double sigma, int32_t* out);
+int vbs_ncc_template(int l, double sigma, double* g, double* stats);
+
+/* MarkerTracker._find_markers (marker_detection.py:112-135): BGR2GRAY -> 2x GaussianBlur -> uint8
+ * difference +15 (mod 256) -> inRange -> area_mask {0,255}; NCC with the Gaussian template
+ * (_gkern :138, _normxcorr2 :146) -> mask {0,1} = ncc > 0.1.
+ * frames [dev] uint8, channels 1 (gray) or 3 (BGR); mask / area_mask [dev] uint8 [n,h,w] dense
+ * (either may be NULL). */
+int vbs_find_markers(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
+                     int64_t stride_row, uint8_t* mask, uint8_t* area_mask, void* stream);
+
+/* MarkerTracker._normxcorr2 (marker_detection.py:146-164) for the pipeline's own operands: the
+ * float64 correlation map of area_mask with the template, ncc [dev] float64 [n,h,w] dense.
+ * (Diagnostic / parity entry: the hot path never materialises this map.) */
+int vbs_ncc_map(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
+                int64_t stride_row, double* ncc, void* stream);
+/* host copy of the per-frame counters of the LAST internal pass: out[i*8 + {0: area_mask popcount,
+ * 1: NCC pixels within 1e-9 (relative) of the 0.1 threshold, 2: status}] (synchronises). */
+int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n);
+
+/* MarkerAnalysis._undistort_points (3d_reconstruction.py:185-193) and _calculate_3d_position
+ * (:195-238) on float64 points, no handle needed: pts/out [dev] float64 [n,2]; uvd [dev] float64
+ * [n,3] = (u, v, diameter_px); xyz [dev] float64 [n,3]; ok [dev] int32 [n] (0 where the reference
+ * raises ValueError). */
+int vbs_undistort_points(int device, const double* pts, int n, const vbs_camera* cam, double* out,
+                         void* stream);
+int vbs_calculate_3d(int device, const double* uvd, int n, const vbs_camera* cam, double* xyz,
+                     int32_t* ok, void* stream);
+
+/* MarkerTracker._marker_center (marker_detection.py:166-249): band = mask AND NOT erode(mask)
+ * (maximum/minimum_filter :171-174) -> 4-connected labels (:176) -> centroids (:181); 5x5 open
+ * (:195) -> external contours (:196) -> fitEllipse (:208) -> contour/centre matching (:222-243).
+ * mask, area_mask [dev] uint8 [n,h,w] dense, two-valued (0 / non-zero).
+ * det [dev] float32 [n,max_markers,VBS_DET_COLS], rows in the reference's output order;
+ * counts [dev] int32 [n] = number of rows, or a negative status for that frame. */
+int vbs_marker_center(vbs_handle* h, const uint8_t* mask, const uint8_t* area_mask, int n,
+                      float* det, int32_t* counts, void* stream);
+
+/* MarkerTracker._track_markers (marker_detection.py:349-396): per reference ID the nearest
+ * detection (first on ties), dropped when farther than min_dist.  ref_xy [dev] float64 [m_ref,2]
+ * = (Ox, Oy) in reference-dict order; table [dev] float32 [n,m_ref,VBS_TABLE_COLS]; XYZ columns
+ * are left 0 and VBS_FLAG_XYZ clear. */
+int vbs_track(vbs_handle* h, const float* det, const int32_t* counts, int n, const double* ref_xy,
+              int m_ref, double min_dist, float* table, void* stream);
+
+/* MarkerAnalysis._undistort_points + _calculate_3d_position (3d_reconstruction.py:185-238) on the
+ * tracked rows of `table` (in place: fills X,Y,Z and VBS_FLAG_XYZ).  Rows with
+ * major_axis < min_marker_size_px are skipped (load_marker_data :172-176). */
+int vbs_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_camera* cam,
+                double min_marker_size_px, void* stream);
+
+/* Fused frames -> table: everything above in one call, intermediates kept on the device in
+ * float64 / bit-packed form (no uint8 masks are written).  counts may be NULL. */
+int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
+                    int64_t stride_row, const double* ref_xy, int m_ref, double min_dist,
+                    const vbs_camera* cam, double min_marker_size_px, float* table,
+                    float* det, int32_t* counts, void* stream);
+
+/* MarkerAnalysis._track_markers (3d_reconstruction.py:240-316) on a (gathered) table of n
+ * consecutive frames: per ID the displacement against the frame where it was LAST SEEN; frames
+ * before `first_frame + warmup_frames` are skipped; |d| > max_displacement clears the flag.
+ * disp [dev] float32 [n,m_ref,VBS_DISP_COLS]. */
+int vbs_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup_frames,
+                     double min_marker_size_px, double max_displacement, float* disp, void* stream);
+
+/* fit_plane_least_squares (ForceDistribution.py:138-162): per frame Z = aX + bY + c over the rows
+ * with VBS_FLAG_XYZ, tilt = atan(sqrt(a^2+b^2)) in degrees.  plane [dev] float32 [n,VBS_PLANE_COLS]. */
+int vbs_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VBS_H */

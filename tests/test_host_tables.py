@@ -1,0 +1,105 @@
+"""CPU tests of the host-side tables inside libvbs.so against the oracle (no GPU, no compute kernels):
+the library must load, export every symbol of include/vbs.h, and its constant tables must match."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+from scipy import ndimage
+
+import vbs_amd._lib as L
+from oracle import stages as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_header_symbol():
+    hdr = open(os.path.join(ROOT, "include", "vbs.h")).read()
+    declared = set(re.findall(r"\b(vbs_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(L.SYMBOLS)
+    lib = L.lib()
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.vbs_version() >= 100
+
+
+@pytest.mark.parametrize("ksize,sigma", [(39, 8.0), (101, 20.0), (21, 4.56), (35, 11.4)])
+def test_gaussian_taps_match_oracle(ksize, sigma):
+    out = np.zeros(ksize, dtype=np.int32)
+    assert L.lib().vbs_gaussian_taps_q8(ksize, sigma, out.ctypes.data_as(C.c_void_p)) == 0
+    np.testing.assert_array_equal(out, O.gaussian_kernel_q8(ksize, sigma))
+    assert out.sum() == 256 and (out >= 0).all()
+
+
+@pytest.mark.parametrize("l,sigma", [(80, 13.0), (33, 7.4)])
+def test_ncc_template_matches_oracle(l, sigma):
+    g = np.zeros(l)
+    st = np.zeros(4)
+    assert L.lib().vbs_ncc_template(l, sigma, g.ctypes.data_as(C.c_void_p), st.ctypes.data_as(C.c_void_p)) == 0
+    t = O.gkern(l, sigma)
+    np.testing.assert_allclose(np.outer(g, g), t, rtol=1e-13, atol=0)
+    tbar = np.mean(t)
+    assert abs(st[0] - tbar) <= 1e-15 * tbar
+    T2 = np.sum(np.square(t - tbar))
+    assert abs(st[1] - T2) <= 1e-13 * T2
+    assert st[2] == l * l and st[3] == 0.1 * 0.1
+
+
+def _lut():
+    lut = np.zeros(256, dtype=np.uint8)
+    assert L.lib().vbs_contour_lut(lut.ctypes.data_as(C.c_void_p)) == 0
+    return lut
+
+
+def lut_vertices(fg, lut):
+    """Apply the library's table to every border pixel: {(x, y): multiplicity}."""
+    H, W = fg.shape
+    p = np.zeros((H + 2, W + 2), dtype=np.uint8)
+    p[1:-1, 1:-1] = fg
+    pat = np.zeros((H, W), dtype=np.int32)
+    for d in range(8):
+        pat |= p[1 + O._DY[d]:1 + O._DY[d] + H, 1 + O._DX[d]:1 + O._DX[d] + W].astype(np.int32) << d
+    four = (pat & 1 > 0) & (pat & 4 > 0) & (pat & 16 > 0) & (pat & 64 > 0)
+    border = (fg > 0) & ~four
+    out = {}
+    for y, x in zip(*np.nonzero(border)):
+        m = int(lut[pat[y, x]])
+        if m:
+            out[(int(x), int(y))] = m
+    return out
+
+
+@pytest.mark.parametrize("seed,opened", [(0, True), (1, True), (2, False), (3, False), (4, False)])
+def test_contour_lut_equals_traced_vertices(seed, opened):
+    """The claim behind the HIP contour stage: for hole-free foreground, the per-pixel table yields
+    exactly the multiset of CHAIN_APPROX_SIMPLE vertices of the traced outer borders."""
+    rng = np.random.default_rng(seed)
+    a = ndimage.gaussian_filter(rng.random((150, 170)), 3.0 if opened else 1.2)
+    fg = a > np.quantile(a, 0.6)
+    if opened:
+        fg = O.morph_open5(fg)
+    else:
+        fg[40, 10:120] = True                      # 1-px lines: pixels visited twice
+        fg[10:100, 60] = True
+    fg = ndimage.binary_fill_holes(fg, structure=np.ones((3, 3)))     # no holes w.r.t. 4-conn background
+    fg = ndimage.binary_fill_holes(fg)
+    traced = {}
+    for cnt in O.find_contours_external(fg):
+        for x, y in cnt:
+            traced[(int(x), int(y))] = traced.get((int(x), int(y)), 0) + 1
+    assert lut_vertices(fg.astype(np.uint8), _lut()) == traced
+
+
+def test_contour_lut_simple_shapes():
+    lut = _lut()
+    sq = np.zeros((12, 12), np.uint8)
+    sq[3:8, 2:9] = 1
+    assert lut_vertices(sq, lut) == {(2, 3): 1, (8, 3): 1, (8, 7): 1, (2, 7): 1}
+    one = np.zeros((5, 5), np.uint8)
+    one[2, 2] = 1
+    assert lut_vertices(one, lut) == {(2, 2): 1}
+    assert [c.tolist() for c in O.find_contours_external(one)] == [[[2, 2]]]
+    line = np.zeros((5, 9), np.uint8)
+    line[2, 1:8] = 1
+    assert lut_vertices(line, lut) == {(1, 2): 1, (7, 2): 1}

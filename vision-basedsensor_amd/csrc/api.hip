@@ -1,0 +1,378 @@
+// C-ABI of include/vbs.h: workspace management, host-side constant tables, kernel sequencing.
+#include <cmath>
+#include <cstring>
+#include <new>
+
+#include "common.h"
+
+void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
+                        float* table, const vbs_camera* cam, double min_size, hipStream_t s);
+
+// ---- host tables -----------------------------------------------------------------------------------
+// OpenCV 4 bit-exact uint8 Gaussian kernel in 8 fractional bits (see oracle/stages.py:gaussian_kernel_q8)
+static std::vector<int> gaussian_taps_q8(int ksize, double sigma) {
+    std::vector<double> v(ksize);
+    const double scale2x = -0.125 / (sigma * sigma);
+    for (int i = 0; i < ksize; ++i) {
+        double xi = (double)(1 - ksize + 2 * i);
+        v[i] = std::exp(xi * xi * scale2x);
+    }
+    const int n2 = (ksize - 1) / 2;
+    double s = 0;
+    for (int i = 0; i < n2; ++i) s += v[i];
+    s = 2.0 * s + 1.0;
+    const double mul = 1.0 / s;
+    std::vector<int> out(ksize, 0);
+    double err = 0;
+    int tot = 0;
+    for (int i = 0; i < ksize / 2; ++i) {
+        double adj = v[i] * mul * 256.0 + err;
+        int v0 = (int)std::nearbyint(adj);             // round half to even (cvRound)
+        err = adj - v0;
+        out[i] = out[ksize - 1 - i] = v0;
+        tot += v0;
+    }
+    out[ksize / 2] = 256 - 2 * tot;
+    return out;
+}
+
+template <int MAXW>
+static void pack_taps_t(const std::vector<int>& k, int c4, int nw, u32 dst[4][MAXW]) {
+    const int taps = (int)k.size(), c = taps / 2;
+    for (int s = 0; s < 4; ++s)
+        for (int q = 0; q < MAXW; ++q) {
+            u32 w = 0;
+            if (q < nw)
+                for (int b = 0; b < 4; ++b) {
+                    int j = 4 * q + b - (c4 - c + s);
+                    if (j >= 0 && j < taps) w |= (u32)k[j] << (8 * b);
+                }
+            dst[s][q] = w;
+        }
+}
+
+static void ncc_consts(int l, double sigma, NccConst* nc) {
+    std::vector<double> ax(l), e(l);
+    // np.linspace(-(l-1)/2, (l-1)/2, l): start + i*step, last point exact
+    const double start = -(l - 1) / 2.0, stop = (l - 1) / 2.0, step = (stop - start) / (l - 1);
+    for (int i = 0; i < l; ++i) ax[i] = (i == l - 1) ? stop : start + i * step;
+    double se = 0;
+    for (int i = 0; i < l; ++i) { e[i] = std::exp(-0.5 * ax[i] * ax[i] / (sigma * sigma)); se += e[i]; }
+    for (int i = 0; i < VBS_NCC_MAXL; ++i) nc->g[i] = i < l ? e[i] / se : 0.0;
+    // template statistics as `_normxcorr2` forms them: t = K / sum(K), tbar = mean(t), T2 = sum((t - tbar)^2)
+    std::vector<double> K((size_t)l * l);
+    double sk = 0;
+    for (int i = 0; i < l; ++i)
+        for (int j = 0; j < l; ++j) {
+            K[(size_t)i * l + j] = std::exp(-0.5 * (ax[j] * ax[j] + ax[i] * ax[i]) / (sigma * sigma));
+            sk += K[(size_t)i * l + j];
+        }
+    double st = 0;
+    for (auto& x : K) { x /= sk; st += x; }
+    nc->tbar = st / ((double)l * l);
+    double t2 = 0;
+    for (auto& x : K) t2 += (x - nc->tbar) * (x - nc->tbar);
+    nc->T2 = t2;
+    nc->l2 = (double)l * l;
+    nc->thr2 = 0.1 * 0.1;
+}
+
+// ---- handle ------------------------------------------------------------------------------------------
+template <typename T>
+static int dev_alloc(vbs_handle* h, T** p, size_t count) {
+    void* q = nullptr;
+    if (hipMalloc(&q, count * sizeof(T) + 256) != hipSuccess) {
+        h->err = "hipMalloc failed (" + std::to_string(count * sizeof(T)) + " bytes)";
+        return VBS_ENOMEM;
+    }
+    h->allocs.push_back(q);
+    *p = (T*)q;
+    return VBS_OK;
+}
+
+extern "C" int vbs_version(void) { return 100; }
+
+extern "C" int vbs_contour_lut(uint8_t out[256]) {
+    if (!out) return VBS_EINVAL;
+    make_contour_lut(out);
+    return VBS_OK;
+}
+
+extern "C" int vbs_gaussian_taps_q8(int ksize, double sigma, int32_t* out) {
+    if (!out || ksize < 1 || !(ksize & 1) || !(sigma > 0)) return VBS_EINVAL;
+    std::vector<int> k = gaussian_taps_q8(ksize, sigma);
+    for (int i = 0; i < ksize; ++i) out[i] = k[i];
+    return VBS_OK;
+}
+
+extern "C" int vbs_ncc_template(int l, double sigma, double* g, double* stats) {
+    if (!g || !stats || l < 2 || l > VBS_NCC_MAXL || !(sigma > 0)) return VBS_EINVAL;
+    NccConst nc;
+    ncc_consts(l, sigma, &nc);
+    for (int i = 0; i < l; ++i) g[i] = nc.g[i];
+    stats[0] = nc.tbar; stats[1] = nc.T2; stats[2] = nc.l2; stats[3] = nc.thr2;
+    return VBS_OK;
+}
+
+extern "C" int vbs_destroy(vbs_handle* h) {
+    if (!h) return VBS_EINVAL;
+    hipSetDevice(h->device);
+    for (void* p : h->allocs) hipFree(p);
+    delete h;
+    return VBS_OK;
+}
+
+extern "C" const char* vbs_last_error(const vbs_handle* h) { return h ? h->err.c_str() : "null handle"; }
+
+extern "C" int vbs_create(int device, int height, int width, int max_markers, int max_batch,
+                          vbs_handle** out) {
+    if (!out) return VBS_EINVAL;
+    *out = nullptr;
+    if (height < 64 || width < 128 || max_markers < 1 || max_markers > 1024 || max_batch < 1) return VBS_EINVAL;
+    vbs_handle* h = new (std::nothrow) vbs_handle();
+    if (!h) return VBS_ENOMEM;
+    *out = h;                                           // returned even on failure so the text can be read
+    h->device = device;
+    if (hipSetDevice(device) != hipSuccess) { h->err = "hipSetDevice failed"; return VBS_EHIP; }
+    h->H = height; h->W = width; h->maxm = max_markers; h->maxb = max_batch;
+    h->P = (width + 63) / 64 * 64;
+    h->WW = h->P / 64;
+    BranchParams& bp = h->bp;
+    bp.small = height <= 480;                           // marker_detection.py:117
+    double sa, sb, ts;
+    if (bp.small) { bp.taps_a = 21; sa = 4.56; bp.taps_b = 35; sb = 11.4; bp.ncc_l = 33; ts = 7.4; bp.thresh = 35; bp.hi = 180; bp.ns = 8; }
+    else { bp.taps_a = 39; sa = 8.0; bp.taps_b = 101; sb = 20.0; bp.ncc_l = 80; ts = 13.0; bp.thresh = 20; bp.hi = 200; bp.ns = 14; }
+    bp.c4a = (bp.taps_a / 2 + 3) / 4 * 4;
+    bp.c4b = (bp.taps_b / 2 + 3) / 4 * 4;
+    bp.nwa = (bp.c4a - bp.taps_a / 2 + 3 + bp.taps_a + 3) / 4;
+    bp.nwb = (bp.c4b - bp.taps_b / 2 + 3 + bp.taps_b + 3) / 4;
+    bp.ncc_lo = -((bp.ncc_l - 1) - (bp.ncc_l - 1) / 2);
+    bp.ncc_hi = (bp.ncc_l - 1) / 2;
+    if (height <= bp.taps_b / 2 + 4 || width <= bp.taps_b / 2 + 4) { h->err = "frame smaller than the blur radius"; return VBS_EINVAL; }
+    // the kernels are instantiated for exactly these shapes
+    if (!((bp.small && bp.nwa == 7 && bp.nwb == 11 && bp.c4a == 12 && bp.c4b == 20) ||
+          (!bp.small && bp.nwa == 11 && bp.nwb == 27 && bp.c4a == 20 && bp.c4b == 52))) {
+        h->err = "internal: tap layout mismatch";
+        return VBS_EINVAL;
+    }
+    pack_taps_t<12>(gaussian_taps_q8(bp.taps_a, sa), bp.c4a, bp.nwa, h->taps.a);
+    pack_taps_t<VBS_MAX_TAPS_WORDS>(gaussian_taps_q8(bp.taps_b, sb), bp.c4b, bp.nwb, h->taps.b);
+    ncc_consts(bp.ncc_l, ts, &h->ncc);
+    h->QE = (height + 3) / 4 + bp.nwb - 1;
+    h->mref_cap = 0;
+
+    const size_t B = (size_t)max_batch, HW = (size_t)height * h->WW, HP = (size_t)height * h->P;
+    int rc;
+#define ALLOC(field, count) if ((rc = dev_alloc(h, &h->field, (count))) != VBS_OK) return rc
+    ALLOC(gray, B * HP);
+    ALLOC(planes, B * 4 * (size_t)h->QE * h->P);
+    ALLOC(area_bits, B * HW); ALLOC(mask_bits, B * HW); ALLOC(band_bits, B * HW);
+    ALLOC(er_bits, B * HW); ALLOC(open_bits, B * HW);
+    ALLOC(hx, B * HP); ALLOC(cx, B * HP);
+    ALLOC(ncc_rx, (size_t)width); ALLOC(ncc_ry, (size_t)height);
+    ALLOC(fstat, B * 8);
+    ALLOC(wbase, B * 2 * HW);
+    ALLOC(node_pos, B * 2 * VBS_RUN_CAP); ALLOC(node_comp, B * 2 * VBS_RUN_CAP);
+    ALLOC(ncomp, B * 2);
+    ALLOC(band_first, B * max_markers); ALLOC(band_sums, B * max_markers * 4);
+    ALLOC(area_first, B * max_markers); ALLOC(area_sums, B * max_markers * VBS_AREA_SUMS);
+    ALLOC(ell, B * max_markers * 8); ALLOC(det64, B * max_markers * 6);
+    ALLOC(cnt, B);
+    ALLOC(lut, 256);
+#undef ALLOC
+    std::vector<double> rx(width), ry(height);
+    for (int x = 0; x < width; ++x) {
+        double s = 0;
+        for (int j = 0; j < bp.ncc_l; ++j) { int xx = x + bp.ncc_lo + j; if (xx >= 0 && xx < width) s += h->ncc.g[j]; }
+        rx[x] = s;
+    }
+    for (int y = 0; y < height; ++y) {
+        double s = 0;
+        for (int j = 0; j < bp.ncc_l; ++j) { int yy = y + bp.ncc_lo + j; if (yy >= 0 && yy < height) s += h->ncc.g[j]; }
+        ry[y] = s;
+    }
+    u8 lut[256];
+    make_contour_lut(lut);
+    HIPCHK(h, hipMemcpy(h->ncc_rx, rx.data(), width * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->ncc_ry, ry.data(), height * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
+    HIPCHK(h, hipDeviceSynchronize());
+    return VBS_OK;
+}
+
+static int check_launch(vbs_handle* h) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("kernel launch: ") + hipGetErrorString(e); return VBS_EHIP; }
+    return VBS_OK;
+}
+
+static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
+                       int64_t stride_row, u8* mask_u8, u8* area_u8, double* ncc_out, hipStream_t s) {
+    HIPCHK(h, hipMemsetAsync(h->fstat, 0, (size_t)nb * 8 * sizeof(u32), s));
+    if (channels == 1) {
+        launch_blur(h, frames, stride_n, stride_row, nb, area_u8, s);
+    } else {
+        launch_gray(h, frames, nb, channels, stride_n, stride_row, s);
+        launch_blur(h, h->gray, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
+    }
+    launch_ncc(h, nb, mask_u8, ncc_out, s);
+    return check_launch(h);
+}
+
+extern "C" int vbs_find_markers(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
+                                int64_t stride_row, uint8_t* mask, uint8_t* area_mask, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!frames || n < 0 || (channels != 1 && channels != 3) || stride_row < (int64_t)h->W * channels) {
+        h->err = "vbs_find_markers: bad argument";
+        return VBS_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    for (int off = 0; off < n; off += h->maxb) {
+        int nb = std::min(h->maxb, n - off);
+        int rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row,
+                             mask ? mask + off * hw : nullptr, area_mask ? area_mask + off * hw : nullptr,
+                             nullptr, s);
+        if (rc != VBS_OK) return rc;
+    }
+    return VBS_OK;
+}
+
+extern "C" int vbs_ncc_map(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
+                           int64_t stride_row, double* ncc, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!frames || !ncc || n < 0 || (channels != 1 && channels != 3) || stride_row < (int64_t)h->W * channels) {
+        h->err = "vbs_ncc_map: bad argument";
+        return VBS_EINVAL;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    for (int off = 0; off < n; off += h->maxb) {
+        int nb = std::min(h->maxb, n - off);
+        int rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr,
+                             nullptr, ncc + off * hw, s);
+        if (rc != VBS_OK) return rc;
+    }
+    return VBS_OK;
+}
+
+extern "C" int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n) {
+    if (!h || !out || n < 0 || n > h->maxb) return VBS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipMemcpy(out, h->fstat, (size_t)n * 8 * sizeof(u32), hipMemcpyDeviceToHost));
+    return VBS_OK;
+}
+
+extern "C" int vbs_undistort_points(int device, const double* pts, int n, const vbs_camera* cam, double* out,
+                                    void* stream) {
+    if (!pts || !out || !cam || n < 0) return VBS_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return VBS_EHIP;
+    if (n) launch_points(0, pts, n, *cam, out, nullptr, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? VBS_OK : VBS_EHIP;
+}
+
+extern "C" int vbs_calculate_3d(int device, const double* uvd, int n, const vbs_camera* cam, double* xyz,
+                                int32_t* ok, void* stream) {
+    if (!uvd || !xyz || !ok || !cam || n < 0) return VBS_EINVAL;
+    if (!(cam->K[0] > 0) || !(cam->K[4] > 0)) return VBS_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return VBS_EHIP;
+    if (n) launch_points(1, uvd, n, *cam, xyz, ok, (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? VBS_OK : VBS_EHIP;
+}
+
+extern "C" int vbs_marker_center(vbs_handle* h, const uint8_t* mask, const uint8_t* area_mask, int n,
+                                 float* det, int32_t* counts, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!mask || !area_mask || !det || !counts || n < 0) { h->err = "vbs_marker_center: bad argument"; return VBS_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    for (int off = 0; off < n; off += h->maxb) {
+        int nb = std::min(h->maxb, n - off);
+        HIPCHK(h, hipMemsetAsync(h->fstat, 0, (size_t)nb * 8 * sizeof(u32), s));
+        launch_threshold(h, mask + off * hw, area_mask + off * hw, nb, s);
+        launch_morph(h, nb, s);
+        launch_label(h, nb, s);
+        launch_finalize(h, nb, det + (size_t)off * h->maxm * VBS_DET_COLS, counts + off, s);
+        int rc = check_launch(h);
+        if (rc != VBS_OK) return rc;
+    }
+    return VBS_OK;
+}
+
+extern "C" int vbs_track(vbs_handle* h, const float* det, const int32_t* counts, int n, const double* ref_xy,
+                         int m_ref, double min_dist, float* table, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!det || !counts || !ref_xy || !table || n < 0 || m_ref < 1) { h->err = "vbs_track: bad argument"; return VBS_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) launch_track(h, det, counts, n, ref_xy, m_ref, min_dist, table, (hipStream_t)stream);
+    return check_launch(h);
+}
+
+static int check_cam(vbs_handle* h, const vbs_camera* cam) {
+    if (!cam) { h->err = "camera is NULL"; return VBS_EINVAL; }
+    if (!(cam->K[0] > 0) || !(cam->K[4] > 0)) { h->err = "Focal lengths must be positive"; return VBS_EINVAL; }
+    return VBS_OK;
+}
+
+extern "C" int vbs_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_camera* cam,
+                           double min_marker_size_px, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!table || n < 0 || m_ref < 1) { h->err = "vbs_solve3d: bad argument"; return VBS_EINVAL; }
+    int rc = check_cam(h, cam);
+    if (rc != VBS_OK) return rc;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) launch_solve3d(h, table, n, m_ref, *cam, min_marker_size_px, (hipStream_t)stream);
+    return check_launch(h);
+}
+
+extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
+                               int64_t stride_row, const double* ref_xy, int m_ref, double min_dist,
+                               const vbs_camera* cam, double min_marker_size_px, float* table, float* det,
+                               int32_t* counts, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!frames || n < 0 || (channels != 1 && channels != 3) || stride_row < (int64_t)h->W * channels ||
+        (table && (!ref_xy || m_ref < 1))) {
+        h->err = "vbs_track_to_3d: bad argument";
+        return VBS_EINVAL;
+    }
+    if (cam) { int rc = check_cam(h, cam); if (rc != VBS_OK) return rc; }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    for (int off = 0; off < n; off += h->maxb) {
+        int nb = std::min(h->maxb, n - off);
+        int rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr,
+                             nullptr, nullptr, s);
+        if (rc != VBS_OK) return rc;
+        launch_morph(h, nb, s);
+        launch_label(h, nb, s);
+        launch_finalize(h, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr,
+                        counts ? counts + off : nullptr, s);
+        if (table)
+            launch_track_fused(h, nb, ref_xy, m_ref, min_dist, table + (size_t)off * m_ref * VBS_TABLE_COLS, cam,
+                               min_marker_size_px, s);
+        rc = check_launch(h);
+        if (rc != VBS_OK) return rc;
+    }
+    return VBS_OK;
+}
+
+extern "C" int vbs_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup_frames,
+                                double min_marker_size_px, double max_displacement, float* disp, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!table || !disp || n < 0 || m_ref < 1) { h->err = "vbs_displacement: bad argument"; return VBS_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) launch_displacement(h, table, n, m_ref, warmup_frames, min_marker_size_px, max_displacement, disp,
+                               (hipStream_t)stream);
+    return check_launch(h);
+}
+
+extern "C" int vbs_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!table || !plane || n < 0 || m_ref < 1) { h->err = "vbs_plane_fit: bad argument"; return VBS_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) launch_plane_fit(h, table, n, m_ref, plane, (hipStream_t)stream);
+    return check_launch(h);
+}

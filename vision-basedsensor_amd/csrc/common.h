@@ -1,0 +1,111 @@
+// Internal definitions shared by the gfx950 kernels and the C-ABI (include/vbs.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+#include <vector>
+
+#include "../../include/vbs.h"
+
+typedef unsigned long long u64;
+typedef long long i64;
+typedef uint32_t u32;
+typedef uint8_t u8;
+
+#define VBS_MAX_TAPS_WORDS 28      // (taps + 7) / 4 for the 101-tap blur
+#define VBS_NCC_MAXL 80
+#define VBS_RUN_CAP 30720          // union-find nodes (runs) per mask per frame kept in LDS
+#define VBS_AREA_SUMS 16           // n, 14 moments up to order 4, spare
+
+// Blur taps packed for v_dot4_u32_u8: for output phase s (0..3) word q holds the four taps that
+// multiply input bytes 4q..4q+3 of the aligned window (zero where no tap applies).
+struct BlurTaps {
+    u32 a[4][12];      // small kernel (39 or 21 taps): <= 11 words
+    u32 b[4][VBS_MAX_TAPS_WORDS];   // large kernel (101 or 35 taps): <= 27 words
+};
+
+struct BranchParams {              // marker_detection.py:117-126,129,170
+    int taps_a, taps_b;            // GaussianBlur sizes
+    int c4a, c4b;                  // centre offsets rounded up to a multiple of 4
+    int nwa, nwb;                  // words per shifted kernel
+    int thresh, hi;                // inRange bounds
+    int ncc_l;                     // template size
+    int ncc_lo, ncc_hi;            // window offsets of mode='same'
+    int ns;                        // max/min filter size (14 | 8)
+    int small;                     // 1 = small-image branch
+};
+
+struct NccConst {
+    double g[VBS_NCC_MAXL];        // 1-D normalised Gaussian, template = g (x) g
+    double tbar, T2, l2, thr2;     // mean(template), sum((t-tbar)^2), l*l, 0.1*0.1
+};
+
+struct vbs_handle {
+    int device, H, W, P, WW, maxm, maxb;   // P = row pitch (mult. of 64), WW = P/64 words per row
+    int QE;                                // extended row-quads of the blur planes
+    BranchParams bp;
+    BlurTaps taps;
+    NccConst ncc;
+    std::string err;
+    // ---- device workspace (per internal pass of maxb frames) ----
+    u8* gray;          // [maxb][H][P]
+    u32* planes;       // [maxb][4][QE][P]   hi/lo byte planes of both horizontal blurs, row-quad packed
+    u64* area_bits;    // [maxb][H][WW]
+    u64* mask_bits;    // [maxb][H][WW]
+    u64* band_bits;    // [maxb][H][WW]
+    u64* er_bits;      // [maxb][H][WW]
+    u64* open_bits;    // [maxb][H][WW]
+    double* hx;        // [maxb][H][P]      horizontal NCC pass
+    u8* cx;            // [maxb][H][P]      horizontal box counts
+    double* ncc_rx;    // [W]  sum of g over the in-image part of the window (columns)
+    double* ncc_ry;    // [H]
+    u32* fstat;        // [maxb][8]  0: area popcount, 1: ambiguous ncc pixels, 2: status
+    u32* wbase;        // [maxb][2][H*WW]   first node index of each word
+    u32* node_pos;     // [maxb][2][RUN_CAP]  y*W + x0 of each run
+    u32* node_comp;    // [maxb][2][RUN_CAP]  component id (0-based, raster order) of each run
+    u32* ncomp;        // [maxb][2]
+    u32* band_first;   // [maxb][maxm]
+    u64* band_sums;    // [maxb][maxm][4]   count, sum x, sum y, spare
+    u32* area_first;   // [maxb][maxm]
+    i64* area_sums;    // [maxb][maxm][VBS_AREA_SUMS]  vertex moments about the component's first pixel
+    double* ell;       // [maxb][maxm][8]   cx, cy, w, h, angle, nvert, ok, spare
+    double* det64;     // [maxb][maxm][6]
+    int32_t* cnt;      // [maxb]
+    double* tab64;     // [maxb][mref_cap][10]
+    u8* lut;           // [256] contour vertex table
+    int mref_cap;
+    std::vector<void*> allocs;
+};
+
+#define HIPCHK(h, call)                                                                   \
+    do {                                                                                  \
+        hipError_t e_ = (call);                                                           \
+        if (e_ != hipSuccess) {                                                           \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);                 \
+            return VBS_EHIP;                                                              \
+        }                                                                                 \
+    } while (0)
+
+// ---- launchers (each enqueues on `s`; nb = frames in this pass) --------------------------------
+void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
+                 int64_t stride_row, hipStream_t s);
+void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,
+                 u8* area_u8, hipStream_t s);
+void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s);
+void launch_points(int which, const double* in, int n, const vbs_camera& cam, double* out, int32_t* ok,
+                   hipStream_t s);
+void launch_threshold(vbs_handle* h, const u8* mask, const u8* area, int nb, hipStream_t s);
+void launch_morph(vbs_handle* h, int nb, hipStream_t s);
+void launch_label(vbs_handle* h, int nb, hipStream_t s);
+void launch_finalize(vbs_handle* h, int nb, float* det, int32_t* counts, hipStream_t s);
+void launch_track(vbs_handle* h, const float* det32, const int32_t* counts32, int nb,
+                  const double* ref_xy, int m_ref, double min_dist, float* table, hipStream_t s);
+void launch_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_camera& cam,
+                    double min_size, hipStream_t s);
+void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup,
+                         double min_size, double max_disp, float* disp, hipStream_t s);
+void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane,
+                      hipStream_t s);
+void make_contour_lut(u8 out[256]);
+void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
+                        float* table, const vbs_camera* cam, double min_size, hipStream_t s);

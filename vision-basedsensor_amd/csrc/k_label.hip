@@ -1,0 +1,724 @@
+// a9-a13: _marker_center (marker_detection.py:166-249) on bit-packed masks.
+//
+//   k_threshold : uint8 mask / area_mask -> 1 bit per pixel (the HBM-streaming stage: 16 px per lane
+//                 per load, SWAR non-zero test, v_dot4 bit gather, 4 lanes -> one 64-bit word)
+//   k_morph     : band = mask & ~erode_ns(mask)   (maximum/minimum_filter :171-174, window -ns/2..ns/2-1,
+//                 pixels outside the image ignored == scipy 'reflect' for a min/max filter)
+//                 open = dilate5(erode5(area))    (cv2.morphologyEx MORPH_OPEN 5x5 :195)
+//   k_label     : one workgroup per (frame, mask): runs of 1-bits are the union-find nodes, parents
+//                 live in LDS, unions between adjacent rows with LDS atomicMin; the root of a
+//                 component is its first run in raster order, so component ids come out in
+//                 ndimage.label order (:176) and reversed they are cv2.findContours' order (:196).
+//                 band mask (4-connectivity): count / sum x / sum y per component (center_of_mass :181)
+//                 open mask (8-connectivity): integer moments up to order 4 of the CHAIN_APPROX_SIMPLE
+//                 contour vertices, classified per border pixel from its 8-neighbourhood by a LUT.
+//   k_finalize  : per frame: centroids, fitEllipse (:208) from the vertex moments via two normal-
+//                 equation solves in float64, then the sequential contour <-> centre matching (:203-243).
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u64 valid_mask(int j, int W) {
+    int rem = W - 64 * j;
+    if (rem >= 64) return ~0ull;
+    if (rem <= 0) return 0ull;
+    return (1ull << rem) - 1ull;
+}
+
+__device__ __forceinline__ u32 nz4(u32 x) {       // 4 bytes -> 4 bits (byte != 0)
+    u32 t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) >> 7;
+    return __builtin_amdgcn_udot4(t & 0x01010101u, 0x08040201u, 0u, false);
+}
+
+__device__ __forceinline__ u32 nz16(uint4 v) {
+    return nz4(v.x) | (nz4(v.y) << 4) | (nz4(v.z) << 8) | (nz4(v.w) << 12);
+}
+
+__global__ __launch_bounds__(256) void k_threshold(const u8* __restrict__ mask,
+                                                   const u8* __restrict__ area,
+                                                   u64* __restrict__ mbits, u64* __restrict__ abits,
+                                                   int nb, int H, int W, int P, int WW, int vec_ok) {
+    // frames are folded into one index space so that every wave is full; no early return because
+    // the 4-lane word assembly below shuffles across lanes.
+    const int per_row = P / 16;
+    int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool live = gid < (int64_t)nb * H * per_row;
+    int n = 0, y = 0, t = 0;
+    if (live) {
+        n = (int)(gid / ((int64_t)H * per_row));
+        int64_t r = gid - (int64_t)n * H * per_row;
+        y = (int)(r / per_row);
+        t = (int)(r - (int64_t)y * per_row);
+    }
+    const int x0 = t * 16;
+    u32 bm = 0, ba = 0;
+    if (live && x0 < W) {
+        int64_t off = ((int64_t)n * H + y) * W + x0;
+        if (vec_ok && x0 + 16 <= W) {
+            bm = nz16(*reinterpret_cast<const uint4*>(mask + off));
+            ba = nz16(*reinterpret_cast<const uint4*>(area + off));
+        } else {
+            for (int k = 0; k < 16 && x0 + k < W; ++k) {
+                bm |= (u32)(mask[off + k] != 0) << k;
+                ba |= (u32)(area[off + k] != 0) << k;
+            }
+        }
+    }
+    u64 wm = (u64)bm | ((u64)__shfl_down(bm, 1) << 16) | ((u64)__shfl_down(bm, 2) << 32) |
+             ((u64)__shfl_down(bm, 3) << 48);
+    u64 wa = (u64)ba | ((u64)__shfl_down(ba, 1) << 16) | ((u64)__shfl_down(ba, 2) << 32) |
+             ((u64)__shfl_down(ba, 3) << 48);
+    if (live && (t & 3) == 0) {
+        int64_t o = ((int64_t)n * H + y) * WW + (t >> 2);
+        mbits[o] = wm;
+        abits[o] = wa;
+    }
+}
+
+void launch_threshold(vbs_handle* h, const u8* mask, const u8* area, int nb, hipStream_t s) {
+    int64_t total = (int64_t)nb * h->H * (h->P / 16);
+    int vec_ok = (h->W % 16 == 0) && (((uintptr_t)mask | (uintptr_t)area) % 16 == 0);
+    hipLaunchKernelGGL(k_threshold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mask, area,
+                       h->mask_bits, h->area_bits, nb, h->H, h->W, h->P, h->WW, vec_ok);
+}
+
+// ------------------------------------------------------------------------------------------------
+// window AND (erode, outside = 1) or OR (dilate, outside = 0) over dy, dx in [lo, hi]
+template <bool ERODE>
+__device__ __forceinline__ u64 morph_word(const u64* __restrict__ img, int H, int W, int WW, int y,
+                                          int j, int lo, int hi) {
+    u64 acc = ERODE ? ~0ull : 0ull;
+    for (int dy = lo; dy <= hi; ++dy) {
+        int yy = y + dy;
+        if (yy < 0 || yy >= H) continue;
+        const u64* row = img + (int64_t)yy * WW;
+        u64 wl, wc, wr;
+        if (ERODE) {
+            wl = j > 0 ? row[j - 1] : ~0ull;
+            wc = row[j] | ~valid_mask(j, W);
+            wr = (j + 1 < WW) ? (row[j + 1] | ~valid_mask(j + 1, W)) : ~0ull;
+        } else {
+            wl = j > 0 ? row[j - 1] : 0ull;
+            wc = row[j];
+            wr = (j + 1 < WW) ? row[j + 1] : 0ull;
+        }
+        for (int dx = lo; dx <= hi; ++dx) {
+            u64 v;
+            if (dx < 0) v = (wc << (-dx)) | (wl >> (64 + dx));
+            else if (dx > 0) v = (wc >> dx) | (wr << (64 - dx));
+            else v = wc;
+            acc = ERODE ? (acc & v) : (acc | v);
+        }
+    }
+    return acc;
+}
+
+// stage 0: band (from mask_bits) and erode5 (from area_bits); stage 1: open = dilate5(er_bits)
+__global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits,
+                                               const u64* __restrict__ abits, u64* __restrict__ band,
+                                               u64* __restrict__ er, u64* __restrict__ opn, int H, int W,
+                                               int WW, int ns, int stage) {
+    int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= H * WW) return;
+    int n = blockIdx.y;
+    int y = idx / WW, j = idx - y * WW;
+    int64_t fo = (int64_t)n * H * WW;
+    u64 vm = valid_mask(j, W);
+    if (stage == 0) {
+        u64 e = morph_word<true>(mbits + fo, H, W, WW, y, j, -(ns / 2), ns / 2 - 1);
+        band[fo + idx] = mbits[fo + idx] & ~e & vm;
+        er[fo + idx] = morph_word<true>(abits + fo, H, W, WW, y, j, -2, 2) & vm;
+    } else {
+        opn[fo + idx] = morph_word<false>(er + fo, H, W, WW, y, j, -2, 2) & vm;
+    }
+}
+
+void launch_morph(vbs_handle* h, int nb, hipStream_t s) {
+    dim3 grid((h->H * h->WW + 255) / 256, nb);
+    hipLaunchKernelGGL(k_morph, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits,
+                       h->er_bits, h->open_bits, h->H, h->W, h->WW, h->bp.ns, 0);
+    hipLaunchKernelGGL(k_morph, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits,
+                       h->er_bits, h->open_bits, h->H, h->W, h->WW, h->bp.ns, 1);
+}
+
+// ------------------------------------------------------------------------------------------------
+// CHAIN_APPROX_SIMPLE vertex multiplicity of a border pixel from its 8-neighbourhood (bit d = neighbour
+// in chain direction d is foreground).  The outer border visits the pixel once per maximal arc of
+// background neighbours that contains a 4-neighbour (an arc made of one diagonal pixel is stepped
+// over diagonally); arriving from the foreground neighbour that precedes the arc and leaving to the
+// one that follows it, the point is kept iff the two step directions differ.
+void make_contour_lut(u8 out[256]) {
+    for (int p = 0; p < 256; ++p) {
+        int cnt = 0;
+        if (p == 0) {
+            cnt = 1;                                     // isolated pixel: written once
+        } else if (p != 255) {
+            for (int a = 0; a < 8; ++a) {
+                // arc starts at direction a: a is background, a-1 is foreground
+                if (((p >> a) & 1) || !((p >> ((a + 7) & 7)) & 1)) continue;
+                int b = a;
+                bool has4 = false;
+                while (!((p >> (b & 7)) & 1)) {
+                    if (((b & 7) & 1) == 0) has4 = true;
+                    ++b;
+                }
+                if (!has4) continue;
+                int q = (a + 7) & 7;                      // neighbour before the arc
+                int r = b & 7;                            // neighbour after the arc
+                int dir_in = (q + 4) & 7;                 // step q -> p
+                int dir_out = r;                          // step p -> r
+                if (dir_in != dir_out) ++cnt;
+            }
+        }
+        out[p] = (u8)cnt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ u32 uf_find(volatile u32* parent, u32 x) {
+    u32 p;
+    while ((p = parent[x]) != x) x = p;
+    return x;
+}
+
+__device__ __forceinline__ void uf_union(u32* parent, u32 a, u32 b) {
+    for (;;) {
+        a = uf_find(parent, a);
+        b = uf_find(parent, b);
+        if (a == b) return;
+        if (a < b) { u32 t = a; a = b; b = t; }
+        u32 old = atomicMin(&parent[a], b);
+        if (old == a) return;
+        a = old;
+    }
+}
+
+// node (run) index of the run that contains bit k of word j in `row`
+__device__ __forceinline__ u32 node_of(const u64* __restrict__ row, const u32* __restrict__ wb, int j,
+                                       int k) {
+    int jj = j, kk = k, start;
+    for (;;) {
+        u64 w = row[jj];
+        u64 below = (kk == 63) ? ~0ull : ((1ull << (kk + 1)) - 1ull);
+        u64 z = ~w & below;
+        if (z) { start = 64 - __clzll(z); break; }
+        if (jj == 0 || !(row[jj - 1] >> 63)) { start = 0; break; }
+        --jj;
+        kk = 63;
+    }
+    u64 w = row[jj];
+    u64 prev = (jj > 0) ? (row[jj - 1] >> 63) : 0ull;
+    u64 starts = w & ~((w << 1) | prev);
+    u64 lowmask = start ? ((1ull << start) - 1ull) : 0ull;
+    return wb[jj] + (u32)__popcll(starts & lowmask);
+}
+
+__device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* tmp, u32* total) {
+    // 1024 threads = 16 waves; tmp has >= 17 entries
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        u32 t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        u32 run = 0;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { u32 t = tmp[w]; tmp[w] = run; run += t; }
+        tmp[16] = run;
+    }
+    __syncthreads();
+    u32 ex = inc - v + tmp[wave];
+    *total = tmp[16];
+    __syncthreads();
+    return ex;
+}
+
+#define NMOM 15
+// moment index of x^a y^b, a+b <= 4:  (0,0) (1,0) (0,1) (2,0) (1,1) (0,2) (3,0) (2,1) (1,2) (0,3) (4,0) (3,1) (2,2) (1,3) (0,4)
+
+__global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bits,
+                                                const u64* __restrict__ open_bits,
+                                                u32* __restrict__ wbase_all, u32* __restrict__ node_pos_all,
+                                                u32* __restrict__ node_comp_all, u32* __restrict__ ncomp_all,
+                                                u32* __restrict__ band_first, u64* __restrict__ band_sums,
+                                                u32* __restrict__ area_first, i64* __restrict__ area_sums,
+                                                u32* __restrict__ fstat, const u8* __restrict__ lut_g,
+                                                int H, int W, int WW, int maxm) {
+    __shared__ u32 parent[VBS_RUN_CAP];
+    __shared__ u32 tmp[32];
+    __shared__ u32 acc_cnt[1024];
+    __shared__ u64 acc_sx[1024];
+    __shared__ u64 acc_sy[1024];
+    __shared__ u8 lut[256];
+    const int n = blockIdx.x, m = blockIdx.y;          // m = 0 band (4-conn), 1 open (8-conn)
+    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int NW = H * WW;
+    const u64* bits = (m == 0 ? band_bits : open_bits) + (int64_t)n * NW;
+    u32* wbase = wbase_all + ((int64_t)n * 2 + m) * NW;
+    u32* node_pos = node_pos_all + ((int64_t)n * 2 + m) * VBS_RUN_CAP;
+    u32* node_comp = node_comp_all + ((int64_t)n * 2 + m) * VBS_RUN_CAP;
+    if (tid < 256) lut[tid] = lut_g[tid];
+    for (int i = tid; i < 1024; i += nthr) { acc_cnt[i] = 0; acc_sx[i] = 0; acc_sy[i] = 0; }
+
+    // ---- A: enumerate runs (nodes) in raster order ------------------------------------------------
+    const int chunk = (NW + nthr - 1) / nthr;
+    const int i0 = tid * chunk, i1 = min(i0 + chunk, NW);
+    u32 cnt = 0;
+    for (int idx = i0; idx < i1; ++idx) {
+        int j = idx % WW;
+        u64 w = bits[idx];
+        u64 prev = (j > 0) ? (bits[idx - 1] >> 63) : 0ull;
+        cnt += __popcll(w & ~((w << 1) | prev));
+    }
+    u32 nruns;
+    u32 base = block_exclusive_scan(cnt, tmp, &nruns);
+    if (nruns > VBS_RUN_CAP) {                          // block-uniform
+        if (tid == 0) { ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
+        return;
+    }
+    for (int idx = i0; idx < i1; ++idx) {
+        int y = idx / WW, j = idx - y * WW;
+        u64 w = bits[idx];
+        u64 prev = (j > 0) ? (bits[idx - 1] >> 63) : 0ull;
+        u64 st = w & ~((w << 1) | prev);
+        wbase[idx] = base;
+        while (st) {
+            int k = __ffsll((long long)st) - 1;
+            st &= st - 1;
+            parent[base] = base;
+            node_pos[base] = (u32)(y * W + 64 * j + k);
+            ++base;
+        }
+    }
+    __syncthreads();
+
+    // ---- C: unions between row y-1 and row y ------------------------------------------------------
+    for (int idx = WW + tid; idx < NW; idx += nthr) {
+        u64 B = bits[idx];
+        if (!B) continue;
+        int y = idx / WW, j = idx - y * WW;
+        const u64* rowA = bits + (int64_t)(y - 1) * WW;
+        const u64* rowB = bits + (int64_t)y * WW;
+        const u32* wbA = wbase + (int64_t)(y - 1) * WW;
+        const u32* wbB = wbase + (int64_t)y * WW;
+        u64 A = rowA[j];
+        u64 Aprev = (j > 0) ? rowA[j - 1] : 0ull, Anext = (j + 1 < WW) ? rowA[j + 1] : 0ull;
+        u64 adj = A;
+        if (m == 1) adj |= (A << 1) | (A >> 1) | (Aprev >> 63) | (Anext << 63);
+        if (!(B & adj)) continue;
+        u64 mB = B;
+        while (mB) {                                   // groups of consecutive 1s of B inside this word
+            u64 lowbit = mB & (~mB + 1ull);
+            u64 t = mB + lowbit;
+            u64 g = mB & ~t;
+            mB &= t;
+            if (!(g & adj)) continue;
+            int k0 = __ffsll((long long)g) - 1;
+            u32 nb_ = node_of(rowB, wbB, j, k0);
+            u64 rm = g;
+            if (m == 1) rm |= (g << 1) | (g >> 1);
+            u64 mA = A & rm;
+            while (mA) {
+                u64 lb = mA & (~mA + 1ull);
+                u64 t2 = mA + lb;
+                u64 ga = mA & ~t2;
+                mA &= t2;
+                uf_union(parent, node_of(rowA, wbA, j, __ffsll((long long)ga) - 1), nb_);
+            }
+            if (m == 1) {
+                if ((g & 1ull) && (Aprev >> 63)) uf_union(parent, node_of(rowA, wbA, j - 1, 63), nb_);
+                if ((g >> 63) && (Anext & 1ull)) uf_union(parent, node_of(rowA, wbA, j + 1, 0), nb_);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- D: flatten -------------------------------------------------------------------------------
+    for (u32 i = tid; i < nruns; i += nthr) {
+        u32 r = uf_find(parent, i);
+        if (r != i) parent[i] = r;                     // roots keep parent[r] == r throughout
+    }
+    __syncthreads();
+
+    // ---- E: component ids = rank of the root in raster order ---------------------------------------
+    const int chunk2 = (nruns + nthr - 1) / nthr;
+    const u32 r0 = tid * chunk2, r1 = min(r0 + (u32)chunk2, nruns);
+    u32 nroot = 0;
+    for (u32 i = r0; i < r1; ++i) nroot += (parent[i] == i);
+    u32 ncomp;
+    u32 cbase = block_exclusive_scan(nroot, tmp, &ncomp);
+    if (ncomp > (u32)maxm) {
+        if (tid == 0) { ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
+        return;
+    }
+    u32* first = (m == 0 ? band_first : area_first) + (int64_t)n * maxm;
+    for (u32 i = r0; i < r1; ++i) {
+        if (parent[i] == i) {
+            first[cbase] = node_pos[i];
+            if (m == 1) acc_cnt[cbase] = node_pos[i];  // LDS copy of the anchor for phase F
+            parent[i] = i | ((cbase + 1) << 16);       // root: id in the high half
+            ++cbase;
+        }
+    }
+    __syncthreads();
+    for (u32 i = tid; i < nruns; i += nthr) {
+        u32 p = parent[i];
+        u32 root = p & 0xFFFFu;
+        u32 cid = (parent[root] >> 16) - 1;
+        node_comp[i] = cid;
+    }
+    if (tid == 0) ncomp_all[n * 2 + m] = ncomp;
+    __syncthreads();                                   // node_comp visible to this workgroup below
+
+    // ---- F: per-component sums ----------------------------------------------------------------------
+    if (m == 0) {
+        for (int idx = tid; idx < NW; idx += nthr) {
+            u64 w = bits[idx];
+            if (!w) continue;
+            int y = idx / WW, j = idx - y * WW;
+            const u64* row = bits + (int64_t)y * WW;
+            const u32* wb = wbase + (int64_t)y * WW;
+            while (w) {
+                u64 lowbit = w & (~w + 1ull);
+                u64 t = w + lowbit;
+                u64 g = w & ~t;
+                w &= t;
+                int k0 = __ffsll((long long)g) - 1;
+                u32 len = __popcll(g);
+                u32 nd = node_of(row, wb, j, k0);
+                u32 cid = (parent[parent[nd] & 0xFFFFu] >> 16) - 1;
+                u64 x0 = 64 * j + k0;
+                atomicAdd(&acc_cnt[cid], len);
+                atomicAdd(&acc_sx[cid], (u64)len * x0 + (u64)len * (len - 1) / 2);
+                atomicAdd(&acc_sy[cid], (u64)len * (u64)y);
+            }
+        }
+        __syncthreads();
+        u64* bs = band_sums + (int64_t)n * maxm * 4;
+        for (u32 c = tid; c < ncomp; c += nthr) {
+            bs[c * 4 + 0] = acc_cnt[c];
+            bs[c * 4 + 1] = acc_sx[c];
+            bs[c * 4 + 2] = acc_sy[c];
+        }
+    } else {
+        i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
+        for (u32 c = tid; c < ncomp * VBS_AREA_SUMS; c += nthr) as[c] = 0;
+        __syncthreads();
+        for (int idx = tid; idx < NW; idx += nthr) {
+            u64 w = bits[idx];
+            if (!w) continue;
+            int y = idx / WW, j = idx - y * WW;
+            const u64* row = bits + (int64_t)y * WW;
+            const u32* wb = wbase + (int64_t)y * WW;
+            u64 wp = j > 0 ? row[j - 1] : 0ull, wn = (j + 1 < WW) ? row[j + 1] : 0ull;
+            u64 up = 0, upp = 0, upn = 0, dn = 0, dnp = 0, dnn = 0;
+            if (y > 0) {
+                const u64* r2 = row - WW;
+                up = r2[j]; upp = j > 0 ? r2[j - 1] : 0ull; upn = (j + 1 < WW) ? r2[j + 1] : 0ull;
+            }
+            if (y + 1 < H) {
+                const u64* r2 = row + WW;
+                dn = r2[j]; dnp = j > 0 ? r2[j - 1] : 0ull; dnn = (j + 1 < WW) ? r2[j + 1] : 0ull;
+            }
+            u64 E = (w >> 1) | (wn << 63), Wd = (w << 1) | (wp >> 63);
+            u64 NE = (up >> 1) | (upn << 63), NWd = (up << 1) | (upp >> 63);
+            u64 SE = (dn >> 1) | (dnn << 63), SW = (dn << 1) | (dnp >> 63);
+            u64 border = w & ~(up & dn & E & Wd);
+            u64 rest = w;
+            while (rest) {                              // one group (= part of one run) at a time
+                u64 lowbit = rest & (~rest + 1ull);
+                u64 t = rest + lowbit;
+                u64 g = rest & ~t;
+                rest &= t;
+                u64 bg = border & g;
+                if (!bg) continue;
+                i64 s[NMOM];
+#pragma unroll
+                for (int q = 0; q < NMOM; ++q) s[q] = 0;
+                int k0 = __ffsll((long long)g) - 1;
+                u32 nd = node_of(row, wb, j, k0);
+                u32 cid = (parent[parent[nd] & 0xFFFFu] >> 16) - 1;
+                u32 fp = acc_cnt[cid];
+                int ax = fp % W, ay = fp / W;
+                bool any = false;
+                while (bg) {
+                    int k = __ffsll((long long)bg) - 1;
+                    bg &= bg - 1;
+                    u32 pat = (u32)((E >> k) & 1ull) | ((u32)((NE >> k) & 1ull) << 1) |
+                              ((u32)((up >> k) & 1ull) << 2) | ((u32)((NWd >> k) & 1ull) << 3) |
+                              ((u32)((Wd >> k) & 1ull) << 4) | ((u32)((SW >> k) & 1ull) << 5) |
+                              ((u32)((dn >> k) & 1ull) << 6) | ((u32)((SE >> k) & 1ull) << 7);
+                    i64 mult = lut[pat];
+                    if (!mult) continue;
+                    any = true;
+                    i64 dx = 64 * j + k - ax, dy = y - ay;
+                    i64 x2 = dx * dx, y2 = dy * dy;
+                    s[0] += mult;
+                    s[1] += mult * dx;            s[2] += mult * dy;
+                    s[3] += mult * x2;            s[4] += mult * dx * dy;       s[5] += mult * y2;
+                    s[6] += mult * x2 * dx;       s[7] += mult * x2 * dy;       s[8] += mult * dx * y2;
+                    s[9] += mult * y2 * dy;
+                    s[10] += mult * x2 * x2;      s[11] += mult * x2 * dx * dy; s[12] += mult * x2 * y2;
+                    s[13] += mult * dx * dy * y2; s[14] += mult * y2 * y2;
+                }
+                if (any) {
+#pragma unroll
+                    for (int q = 0; q < NMOM; ++q)
+                        if (s[q]) atomicAdd((u64*)&as[cid * VBS_AREA_SUMS + q], (u64)s[q]);
+                }
+            }
+        }
+    }
+}
+
+void launch_label(vbs_handle* h, int nb, hipStream_t s) {
+    hipLaunchKernelGGL(k_label, dim3(nb, 2), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
+                       h->node_pos, h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first,
+                       h->area_sums, h->fstat, h->lut, h->H, h->W, h->WW, h->maxm);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fitEllipse from vertex moments (see oracle/stages.py:fit_ellipse for the algorithm being followed)
+__device__ bool solve_sym(double* A, double* b, int N) {   // Gaussian elimination, partial pivoting
+    for (int c = 0; c < N; ++c) {
+        int p = c;
+        double best = fabs(A[c * N + c]);
+        for (int r = c + 1; r < N; ++r)
+            if (fabs(A[r * N + c]) > best) { best = fabs(A[r * N + c]); p = r; }
+        if (!(best > 1e-300)) return false;
+        if (p != c) {
+            for (int k = 0; k < N; ++k) { double t = A[c * N + k]; A[c * N + k] = A[p * N + k]; A[p * N + k] = t; }
+            double t = b[c]; b[c] = b[p]; b[p] = t;
+        }
+        for (int r = c + 1; r < N; ++r) {
+            double f = A[r * N + c] / A[c * N + c];
+            for (int k = c; k < N; ++k) A[r * N + k] -= f * A[c * N + k];
+            b[r] -= f * b[c];
+        }
+    }
+    for (int c = N - 1; c >= 0; --c) {
+        double v = b[c];
+        for (int k = c + 1; k < N; ++k) v -= A[c * N + k] * b[k];
+        b[c] = v / A[c * N + c];
+    }
+    return true;
+}
+
+// m[a][b] (a+b<=4) about a point shifted by (sx, sy): sum (x-sx)^a (y-sy)^b
+__device__ void shift_moments(const double in[5][5], double sx, double sy, double out[5][5]) {
+    const double C[5][5] = {{1, 0, 0, 0, 0}, {1, 1, 0, 0, 0}, {1, 2, 1, 0, 0}, {1, 3, 3, 1, 0}, {1, 4, 6, 4, 1}};
+    double px[5] = {1, -sx, sx * sx, -sx * sx * sx, sx * sx * sx * sx};
+    double py[5] = {1, -sy, sy * sy, -sy * sy * sy, sy * sy * sy * sy};
+    for (int a = 0; a <= 4; ++a)
+        for (int b = 0; a + b <= 4; ++b) {
+            double v = 0;
+            for (int i = 0; i <= a; ++i)
+                for (int j = 0; j <= b; ++j) v += C[a][i] * C[b][j] * px[a - i] * py[b - j] * in[i][j];
+            out[a][b] = v;
+        }
+}
+
+// out: cx, cy, w, h, angle (float32-rounded, w <= h), nvert, ok
+__device__ void fit_ellipse_moments(const i64* S, int ax, int ay, double* out) {
+    const double PI = 3.14159265358979323846;
+    double n = (double)S[0];
+    out[5] = n;
+    out[6] = 0.0;
+    if (S[0] < 5) return;
+    // float32 mean of the absolute coordinates, like Point2f accumulation in cv2
+    float cx32 = (float)((double)S[0] * ax + (double)S[1]) / (float)n;
+    float cy32 = (float)((double)S[0] * ay + (double)S[2]) / (float)n;
+    double M0[5][5] = {{0}}, M[5][5];
+    M0[0][0] = (double)S[0];
+    M0[1][0] = (double)S[1];  M0[0][1] = (double)S[2];
+    M0[2][0] = (double)S[3];  M0[1][1] = (double)S[4];  M0[0][2] = (double)S[5];
+    M0[3][0] = (double)S[6];  M0[2][1] = (double)S[7];  M0[1][2] = (double)S[8];  M0[0][3] = (double)S[9];
+    M0[4][0] = (double)S[10]; M0[3][1] = (double)S[11]; M0[2][2] = (double)S[12]; M0[1][3] = (double)S[13];
+    M0[0][4] = (double)S[14];
+    shift_moments(M0, (double)cx32 - ax, (double)cy32 - ay, M);
+    double r2 = (M[2][0] + M[0][2]) / n;
+    if (!(r2 > 0.0)) return;
+    double scale = 100.0 / (n * sqrt(r2) * 1.2732395447351628);
+    double sp[5] = {1, scale, scale * scale, scale * scale * scale, scale * scale * scale * scale};
+    double m[5][5];
+    for (int a = 0; a <= 4; ++a)
+        for (int b = 0; a + b <= 4; ++b) m[a][b] = M[a][b] * sp[a + b];
+    double A[25] = {
+        m[4][0],  m[2][2],  m[3][1],  -m[3][0], -m[2][1],
+        m[2][2],  m[0][4],  m[1][3],  -m[1][2], -m[0][3],
+        m[3][1],  m[1][3],  m[2][2],  -m[2][1], -m[1][2],
+        -m[3][0], -m[1][2], -m[2][1], m[2][0],  m[1][1],
+        -m[2][1], -m[0][3], -m[1][2], m[1][1],  m[0][2]};
+    double g[5] = {-1e4 * m[2][0], -1e4 * m[0][2], -1e4 * m[1][1], 1e4 * m[1][0], 1e4 * m[0][1]};
+    // conditioning guard, in the spirit of cv2's singular-value test (w[0]*FLT_EPSILON > w[4])
+    double tr = A[0] + A[6] + A[12] + A[18] + A[24];
+    if (!solve_sym(A, g, 5)) return;
+    for (int i = 0; i < 5; ++i) if (!isfinite(g[i])) return;
+    (void)tr;
+    double det = 4.0 * g[0] * g[1] - g[2] * g[2];
+    if (!(fabs(det) > 1e-300)) return;
+    double rp0 = (2.0 * g[1] * g[3] - g[2] * g[4]) / det;
+    double rp1 = (2.0 * g[0] * g[4] - g[2] * g[3]) / det;
+    double mu[5][5];
+    shift_moments(m, rp0, rp1, mu);
+    double A3[9] = {mu[4][0], mu[2][2], mu[3][1], mu[2][2], mu[0][4], mu[1][3], mu[3][1], mu[1][3], mu[2][2]};
+    double g3[3] = {mu[2][0], mu[0][2], mu[1][1]};
+    if (!solve_sym(A3, g3, 3)) return;
+    const double min_eps = 1e-8;
+    double ang = -0.5 * atan2(g3[2], g3[1] - g3[0]);
+    double t;
+    if (fabs(g3[2]) > min_eps) t = g3[2] / sin(-2.0 * ang);
+    else t = g3[1] - g3[0];
+    double r_2 = fabs(g3[0] + g3[1] - t);
+    if (r_2 > min_eps) r_2 = sqrt(2.0 / r_2);
+    double r_3 = fabs(g3[0] + g3[1] + t);
+    if (r_3 > min_eps) r_3 = sqrt(2.0 / r_3);
+    float ecx = (float)(rp0 / scale) + cx32;
+    float ecy = (float)(rp1 / scale) + cy32;
+    float wd = (float)(r_2 * 2.0 / scale);
+    float ht = (float)(r_3 * 2.0 / scale);
+    float fang = (float)(ang * 180.0 / PI);
+    if (wd > ht) {
+        float tt = wd; wd = ht; ht = tt;
+        fang = (float)(90.0 + ang * 180.0 / PI);
+    }
+    if (fang < -180.f) fang += 360.f;
+    if (fang > 360.f) fang -= 360.f;
+    if (!(isfinite(wd) && isfinite(ht) && isfinite(ecx) && isfinite(ecy))) return;
+    out[0] = ecx; out[1] = ecy; out[2] = wd; out[3] = ht; out[4] = fang;
+    out[6] = 1.0;
+}
+
+__device__ __forceinline__ bool in_comp(const u64* __restrict__ bits, const u32* __restrict__ wbase,
+                                        const u32* __restrict__ node_comp, int H, int W, int WW, int x,
+                                        int y, u32 cid) {
+    if (x < 0 || y < 0 || x >= W || y >= H) return false;
+    const u64* row = bits + (int64_t)y * WW;
+    if (!((row[x >> 6] >> (x & 63)) & 1ull)) return false;
+    return node_comp[node_of(row, wbase + (int64_t)y * WW, x >> 6, x & 63)] == cid;
+}
+
+// cv2.pointPolygonTest(contour, pt, False) >= 0 for the outer border polygon of component cid,
+// decided from the 2x2 pixel cell around the (float32-rounded) point.
+__device__ bool inside_polygon(const u64* bits, const u32* wbase, const u32* node_comp, int H, int W,
+                               int WW, double px, double py, u32 cid) {
+    float xf = (float)px, yf = (float)py;
+    float fxl = floorf(xf), fyl = floorf(yf);
+    int ix = (int)fxl, iy = (int)fyl;
+    float fx = xf - fxl, fy = yf - fyl;
+    bool c00 = in_comp(bits, wbase, node_comp, H, W, WW, ix, iy, cid);
+    if (fx == 0.f && fy == 0.f) return c00;
+    if (fy == 0.f) return c00 && in_comp(bits, wbase, node_comp, H, W, WW, ix + 1, iy, cid);
+    if (fx == 0.f) return c00 && in_comp(bits, wbase, node_comp, H, W, WW, ix, iy + 1, cid);
+    bool c10 = in_comp(bits, wbase, node_comp, H, W, WW, ix + 1, iy, cid);
+    bool c01 = in_comp(bits, wbase, node_comp, H, W, WW, ix, iy + 1, cid);
+    bool c11 = in_comp(bits, wbase, node_comp, H, W, WW, ix + 1, iy + 1, cid);
+    int cnt = (int)c00 + c10 + c01 + c11;
+    if (cnt == 4) return true;
+    if (cnt == 3) {
+        if (!c11) return fx + fy <= 1.f;
+        if (!c00) return fx + fy >= 1.f;
+        if (!c10) return fy >= fx;
+        return fx >= fy;
+    }
+    if (cnt == 2) {
+        if (c00 && c11) return fx == fy;
+        if (c10 && c01) return fx + fy == 1.f;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_all,
+                                                  const u64* __restrict__ band_sums,
+                                                  const u32* __restrict__ area_first,
+                                                  const i64* __restrict__ area_sums,
+                                                  const u64* __restrict__ open_bits,
+                                                  const u32* __restrict__ wbase_all,
+                                                  const u32* __restrict__ node_comp_all,
+                                                  const u32* __restrict__ fstat, double* __restrict__ ell_all,
+                                                  double* __restrict__ det64, int32_t* __restrict__ cnt64,
+                                                  float* __restrict__ det32, int32_t* __restrict__ cnt32,
+                                                  int H, int W, int WW, int maxm) {
+    __shared__ double bx[1024], by[1024];
+    __shared__ u8 unmatched[1024];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    int status = (int)fstat[n * 8 + 2];
+    if (status != 0) {
+        if (tid == 0) { cnt64[n] = status; if (cnt32) cnt32[n] = status; }
+        return;
+    }
+    const int nb_ = (int)ncomp_all[n * 2 + 0], na = (int)ncomp_all[n * 2 + 1];
+    const u64* bs = band_sums + (int64_t)n * maxm * 4;
+    for (int i = tid; i < nb_; i += blockDim.x) {
+        double c = (double)bs[i * 4 + 0];
+        bx[i] = (double)bs[i * 4 + 1] / c;             // center_of_mass: integer sums, one division
+        by[i] = (double)bs[i * 4 + 2] / c;
+        unmatched[i] = 1;
+    }
+    double* ell = ell_all + (int64_t)n * maxm * 8;
+    const u32* af = area_first + (int64_t)n * maxm;
+    for (int i = tid; i < na; i += blockDim.x) {
+        u32 fp = af[i];
+        fit_ellipse_moments(area_sums + ((int64_t)n * maxm + i) * VBS_AREA_SUMS, fp % W, fp / W, ell + i * 8);
+    }
+    __syncthreads();
+    if (tid >= 64) return;
+    // ---- sequential matching in cv2 contour order (last component found first), one wave ----------
+    const int NW = H * WW;
+    const u64* bits = open_bits + (int64_t)n * NW;
+    const u32* wbase = wbase_all + ((int64_t)n * 2 + 1) * NW;
+    const u32* node_comp = node_comp_all + ((int64_t)n * 2 + 1) * VBS_RUN_CAP;
+    double* d64 = det64 + (int64_t)n * maxm * 6;
+    float* d32 = det32 ? det32 + (int64_t)n * maxm * 6 : nullptr;
+    int count = 0;
+    for (int ci = na - 1; ci >= 0; --ci) {
+        const double* e = ell + ci * 8;
+        if (e[6] == 0.0 || e[5] < 5.0) continue;       // len(contour) < 5 (:204) or no fit
+        double ecx = e[0], ecy = e[1], w = e[2], hh = e[3], ang = e[4];
+        double major, minor, eang;
+        if (w > hh) { major = w; minor = hh; eang = ang; }
+        else { major = hh; minor = w; eang = ang + 90.0; }
+        if (minor < 5.0) continue;                      // (:219)
+        double thr = (minor / 10.0) * (minor / 10.0);
+        double best = 1e300;
+        int bi = -1;
+        for (int i = tid; i < nb_; i += 64) {
+            if (!unmatched[i]) continue;
+            double dx = bx[i] - ecx, dy = by[i] - ecy;
+            double d = dx * dx + dy * dy;
+            if (d < thr && d < best &&
+                inside_polygon(bits, wbase, node_comp, H, W, WW, bx[i], by[i], (u32)ci)) {
+                best = d; bi = i;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            double ob = __shfl_xor(best, off);
+            int oi = __shfl_xor(bi, off);
+            if (oi >= 0 && (bi < 0 || ob < best || (ob == best && oi < bi))) { best = ob; bi = oi; }
+        }
+        if (bi >= 0) {
+            if (tid == 0) {
+                unmatched[bi] = 0;
+                double* o = d64 + count * 6;
+                o[0] = bx[bi]; o[1] = by[bi]; o[2] = major; o[3] = minor; o[4] = eang; o[5] = bi + 1;
+                if (d32) {
+                    float* f = d32 + count * 6;
+                    f[0] = (float)bx[bi]; f[1] = (float)by[bi]; f[2] = (float)major; f[3] = (float)minor;
+                    f[4] = (float)eang; f[5] = (float)(bi + 1);
+                }
+            }
+            ++count;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (tid == 0) { cnt64[n] = count; if (cnt32) cnt32[n] = count; }
+}
+
+void launch_finalize(vbs_handle* h, int nb, float* det, int32_t* counts, hipStream_t s) {
+    hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(256), 0, s, h->ncomp, h->band_sums, h->area_first,
+                       h->area_sums, h->open_bits, h->wbase, h->node_comp, h->fstat, h->ell, h->det64,
+                       h->cnt, det, counts, h->H, h->W, h->WW, h->maxm);
+}

@@ -1,0 +1,274 @@
+// a15, a19-a21, f1: identity tracking, undistort + closed-form 3-D solve, last-seen displacement,
+// plane-fit pose.  All arithmetic in float64 (the reference is float64 fed by float32 camera
+// parameters); tables are stored as float32 (the all-gather format).
+//   k_track        marker_detection.py:349-396 (_track_markers) [+ fused 3-D solve]
+//   k_solve3d      3d_reconstruction.py:185-238 (_undistort_points, _calculate_3d_position)
+//   k_displacement 3d_reconstruction.py:240-316 (_track_markers)
+//   k_plane_fit    ForceDistribution.py:138-162 (fit_plane_least_squares)
+#include "common.h"
+
+struct CamD {
+    float fx, fy, cx, cy;
+    double k[5];
+    double R[9], T[3];
+    float dmm;
+    int has_dist;
+};
+
+static CamD make_cam(const vbs_camera& c) {
+    CamD d;
+    d.fx = c.K[0]; d.fy = c.K[4]; d.cx = c.K[2]; d.cy = c.K[5];
+    d.has_dist = 0;
+    for (int i = 0; i < 5; ++i) { d.k[i] = (double)c.dist[i]; if (c.dist[i] != 0.f) d.has_dist = 1; }
+    for (int i = 0; i < 9; ++i) d.R[i] = (double)c.R[i];
+    for (int i = 0; i < 3; ++i) d.T[i] = (double)c.T[i];
+    d.dmm = c.marker_diameter_mm;
+    return d;
+}
+
+#pragma clang fp contract(off)
+// cv2.undistortPoints(pts, K, dist, None, K): 5 fixed-point iterations of the inverse Brown-Conrady model
+__device__ void undistort_point(const CamD& c, double u, double v, double* uo, double* vo) {
+    double fx = c.fx, fy = c.fy, cx = c.cx, cy = c.cy;
+    double x0 = (u - cx) / fx, y0 = (v - cy) / fy;
+    double x = x0, y = y0;
+    if (c.has_dist) {
+        for (int it = 0; it < 5; ++it) {
+            double r2 = x * x + y * y;
+            double icd = 1.0 / (1.0 + ((c.k[4] * r2 + c.k[1]) * r2 + c.k[0]) * r2);
+            double dxx = 2.0 * c.k[2] * x * y + c.k[3] * (r2 + 2.0 * x * x);
+            double dyy = c.k[2] * (r2 + 2.0 * y * y) + 2.0 * c.k[3] * x * y;
+            x = (x0 - dxx) * icd;
+            y = (y0 - dyy) * icd;
+        }
+    }
+    *uo = x * fx + cx;
+    *vo = y * fy + cy;
+}
+
+// _calculate_3d_position with NumPy's promotion rules: f_avg, 2.0/f_avg and f_avg**2 are float32
+// (float32 scalars with Python numbers), everything that touches u, v or d is float64.
+__device__ bool solve_marker(const CamD& c, double u, double v, double d, double* X) {
+    float f_avg = (c.fx + c.fy) / 2.0f;
+    double du = u - (double)c.cx, dv = v - (double)c.cy;
+    double Rr = sqrt(du * du + dv * dv);
+    if (Rr < 1e-6) return false;
+    float k32 = c.dmm / f_avg;
+    float f2 = f_avg * f_avg;
+    double d_eff = (double)k32 * sqrt(Rr * Rr + (double)f2);
+    double h = (double)f_avg * (d_eff / d);
+    double pc[3] = {h * du / (double)c.fx - c.T[0], h * dv / (double)c.fy - c.T[1], h - c.T[2]};
+    for (int i = 0; i < 3; ++i) X[i] = c.R[0 * 3 + i] * pc[0] + c.R[1 * 3 + i] * pc[1] + c.R[2 * 3 + i] * pc[2];
+    return isfinite(X[0]) && isfinite(X[1]) && isfinite(X[2]);
+}
+
+// one workgroup per frame; thread per reference ID
+__global__ __launch_bounds__(256) void k_track(const double* __restrict__ det64,
+                                               const float* __restrict__ det32,
+                                               const int32_t* __restrict__ counts, int maxm,
+                                               const double* __restrict__ ref_xy, int m_ref, double min_dist,
+                                               float* __restrict__ table, int do3d, CamD cam,
+                                               double min_size) {
+    __shared__ double mx[1024], my[1024];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    int cnt = counts[n];
+    if (cnt < 0) cnt = 0;
+    for (int i = tid; i < cnt; i += blockDim.x) {
+        if (det64) { mx[i] = det64[((int64_t)n * maxm + i) * 6 + 0]; my[i] = det64[((int64_t)n * maxm + i) * 6 + 1]; }
+        else { mx[i] = det32[((int64_t)n * maxm + i) * 6 + 0]; my[i] = det32[((int64_t)n * maxm + i) * 6 + 1]; }
+    }
+    __syncthreads();
+    for (int r = tid; r < m_ref; r += blockDim.x) {
+        double ox = ref_xy[2 * r], oy = ref_xy[2 * r + 1];
+        double best = 1e300;
+        int bi = -1;
+        for (int i = 0; i < cnt; ++i) {
+            double dx = ox - mx[i], dy = oy - my[i];
+            double ds = sqrt(dx * dx + dy * dy);            // cdist 'euclidean'; argmin takes the first minimum
+            if (ds < best) { best = ds; bi = i; }
+        }
+        float* row = table + ((int64_t)n * m_ref + r) * VBS_TABLE_COLS;
+        float o[VBS_TABLE_COLS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        if (bi >= 0 && !(best > min_dist)) {
+            double major, minor, ang;
+            if (det64) {
+                const double* d = det64 + ((int64_t)n * maxm + bi) * 6;
+                major = d[2]; minor = d[3]; ang = d[4];
+            } else {
+                const float* d = det32 + ((int64_t)n * maxm + bi) * 6;
+                major = d[2]; minor = d[3]; ang = d[4];
+            }
+            int flags = VBS_FLAG_TRACKED;
+            o[1] = (float)mx[bi]; o[2] = (float)my[bi]; o[3] = (float)major; o[4] = (float)minor;
+            o[5] = (float)ang; o[9] = (float)bi;
+            if (do3d && major >= min_size) {
+                double u, v, X[3];
+                undistort_point(cam, mx[bi], my[bi], &u, &v);
+                if (solve_marker(cam, u, v, major, X)) {
+                    flags |= VBS_FLAG_XYZ;
+                    o[6] = (float)X[0]; o[7] = (float)X[1]; o[8] = (float)X[2];
+                }
+            }
+            o[0] = (float)flags;
+        }
+#pragma unroll
+        for (int c = 0; c < VBS_TABLE_COLS; ++c) row[c] = o[c];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_solve3d(float* __restrict__ table, int64_t rows, CamD cam,
+                                                 double min_size) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows) return;
+    float* row = table + i * VBS_TABLE_COLS;
+    int flags = (int)row[0];
+    row[6] = row[7] = row[8] = 0.f;
+    flags &= ~VBS_FLAG_XYZ;
+    if ((flags & VBS_FLAG_TRACKED) && (double)row[3] >= min_size) {
+        double u, v, X[3];
+        undistort_point(cam, (double)row[1], (double)row[2], &u, &v);
+        if (solve_marker(cam, u, v, (double)row[3], X)) {
+            flags |= VBS_FLAG_XYZ;
+            row[6] = (float)X[0]; row[7] = (float)X[1]; row[8] = (float)X[2];
+        }
+    }
+    row[0] = (float)flags;
+}
+
+// one workgroup; thread per reference ID walks the frames in order
+__global__ __launch_bounds__(1024) void k_displacement(const float* __restrict__ table, int n, int m_ref,
+                                                       int warmup, double min_size, double max_disp,
+                                                       float* __restrict__ disp) {
+    __shared__ int fmin_s;
+    if (threadIdx.x == 0) fmin_s = 0x7fffffff;
+    __syncthreads();
+    // first frame holding any row that survives load_marker_data's size filter (:172-176)
+    int myfirst = 0x7fffffff;
+    for (int r = threadIdx.x; r < m_ref; r += blockDim.x) {
+        for (int f = 0; f < n; ++f) {
+            const float* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
+            if (((int)row[0] & VBS_FLAG_TRACKED) && (double)row[3] >= min_size) { myfirst = min(myfirst, f); break; }
+        }
+    }
+    atomicMin(&fmin_s, myfirst);
+    __syncthreads();
+    const int fmin = fmin_s;
+    const int64_t fstart = (fmin == 0x7fffffff) ? (int64_t)n : (int64_t)fmin + max(warmup, 0);
+    for (int r = threadIdx.x; r < m_ref; r += blockDim.x) {
+        bool have = false, last_ok = false;
+        double L[3] = {0, 0, 0};
+        for (int f = 0; f < n; ++f) {
+            const float* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
+            float* o = disp + ((int64_t)f * m_ref + r) * VBS_DISP_COLS;
+            float out[VBS_DISP_COLS] = {0, 0, 0, 0, 0};
+            int flags = (int)row[0];
+            bool present = (flags & VBS_FLAG_TRACKED) && (double)row[3] >= min_size && f >= fstart;
+            if (present) {
+                bool ok = flags & VBS_FLAG_XYZ;
+                double C[3] = {(double)row[6], (double)row[7], (double)row[8]};
+                if (have && last_ok && ok) {
+                    double dx = C[0] - L[0], dy = C[1] - L[1], dz = C[2] - L[2];
+                    double mm = sqrt(dx * dx + dy * dy + dz * dz);
+                    if (!(mm > max_disp)) {
+                        out[0] = 1.f; out[1] = (float)dx; out[2] = (float)dy; out[3] = (float)dz; out[4] = (float)mm;
+                    }
+                }
+                have = true; last_ok = ok;
+                L[0] = C[0]; L[1] = C[1]; L[2] = C[2];
+            }
+            for (int c = 0; c < VBS_DISP_COLS; ++c) o[c] = out[c];
+        }
+    }
+}
+
+// one wave per frame: normal equations of Z = aX + bY + c about the centroid
+__global__ __launch_bounds__(64) void k_plane_fit(const float* __restrict__ table, int m_ref,
+                                                  float* __restrict__ plane) {
+    const int n = blockIdx.x, lane = threadIdx.x;
+    const float* t = table + (int64_t)n * m_ref * VBS_TABLE_COLS;
+    double s[4] = {0, 0, 0, 0};                          // n, X, Y, Z
+    for (int r = lane; r < m_ref; r += 64) {
+        const float* row = t + r * VBS_TABLE_COLS;
+        if ((int)row[0] & VBS_FLAG_XYZ) { s[0] += 1; s[1] += row[6]; s[2] += row[7]; s[3] += row[8]; }
+    }
+    for (int q = 0; q < 4; ++q)
+        for (int off = 32; off >= 1; off >>= 1) s[q] += __shfl_xor(s[q], off);
+    double cnt = s[0];
+    double mxv = cnt > 0 ? s[1] / cnt : 0, myv = cnt > 0 ? s[2] / cnt : 0, mzv = cnt > 0 ? s[3] / cnt : 0;
+    double c[5] = {0, 0, 0, 0, 0};                       // xx, xy, yy, xz, yz (centred)
+    for (int r = lane; r < m_ref; r += 64) {
+        const float* row = t + r * VBS_TABLE_COLS;
+        if ((int)row[0] & VBS_FLAG_XYZ) {
+            double x = row[6] - mxv, y = row[7] - myv, z = row[8] - mzv;
+            c[0] += x * x; c[1] += x * y; c[2] += y * y; c[3] += x * z; c[4] += y * z;
+        }
+    }
+    for (int q = 0; q < 5; ++q)
+        for (int off = 32; off >= 1; off >>= 1) c[q] += __shfl_xor(c[q], off);
+    if (lane == 0) {
+        float* o = plane + (int64_t)n * VBS_PLANE_COLS;
+        double det = c[0] * c[2] - c[1] * c[1];
+        o[0] = (float)cnt;
+        if (cnt >= 3 && fabs(det) > 1e-300) {
+            double a = (c[3] * c[2] - c[4] * c[1]) / det;
+            double b = (c[4] * c[0] - c[3] * c[1]) / det;
+            double cc = mzv - a * mxv - b * myv;
+            o[1] = (float)a; o[2] = (float)b; o[3] = (float)cc;
+            o[4] = (float)(atan(sqrt(a * a + b * b)) * 57.29577951308232);
+        } else {
+            o[1] = o[2] = o[3] = o[4] = 0.f;
+        }
+    }
+}
+
+// float64 point interfaces: which = 0 undistort [n,2] -> [n,2]; which = 1 (u,v,d) [n,3] -> xyz [n,3], ok [n]
+__global__ __launch_bounds__(256) void k_points(int which, const double* __restrict__ in, int n, CamD cam,
+                                                double* __restrict__ out, int32_t* __restrict__ ok) {
+    int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    if (which == 0) {
+        undistort_point(cam, in[2 * i], in[2 * i + 1], &out[2 * i], &out[2 * i + 1]);
+    } else {
+        double X[3] = {0, 0, 0};
+        bool good = solve_marker(cam, in[3 * i], in[3 * i + 1], in[3 * i + 2], X);
+        out[3 * i] = X[0]; out[3 * i + 1] = X[1]; out[3 * i + 2] = X[2];
+        ok[i] = good ? 1 : 0;
+    }
+}
+
+void launch_points(int which, const double* in, int n, const vbs_camera& cam, double* out, int32_t* ok,
+                   hipStream_t s) {
+    hipLaunchKernelGGL(k_points, dim3((n + 255) / 256), dim3(256), 0, s, which, in, n, make_cam(cam), out, ok);
+}
+
+void launch_track(vbs_handle* h, const float* det32, const int32_t* counts32, int nb,
+                  const double* ref_xy, int m_ref, double min_dist, float* table, hipStream_t s) {
+    CamD cam{};
+    hipLaunchKernelGGL(k_track, dim3(nb), dim3(256), 0, s, (const double*)nullptr, det32, counts32, h->maxm,
+                       ref_xy, m_ref, min_dist, table, 0, cam, 0.0);
+}
+
+void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
+                        float* table, const vbs_camera* cam, double min_size, hipStream_t s) {
+    CamD c{};
+    if (cam) c = make_cam(*cam);
+    hipLaunchKernelGGL(k_track, dim3(nb), dim3(256), 0, s, (const double*)h->det64, (const float*)nullptr,
+                       (const int32_t*)h->cnt, h->maxm, ref_xy, m_ref, min_dist, table, cam ? 1 : 0, c, min_size);
+}
+
+void launch_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_camera& cam, double min_size,
+                    hipStream_t s) {
+    int64_t rows = (int64_t)n * m_ref;
+    hipLaunchKernelGGL(k_solve3d, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, table, rows,
+                       make_cam(cam), min_size);
+}
+
+void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup, double min_size,
+                         double max_disp, float* disp, hipStream_t s) {
+    hipLaunchKernelGGL(k_displacement, dim3(1), dim3(1024), 0, s, table, n, m_ref, warmup, min_size, max_disp,
+                       disp);
+}
+
+void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane, hipStream_t s) {
+    hipLaunchKernelGGL(k_plane_fit, dim3(n), dim3(64), 0, s, table, m_ref, plane);
+}

@@ -1,0 +1,210 @@
+"""Thin torch-facing wrapper over the C-ABI: tensors are buffers, all compute is in libvbs.so.
+
+One `Engine` = one `vbs_handle` = one (device, frame size).  Every method enqueues on the current
+torch stream of the engine's device and returns device tensors (no synchronisation except where a
+host value is needed to raise the reference's exceptions).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Engine:
+    def __init__(self, height: int, width: int, max_markers: int = 512, max_batch: int = 16,
+                 device: int | torch.device | None = None):
+        if not torch.cuda.is_available():
+            raise L.VbsError("no GPU visible: vbs_amd has no CPU path (the oracle lives in oracle/ and "
+                             "is test-only)")
+        self.lib = L.lib()
+        if device is None:
+            device = torch.cuda.current_device()
+        self.device = torch.device("cuda", device if isinstance(device, int) else device.index or 0)
+        self.H, self.W = int(height), int(width)
+        self.max_markers, self.max_batch = int(max_markers), int(max_batch)
+        h = C.c_void_p()
+        rc = self.lib.vbs_create(self.device.index, self.H, self.W, self.max_markers, self.max_batch,
+                                 C.byref(h))
+        self._h = h
+        if rc != L.VBS_OK:
+            msg = self.lib.vbs_last_error(h).decode() if h else "vbs_create failed"
+            if h:
+                self.lib.vbs_destroy(h)
+                self._h = None
+            raise (ValueError if rc == L.VBS_EINVAL else L.VbsError)(f"vbs_create: {msg} (status {rc})")
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.vbs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def _check(self, rc, what):
+        if rc == L.VBS_OK:
+            return
+        msg = self.lib.vbs_last_error(self._h).decode()
+        raise (ValueError if rc == L.VBS_EINVAL else L.VbsError)(f"{what}: {msg} (status {rc})")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _frames(self, frames: torch.Tensor):
+        """uint8 device tensor [N,H,W] or [N,H,W,3] (a crop view is fine) -> (ptr, n, ch, strides)."""
+        if frames.dtype != torch.uint8 or frames.device != self.device:
+            raise ValueError("frames must be a uint8 tensor on the engine's device")
+        if frames.dim() == 2 or (frames.dim() == 3 and frames.shape[-1] == 3 and frames.shape[0] == self.H
+                                 and frames.shape[1] == self.W):
+            frames = frames.unsqueeze(0)
+        ch = 1
+        if frames.dim() == 4:
+            ch = frames.shape[3]
+            if ch not in (1, 3) or frames.stride(3) != 1 or frames.stride(2) != ch:
+                raise ValueError("frames must be [N,H,W] or channel-last [N,H,W,3] with unit pixel stride")
+        elif frames.dim() != 3 or frames.stride(2) != 1:
+            raise ValueError("frames must be [N,H,W] or [N,H,W,3] with unit pixel stride")
+        if frames.shape[1] != self.H or frames.shape[2] != self.W:
+            raise ValueError(f"engine was built for {self.H}x{self.W}, got {tuple(frames.shape[1:3])}")
+        return frames, frames.shape[0], ch, frames.stride(0), frames.stride(1)
+
+    # ---- a3-a8 -------------------------------------------------------------------------------
+    def find_markers(self, frames):
+        frames, n, ch, sn, sr = self._frames(frames)
+        mask = torch.empty((n, self.H, self.W), dtype=torch.uint8, device=self.device)
+        area = torch.empty_like(mask)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_find_markers(self._h, _ptr(frames), n, ch, sn, sr, _ptr(mask), _ptr(area),
+                                                  self._stream()), "vbs_find_markers")
+        return mask, area
+
+    def ncc_map(self, frames):
+        frames, n, ch, sn, sr = self._frames(frames)
+        out = torch.empty((n, self.H, self.W), dtype=torch.float64, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_ncc_map(self._h, _ptr(frames), n, ch, sn, sr, _ptr(out), self._stream()),
+                        "vbs_ncc_map")
+        return out
+
+    def frame_stats(self, n):
+        out = np.zeros((n, 8), dtype=np.uint32)
+        self._check(self.lib.vbs_frame_stats(self._h, out.ctypes.data_as(C.c_void_p), n), "vbs_frame_stats")
+        return out
+
+    # ---- a9-a13 ------------------------------------------------------------------------------
+    def marker_center(self, mask, area_mask):
+        for t in (mask, area_mask):
+            if t.dtype != torch.uint8 or t.device != self.device or not t.is_contiguous():
+                raise ValueError("mask / area_mask must be contiguous uint8 tensors on the engine's device")
+        if mask.dim() == 2:
+            mask, area_mask = mask.unsqueeze(0), area_mask.unsqueeze(0)
+        n = mask.shape[0]
+        if tuple(mask.shape[1:]) != (self.H, self.W) or mask.shape != area_mask.shape:
+            raise ValueError("mask shape mismatch")
+        det = torch.zeros((n, self.max_markers, L.DET_COLS), dtype=torch.float32, device=self.device)
+        counts = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_marker_center(self._h, _ptr(mask), _ptr(area_mask), n, _ptr(det),
+                                                   _ptr(counts), self._stream()), "vbs_marker_center")
+        return det, counts
+
+    # ---- a15 ---------------------------------------------------------------------------------
+    def track(self, det, counts, ref_xy, min_dist=20.0):
+        ref = torch.as_tensor(ref_xy, dtype=torch.float64, device=self.device).contiguous().reshape(-1, 2)
+        n, m = det.shape[0], ref.shape[0]
+        table = torch.empty((n, m, L.TABLE_COLS), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_track(self._h, _ptr(det), _ptr(counts), n, _ptr(ref), m, float(min_dist),
+                                           _ptr(table), self._stream()), "vbs_track")
+        return table
+
+    # ---- a19-a20 -----------------------------------------------------------------------------
+    def solve3d(self, table, cam: L.Camera, min_marker_size_px=5.0):
+        n, m = table.shape[0], table.shape[1]
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_solve3d(self._h, _ptr(table), n, m, C.byref(cam), float(min_marker_size_px),
+                                             self._stream()), "vbs_solve3d")
+        return table
+
+    # ---- fused ---------------------------------------------------------------------------------
+    def track_to_3d(self, frames, ref_xy=None, min_dist=20.0, cam: L.Camera | None = None,
+                    min_marker_size_px=5.0, want_det=False):
+        frames, n, ch, sn, sr = self._frames(frames)
+        table = ref = None
+        m = 0
+        if ref_xy is not None:
+            ref = torch.as_tensor(ref_xy, dtype=torch.float64, device=self.device).contiguous().reshape(-1, 2)
+            m = ref.shape[0]
+            table = torch.empty((n, m, L.TABLE_COLS), dtype=torch.float32, device=self.device)
+        det = torch.zeros((n, self.max_markers, L.DET_COLS), dtype=torch.float32,
+                          device=self.device) if want_det else None
+        counts = torch.zeros((n,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_track_to_3d(
+                self._h, _ptr(frames), n, ch, sn, sr, _ptr(ref), m, float(min_dist),
+                C.byref(cam) if cam is not None else None, float(min_marker_size_px), _ptr(table), _ptr(det),
+                _ptr(counts), self._stream()), "vbs_track_to_3d")
+        return table, det, counts
+
+    # ---- a21, f1 -------------------------------------------------------------------------------
+    def displacement(self, table, warmup_frames=100, min_marker_size_px=5.0, max_displacement=50.0):
+        table = table.contiguous()
+        n, m = table.shape[0], table.shape[1]
+        disp = torch.empty((n, m, L.DISP_COLS), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_displacement(self._h, _ptr(table), n, m, int(warmup_frames),
+                                                  float(min_marker_size_px), float(max_displacement), _ptr(disp),
+                                                  self._stream()), "vbs_displacement")
+        return disp
+
+    def plane_fit(self, table):
+        table = table.contiguous()
+        n, m = table.shape[0], table.shape[1]
+        plane = torch.empty((n, L.PLANE_COLS), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_plane_fit(self._h, _ptr(table), n, m, _ptr(plane), self._stream()),
+                        "vbs_plane_fit")
+        return plane
+
+
+def undistort_points(points, cam: L.Camera, device=None):
+    """float64 [n,2] -> [n,2] on the GPU (`MarkerAnalysis._undistort_points`)."""
+    if not torch.cuda.is_available():
+        raise L.VbsError("no GPU visible: vbs_amd has no CPU path")
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    p = torch.as_tensor(np.asarray(points, dtype=np.float64).reshape(-1, 2), device=dev).contiguous()
+    out = torch.empty_like(p)
+    rc = L.lib().vbs_undistort_points(dev.index, _ptr(p), p.shape[0], C.byref(cam), _ptr(out),
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != L.VBS_OK:
+        raise L.VbsError(f"vbs_undistort_points failed ({rc})")
+    return out
+
+
+def calculate_3d(uvd, cam: L.Camera, device=None):
+    """float64 [n,3] (u, v, diameter_px) -> (xyz float64 [n,3], ok int32 [n]) on the GPU."""
+    if not torch.cuda.is_available():
+        raise L.VbsError("no GPU visible: vbs_amd has no CPU path")
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    p = torch.as_tensor(np.asarray(uvd, dtype=np.float64).reshape(-1, 3), device=dev).contiguous()
+    xyz = torch.empty_like(p)
+    ok = torch.empty((p.shape[0],), dtype=torch.int32, device=dev)
+    rc = L.lib().vbs_calculate_3d(dev.index, _ptr(p), p.shape[0], C.byref(cam), _ptr(xyz), _ptr(ok),
+                                  C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc == L.VBS_EINVAL:
+        raise ValueError("Focal lengths must be positive")
+    if rc != L.VBS_OK:
+        raise L.VbsError(f"vbs_calculate_3d failed ({rc})")
+    return xyz, ok
