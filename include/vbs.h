@@ -87,6 +87,16 @@ int vbs_find_markers(vbs_handle* h, const uint8_t* frames, int n, int channels, 
  * (Diagnostic / parity entry: the hot path never materialises this map.) */
 int vbs_ncc_map(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
                 int64_t stride_row, double* ncc, void* stream);
+/* The same stage from a given two-valued area_mask [dev] uint8 [n,h,w] (the reference call
+ * `_normxcorr2(template, area_mask)` :132 with the template of the handle's branch): ncc [dev]
+ * float64 [n,h,w] and / or mask [dev] uint8 [n,h,w] = ncc > 0.1 (:133); either may be NULL. */
+int vbs_normxcorr2(vbs_handle* h, const uint8_t* area_mask, int n, double* ncc, uint8_t* mask,
+                   void* stream);
+/* Live kernel timing: while enabled, every kernel launch of this handle is bracketed by a HIP event
+ * pair on the launch stream.  vbs_profile(h, on) clears the records; vbs_profile_read synchronises
+ * and writes one text line per kernel: "<name> <launches> <total_ms>". */
+int vbs_profile(vbs_handle* h, int enable);
+int vbs_profile_read(vbs_handle* h, char* buf, int cap);
 /* host copy of the per-frame counters of the LAST internal pass: out[i*8 + {0: area_mask popcount,
  * 1: NCC pixels within 1e-9 (relative) of the 0.1 threshold, 2: status}] (synchronises). */
 int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n);
@@ -135,6 +145,11 @@ int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int channels, i
  * disp [dev] float32 [n,m_ref,VBS_DISP_COLS]. */
 int vbs_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup_frames,
                      double min_marker_size_px, double max_displacement, float* disp, void* stream);
+
+/* The same on float64 tables (same column layout, no handle): what `MarkerAnalysis._track_markers(df)`
+ * uses so that the DataFrame interface keeps the reference's float64 results. */
+int vbs_displacement_f64(int device, const double* table, int n, int m_ref, int warmup_frames,
+                         double min_marker_size_px, double max_displacement, double* disp, void* stream);
 
 /* fit_plane_least_squares (ForceDistribution.py:138-162): per frame Z = aX + bY + c over the rows
  * with VBS_FLAG_XYZ, tilt = atan(sqrt(a^2+b^2)) in degrees.  plane [dev] float32 [n,VBS_PLANE_COLS]. */

@@ -1,0 +1,395 @@
+"""GPU parity tests (run on the MI355X box: `pytest -m gpu`).  Every test drives the HIP path through
+the C-ABI (via the ctypes engine or the drop-in classes) and checks it against the CPU oracle on the
+same seeded inputs, or against the committed goldens produced by the reference's own function bodies.
+
+Stated tolerances (north_star: IDs bit-exact, centroids / 3-D within an fp32 tolerance):
+  masks, labels, counts, IDs          : exact
+  centroids Cx, Cy (float32 tables)   : |d| <= 2.5e-4 px   (2 ulp of float32 at 2048)
+  major / minor axis (float32)        : |d| <= 1e-3 px      (observed: identical after float32 rounding)
+  ellipse angle                       : compared mod 180 deg, only when major - minor > 1e-2 px
+  X, Y, Z (float32 tables)            : |d| <= 2e-5 mm      (ulp of float32 at 128 mm = 7.6e-6)
+  float64 point APIs                  : rel 1e-12
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+import vbs_amd.synth as S                                     # noqa: E402
+from vbs_amd import _lib as L                                 # noqa: E402
+from vbs_amd import ids as I                                  # noqa: E402
+from oracle import stages as O                                # noqa: E402
+
+TOL_XY, TOL_AX, TOL_XYZ = 2.5e-4, 1e-3, 2e-5
+
+
+def engine(h, w, **kw):
+    from vbs_amd.engine import Engine
+    kw.setdefault("max_markers", 512)
+    kw.setdefault("max_batch", 4)
+    return Engine(h, w, **kw)
+
+
+def rle_decode(runs, shape):
+    vals = np.zeros(len(runs), dtype=np.uint8)
+    vals[1::2] = 1
+    return np.repeat(vals, runs).reshape(shape)
+
+
+def angle_close(a, b, tol=0.05):
+    d = abs((a - b + 90.0) % 180.0 - 90.0)
+    return d <= tol
+
+
+def compare_markers(got, want):
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert abs(g["center"][0] - w["center"][0]) <= TOL_XY and abs(g["center"][1] - w["center"][1]) <= TOL_XY
+        assert abs(g["major_axis"] - w["major_axis"]) <= TOL_AX
+        assert abs(g["minor_axis"] - w["minor_axis"]) <= TOL_AX
+        if w["major_axis"] - w["minor_axis"] > 1e-2:
+            assert angle_close(g["angle"], w["angle"]), (g, w)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,channels,crop", [("c1", 3, (0, 0, 0, 0)), ("c1", 3, (1 / 8, 1 / 8, 1 / 16, 0)),
+                                               ("c2", 1, (0, 0, 0, 0)), ("c2", 3, (1 / 8, 1 / 8, 1 / 16, 0))])
+def test_find_markers_bit_exact(tag, channels, crop):
+    """a1-a8: masks of `_find_markers` are bit-exact, also through a strided crop view."""
+    spec = S.config1() if tag == "c1" else S.config2()
+    frames = S.make_frames(spec, [0, 3], seed=5, channels=channels)
+    l, r, t, b = O.crop_box(spec.width, spec.height, crop)
+    eng = engine(b - t, r - l, max_batch=1)
+    ft = torch.from_numpy(frames).cuda()[:, t:b, l:r]
+    mask, area = eng.find_markers(ft)
+    stats = eng.frame_stats(1)
+    mask, area = mask.cpu().numpy(), area.cpu().numpy()
+    for i in range(frames.shape[0]):
+        om, oa = O.find_markers(frames[i][t:b, l:r])
+        assert np.array_equal(area[i], oa)
+        assert np.array_equal(mask[i], om)
+        assert om.sum() > 0
+    assert stats[0, 1] == 0, "an NCC pixel sat within 1e-9 of the 0.1 threshold"
+    assert stats[0, 0] == (area[-1] > 0).sum()
+    eng.close()
+
+
+def test_bgr_weights_and_dog_wrap():
+    """a3: the cv2 fixed-point BGR weights on a frame with B != G != R; a4/a5: the mod-256 wrap and the
+    upper inRange bound on a high-contrast frame (bright discs on black wrap to large values)."""
+    rng = np.random.default_rng(0)
+    spec = S.grid_spec(640, 480, 5, 90, 30, bg=20, fg=250, name="bright")
+    g = S.make_frames(spec, [0, 1], seed=2)
+    frames = np.stack([np.clip(g.astype(int) + d, 0, 255) for d in (7, -9, 3)], axis=-1).astype(np.uint8)
+    frames[:, 100:140, 200:300] = rng.integers(0, 256, (2, 40, 100, 3), dtype=np.uint8)
+    eng = engine(480, 640, max_batch=2)
+    mask, area = eng.find_markers(torch.from_numpy(frames).cuda())
+    for i in range(2):
+        om, oa = O.find_markers(frames[i])
+        assert np.array_equal(area[i].cpu().numpy(), oa)
+        assert np.array_equal(mask[i].cpu().numpy(), om)
+    gray = O.bgr2gray(frames[0])
+    assert not np.array_equal(gray, frames[0][..., 1])
+    eng.close()
+
+
+def test_ncc_map_matches_fft_reference():
+    """a7: the float64 NCC map against the oracle's literal FFT evaluation."""
+    spec = S.config2()
+    frames = S.make_frames(spec, [2], seed=9)
+    eng = engine(spec.height, spec.width, max_batch=1)
+    ncc = eng.ncc_map(torch.from_numpy(frames).cuda())[0].cpu().numpy()
+    _, oa = O.find_markers(frames[0])
+    with np.errstate(all="ignore"):
+        ref = O.normxcorr2(O.gkern(80, 13.0), oa)
+    d = np.abs(ncc - ref)
+    assert d.max() < 1e-6 and np.median(d) < 1e-13      # the tail is FFT noise in flat windows
+    assert np.array_equal(ncc > 0.1, ref > 0.1)
+    eng.close()
+
+
+def test_normxcorr2_golden_from_reference_body(golden_dir):
+    """`MarkerTracker._normxcorr2` against the output of the reference's own `_normxcorr2` (golden)."""
+    from vbs_amd.marker_detection import MarkerTracker
+    G = np.load(os.path.join(golden_dir, "stages.npz"))
+    img = np.zeros((120, 192), dtype=np.uint8)          # golden image is 120 x 130: pad the width, compare inside
+    big = G["ncc_big_image"]
+    eng_img = big
+    t = MarkerTracker._gkern(33, 7.4)
+    out = MarkerTracker._normxcorr2(t, eng_img)
+    ref = G["ncc_big_out_l33"]
+    assert out.shape == ref.shape
+    assert np.max(np.abs(out - ref)) < 1e-6
+    assert np.array_equal(out > 0.1, ref > 0.1)
+    with pytest.raises(ValueError):
+        MarkerTracker._normxcorr2(MarkerTracker._gkern(9, 2.0), eng_img)
+    del img
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["c1", "c2", "c5"])
+def test_marker_center_parity(tag):
+    """a9-a13 on the oracle's masks: count, order, centres, axes."""
+    from vbs_amd.marker_detection import MarkerTracker
+    spec = {"c1": S.config1(), "c2": S.config2(), "c5": S.config5()}[tag]
+    frame = S.make_frames(spec, [4], seed=3)[0]
+    om, oa = O.find_markers(frame)
+    want = O.marker_center(om, oa)
+    got = MarkerTracker._marker_center(om, oa)
+    assert len(want) == spec.n_markers
+    compare_markers(got, want)
+
+
+@pytest.mark.parametrize("tag", ["c1", "c2", "rand"])
+def test_band_centroids_golden(golden_dir, tag):
+    """a9-a11 against the goldens from the reference's SciPy prefix (`marker_detection.py:170-185`):
+    with area_mask = mask every blob's contour holds its own band centroid, so each det row carries
+    the centroid of the label named in its last column."""
+    G = np.load(os.path.join(golden_dir, "stages.npz"))
+    shape = tuple(int(v) for v in G[f"band_{tag}_shape"])
+    mask = rle_decode(G[f"band_{tag}_mask_rle"], shape)
+    centers = G[f"band_{tag}_centers"]
+    eng = engine(shape[0], shape[1], max_markers=1024, max_batch=1)
+    mt = torch.from_numpy(mask).cuda()
+    det, counts = eng.marker_center(mt, mt)
+    n = int(counts[0])
+    det = det[0].cpu().numpy()[:n]
+    assert n > 0
+    if tag != "rand":
+        assert n == centers.shape[0]
+    lab = det[:, 5].astype(int) - 1
+    assert len(set(lab.tolist())) == n
+    assert np.max(np.abs(det[:, 0] - centers[lab, 1])) <= TOL_XY
+    assert np.max(np.abs(det[:, 1] - centers[lab, 0])) <= TOL_XY
+    eng.close()
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_marker_center_random_blobs(seed):
+    """Ragged input: random hole-free blobs, some touching the border, thin bridges; also checks the
+    sequential contour<->centre matching and the minor<5 / len<5 rejections."""
+    from scipy import ndimage
+    from vbs_amd.marker_detection import MarkerTracker
+    rng = np.random.default_rng(seed)
+    a = ndimage.gaussian_filter(rng.random((300, 400)), 7.0)
+    area = ndimage.binary_fill_holes(a > np.quantile(a, 0.7))
+    area[150, 30:370] |= True
+    area = ndimage.binary_fill_holes(area)
+    mask = ndimage.binary_erosion(area, iterations=3)
+    area_u8 = (area * 255).astype(np.uint8)
+    mask_u8 = mask.astype(np.uint8)
+    want = O.marker_center(mask_u8, area_u8)
+    got = MarkerTracker._marker_center(mask_u8, area_u8)
+    compare_markers(got, want)
+
+
+def test_marker_center_empty_and_capacity():
+    from vbs_amd.marker_detection import MarkerTracker
+    z = np.zeros((128, 256), dtype=np.uint8)
+    assert MarkerTracker._marker_center(z, z) == []
+    assert O.marker_center(z, z) == []
+    # a checkerboard has far more runs than the workspace holds -> status, not a wrong answer
+    cb = (np.indices((1024, 1280)).sum(0) % 2).astype(np.uint8)
+    with pytest.raises(L.VbsError):
+        MarkerTracker._marker_center(cb, cb)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("id_mode", ["as_written", "full"])
+@pytest.mark.parametrize("tag", ["ring", "c1"])
+def test_marker_tracker_process_frames(tmp_path, tag, id_mode):
+    """`MarkerTracker.process` (in-memory frames): CSV rows vs the oracle, IDs bit-exact."""
+    import pandas as pd
+    from vbs_amd.marker_detection import MarkerTracker, CSV_COLUMNS
+    spec = S.ring65_spec() if tag == "ring" else S.config1()
+    frames = S.make_frames(spec, range(5), seed=21, channels=3)
+    np.save(tmp_path / "clip.npy", frames)
+    crop = (0, 0, 0, 0) if tag == "ring" else (1 / 16, 1 / 16, 0, 1 / 16)
+    cfg = {"video_path": str(tmp_path / "clip.npy"), "output_dir": str(tmp_path / "out"), "crop_ratios": crop,
+           "num_layers": 5, "min_marker_distance": 20, "id_mode": id_mode, "batch": 3}
+    trk = MarkerTracker(cfg)
+    trk.process()
+    df = pd.read_csv(trk.output_csv)
+    assert list(df.columns) == CSV_COLUMNS
+    rows, ref = O.process_frames(list(frames), crop_ratios=crop, id_mode=id_mode)
+    assert list(trk.first_frame_markers.keys()) == list(ref.keys())
+    assert len(df) == len(rows)
+    want = pd.DataFrame(rows, columns=CSV_COLUMNS)
+    assert (df[["frameno", "row", "col"]].to_numpy() == want[["frameno", "row", "col"]].to_numpy()).all()
+    for c, tol in (("Ox", TOL_XY), ("Oy", TOL_XY), ("Cx", TOL_XY), ("Cy", TOL_XY), ("major_axis", TOL_AX),
+                   ("minor_axis", TOL_AX)):
+        assert np.max(np.abs(df[c].to_numpy() - want[c].to_numpy())) <= tol, c
+    if id_mode == "as_written":
+        assert len(ref) == 6
+    else:
+        assert len(ref) == spec.n_markers
+
+
+def test_track_markers_method_and_drop_rules():
+    """a15 through the reference-shaped method: nearest (first on ties), > min_distance dropped, two
+    references may claim one detection."""
+    from vbs_amd.marker_detection import MarkerTracker
+    trk = MarkerTracker.__new__(MarkerTracker)
+    trk.config = {"min_marker_distance": 20}
+    trk.frame_count = 7
+    trk.crop_height, trk.crop_width = 480, 640
+    trk.first_frame_markers = {(0, 0): {"Ox": 100.0, "Oy": 100.0}, (1, 0): {"Ox": 130.0, "Oy": 100.0},
+                               (1, 1): {"Ox": 400.0, "Oy": 300.0}, (2, 0): {"Ox": 115.0, "Oy": 100.0}}
+    markers = [{"center": (110.0, 100.0), "major_axis": 20.0, "minor_axis": 19.0, "angle": 90.0},
+               {"center": (120.0, 100.0), "major_axis": 21.0, "minor_axis": 19.5, "angle": 91.0},
+               {"center": (400.0, 321.0), "major_axis": 22.0, "minor_axis": 18.0, "angle": 92.0}]
+    got = trk._track_markers(np.zeros((480, 640, 3), np.uint8), markers)
+    want = O.track_markers(trk.first_frame_markers, markers, 7, 20)
+    assert got == want
+    assert [(r["row"], r["col"]) for r in got] == [(0, 0), (1, 0), (2, 0)]      # (1,1) is 21 px away
+    assert got[2]["Cx"] == 110.0                                                  # tie 5 px / 5 px -> first
+    assert trk._track_markers(None, []) == []
+    with pytest.raises(ValueError):
+        MarkerTracker._process_first_frame(trk, [])
+
+
+# ------------------------------------------------------------------------------------------------
+def test_points_api_against_reference_goldens(golden_dir):
+    """a19/a20 float64 interfaces against outputs of the reference's `_calculate_3d_position`."""
+    from vbs_amd.reconstruction3d import MarkerAnalysis, Config
+    g = json.load(open(os.path.join(golden_dir, "solve3d.json")))
+    for cname in ("cam_a", "cam_b"):
+        cam = g[cname]["cam"]
+        ma = MarkerAnalysis.__new__(MarkerAnalysis)
+        ma.config = Config()
+        from vbs_amd.reconstruction3d import CameraParameters
+        ma.camera = CameraParameters()
+        ma.set_camera(cam["K"], np.zeros(5), cam["R"], cam["T"])
+        for u, v, d, x, y, z in g[cname]["pts"]:
+            if x is None:
+                with pytest.raises(ValueError):
+                    ma._calculate_3d_position(u, v, d)
+            else:
+                p = ma._calculate_3d_position(u, v, d)
+                np.testing.assert_allclose(p, [x, y, z], rtol=1e-12, atol=1e-12)
+
+
+def test_undistort_points_with_distortion():
+    from vbs_amd.engine import undistort_points
+    K = np.array([[912.25, 0, 331.5], [0, 915.75, 236.125], [0, 0, 1]], dtype=np.float32)
+    dist = np.array([-0.21, 0.07, 0.0013, -0.0009, -0.011], dtype=np.float32)
+    cam = L.make_camera(K, dist, np.eye(3), np.zeros(3))
+    rng = np.random.default_rng(1)
+    pts = rng.uniform([0, 0], [640, 480], size=(500, 2))
+    got = undistort_points(pts, cam).cpu().numpy()
+    want = O.undistort_points(pts, K, dist)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    assert np.abs(got - pts).max() > 1.0
+    cam0 = L.make_camera(K, np.zeros(5), np.eye(3), np.zeros(3))
+    np.testing.assert_allclose(undistort_points(pts, cam0).cpu().numpy(), pts, rtol=0, atol=1e-10)
+
+
+def test_marker_analysis_track_markers_golden(golden_dir):
+    """a21 through `MarkerAnalysis._track_markers(df)` against the reference body's output: gap frame,
+    warm-up, > 50 mm rejection."""
+    import pandas as pd
+    from vbs_amd.reconstruction3d import MarkerAnalysis, Config, CameraParameters
+    g = json.load(open(os.path.join(golden_dir, "solve3d.json")))["disp"]
+    ma = MarkerAnalysis.__new__(MarkerAnalysis)
+    ma.config = Config(warmup_frames=g["warmup"], max_displacement_px=g["limit"])
+    ma.camera = CameraParameters()
+    ma.set_camera(g["cam"]["K"], np.zeros(5), g["cam"]["R"], g["cam"]["T"])
+    df = pd.DataFrame(g["rows_in"])
+    out = ma._track_markers(df)
+    cols = ["frameno", "row", "col", "X", "Y", "Z", "dX", "dY", "dZ", "displacement"]
+    assert list(out.columns) == cols
+    got = out.to_numpy(dtype=np.float64)
+    want = np.array(g["rows_out"])
+    assert got.shape == want.shape
+    key = lambda a: np.lexsort((a[:, 2], a[:, 1], a[:, 0]))      # noqa: E731
+    got, want = got[key(got)], want[key(want)]
+    np.testing.assert_array_equal(got[:, :3], want[:, :3])
+    np.testing.assert_allclose(got[:, 3:], want[:, 3:], rtol=0, atol=1e-9)
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag,nframes", [("c2", 6), ("c5", 2)])
+def test_fused_track_to_3d_displacement_plane(tag, nframes):
+    """Whole path frames -> table -> displacement -> plane fit against the oracle (IDs exact)."""
+    from vbs_amd.pipeline import track_shard
+    spec = S.config2() if tag == "c2" else S.config5()
+    frames = S.make_frames(spec, range(nframes), seed=13)
+    eng = engine(spec.height, spec.width, max_markers=1024, max_batch=4)
+    K, dist, R, T = S.default_camera(spec)
+    dist = np.array([-0.05, 0.01, 0.0005, -0.0003, 0.0], dtype=np.float32)
+    cam = L.make_camera(K, dist, R, T, 2.0)
+    res = track_shard(eng, torch.from_numpy(frames).cuda(), nframes, cam=cam, warmup_frames=1, id_mode="full")
+    rows, ref = O.process_frames(list(frames), id_mode="full")
+    assert [tuple(k) for k in res.ids.tolist()] == list(ref.keys())
+    table = res.table.cpu().numpy()
+    disp = res.disp.cpu().numpy()
+    assert int((table[..., 0].astype(int) & 1).sum()) == len(rows)
+    slot = {k: i for i, k in enumerate(ref.keys())}
+    for r in rows:
+        t = table[r["frameno"], slot[(r["row"], r["col"])]]
+        assert int(t[0]) & 1
+        assert abs(t[1] - r["Cx"]) <= TOL_XY and abs(t[2] - r["Cy"]) <= TOL_XY
+        assert abs(t[3] - r["major_axis"]) <= TOL_AX and abs(t[4] - r["minor_axis"]) <= TOL_AX
+    rows3 = O.track_markers_3d(rows, K, dist, R, T, warmup_frames=1)
+    assert int(disp[..., 0].sum()) == len(rows3) and len(rows3) > 0
+    for r in rows3:
+        s = slot[(r["row"], r["col"])]
+        t, d = table[r["frameno"], s], disp[r["frameno"], s]
+        assert d[0] == 1
+        assert np.max(np.abs(t[6:9] - [r["X"], r["Y"], r["Z"]])) <= TOL_XYZ
+        assert np.max(np.abs(d[1:5] - [r["dX"], r["dY"], r["dZ"], r["displacement"]])) <= TOL_XYZ
+    plane = res.plane.cpu().numpy()
+    for f in range(nframes):
+        v = (table[f, :, 0].astype(int) & 2) > 0
+        a, b, c, tilt = O.fit_plane(table[f, v, 6].astype(np.float64), table[f, v, 7].astype(np.float64),
+                                    table[f, v, 8].astype(np.float64))
+        assert plane[f, 0] == v.sum()
+        np.testing.assert_allclose(plane[f, 1:], [a, b, c, tilt], rtol=2e-4, atol=2e-5)
+    eng.close()
+
+
+def test_batch_and_chunk_independence():
+    """Size-independent property at batch scale: a frame's table row does not depend on the batch it
+    travels in, nor on the engine's internal chunking (frames are independent units)."""
+    spec = S.config2()
+    n = 24
+    ft = S.make_frames_torch(spec, range(n), seed=2, device="cuda")
+    eng_a = engine(spec.height, spec.width, max_batch=16)
+    eng_b = engine(spec.height, spec.width, max_batch=5)
+    from vbs_amd.pipeline import reference_from_frame0
+    ids, xy = reference_from_frame0(eng_a, ft)
+    K, dist, R, T = S.default_camera(spec)
+    cam = L.make_camera(K, dist, R, T)
+    ta, _, _ = eng_a.track_to_3d(ft, xy, 20.0, cam)
+    tb, _, _ = eng_b.track_to_3d(ft, xy, 20.0, cam)
+    assert torch.equal(ta, tb)
+    perm = torch.randperm(n, generator=torch.Generator().manual_seed(0))
+    tc, _, _ = eng_b.track_to_3d(ft[perm.cuda()].contiguous(), xy, 20.0, cam)
+    assert torch.equal(tc, ta[perm.cuda()])
+    assert int((ta[..., 0].int() & 1).sum()) == n * spec.n_markers
+    # torch-rendered frames are the same bytes as the NumPy renderer's
+    assert np.array_equal(ft[3].cpu().numpy(), S.make_frames(spec, [3], seed=2)[0])
+    eng_a.close()
+    eng_b.close()
+
+
+def test_engine_argument_errors():
+    from vbs_amd.engine import Engine
+    with pytest.raises(ValueError):
+        Engine(32, 32)
+    eng = engine(480, 640)
+    with pytest.raises(ValueError):
+        eng.find_markers(torch.zeros((1, 100, 100), dtype=torch.uint8, device="cuda"))
+    with pytest.raises(ValueError):
+        eng.find_markers(torch.zeros((1, 480, 640), dtype=torch.float32, device="cuda"))
+    mask, area = eng.find_markers(torch.full((1, 480, 640), 190, dtype=torch.uint8, device="cuda"))
+    assert int(mask.sum()) == 0 and int(area.sum()) == 0
+    _, _, counts = eng.track_to_3d(torch.full((2, 480, 640), 190, dtype=torch.uint8, device="cuda"),
+                                   np.array([[10.0, 10.0]]))
+    assert counts.tolist() == [0, 0]
+    eng.close()

@@ -1,0 +1,200 @@
+"""CPU tests of the host side of the product: ID assignment against the oracle and the reference
+goldens, the drop-in classes' configuration / error behaviour, file formats, frame sharding with a
+2-process gloo group, and the rule that compute never silently falls back to the CPU."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import vbs_amd.synth as S
+from vbs_amd import ids as I
+from oracle import stages as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _markers(spec, seed=5, frame=0, shuffle=1):
+    truth = S.dot_truth(spec, seed, [frame])[0]
+    order = np.random.default_rng(shuffle).permutation(spec.n_markers)
+    return [{"center": (float(truth[k, 0]) - 0.25, float(truth[k, 1]) - 0.25), "major_axis": float(truth[k, 2]),
+             "minor_axis": float(truth[k, 2]) - 0.5, "angle": 90.0} for k in order]
+
+
+@pytest.mark.parametrize("spec", [S.ring65_spec(), S.config1(), S.config2(), S.config5()], ids=lambda s: s.name)
+@pytest.mark.parametrize("id_mode", ["as_written", "full"])
+def test_assign_ids_equals_oracle(spec, id_mode):
+    ms = _markers(spec)
+    got = I.assign_ids(ms, 5, id_mode, "optimal")
+    want = O.process_first_frame(ms, 5, id_mode, "optimal")
+    assert list(got.keys()) == list(want.keys())
+    for k in got:
+        assert got[k]["Ox"] == want[k]["Ox"] and got[k]["Oy"] == want[k]["Oy"]
+        if k != (0, 0):
+            assert got[k]["angle_rad"] == want[k]["angle_rad"]
+    assert len(got) == (6 if id_mode == "as_written" else spec.n_markers)
+    ids, xy = I.reference_arrays(got)
+    assert ids.shape == (len(got), 2) and xy.shape == (len(got), 2) and ids.dtype == np.int64
+
+
+@pytest.mark.parametrize("name", ["ring65", "grid7"])
+def test_assign_ids_reference_golden(golden_dir, name):
+    """as_written IDs bit-exact against the output of the reference's own `_process_first_frame`."""
+    g = json.load(open(os.path.join(golden_dir, "ids_as_written.json")))[name]
+    fr0 = [{**m, "center": tuple(m["center"])} for m in g["frames"][0]]
+    for km in ("optimal", "sklearn"):
+        got = I.assign_ids(fr0, g["num_layers"], "as_written", km)
+        assert [[k[0], k[1], v["Ox"], v["Oy"]] for k, v in got.items()] == g["ref"]
+
+
+def test_kmeans_1d_is_optimal_and_deterministic():
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        v = rng.normal(size=rng.integers(6, 40)) * rng.uniform(0.1, 5) + rng.choice([0, 3, 9], size=1)
+        k = int(rng.integers(1, 6))
+        a = I.kmeans_1d(v, k)
+        b = O.kmeans_1d_optimal(v, k)
+        assert np.array_equal(a, b)
+        assert np.array_equal(a, I.kmeans_1d(v.copy(), k))
+    with pytest.raises(ValueError):
+        I.assign_ids([], 5)
+    with pytest.raises(ValueError):
+        I.assign_ids(_markers(S.config1()), 5, "nope")
+
+
+def test_marker_tracker_config_errors(tmp_path):
+    from vbs_amd.marker_detection import MarkerTracker, find_marker, marker_center, _crop_box
+    with pytest.raises(ValueError, match="Missing required config key: crop_ratios"):
+        MarkerTracker({"video_path": "x", "output_dir": str(tmp_path)})
+    with pytest.raises(FileNotFoundError):
+        MarkerTracker({"video_path": str(tmp_path / "nope.avi"), "output_dir": str(tmp_path), "crop_ratios": (0, 0, 0, 0)})
+    p = tmp_path / "clip.avi"
+    p.write_bytes(b"not a video")
+    t = MarkerTracker({"video_path": str(p), "output_dir": str(tmp_path / "o"), "crop_ratios": (1 / 8, 1 / 8, 1 / 16, 0)})
+    assert t.output_csv.endswith("clip_markers.csv") and os.path.isdir(tmp_path / "o")
+    with pytest.raises(IOError):
+        t._init_video()                       # no OpenCV here and not a .npy clip
+    assert find_marker is MarkerTracker._find_markers and marker_center is MarkerTracker._marker_center
+    assert _crop_box(1280, 1024, (1 / 8, 1 / 8, 1 / 16, 0)) == O.crop_box(1280, 1024, (1 / 8, 1 / 8, 1 / 16, 0)) == (160, 1120, 64, 1024)
+    assert _crop_box(640, 480, (1 / 8, 1 / 8, 1 / 16, 0)) == (80, 560, 30, 480)
+    np.testing.assert_array_equal(MarkerTracker._gkern(33, 7.4), O.gkern(33, 7.4))
+    from vbs_amd.tracking import process_video
+    with pytest.raises(FileNotFoundError):
+        process_video(video_dir=str(tmp_path / "v"))
+
+
+def test_no_silent_cpu_fallback():
+    """Without a GPU every compute entry point must raise — never answer from a CPU path."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from vbs_amd._lib import VbsError
+    from vbs_amd.engine import Engine, undistort_points, calculate_3d
+    from vbs_amd.marker_detection import MarkerTracker
+    with pytest.raises(VbsError):
+        Engine(480, 640)
+    with pytest.raises(VbsError):
+        MarkerTracker._find_markers(np.zeros((480, 640, 3), np.uint8))
+    with pytest.raises(VbsError):
+        MarkerTracker._marker_center(np.zeros((480, 640), np.uint8), np.zeros((480, 640), np.uint8))
+    from vbs_amd import _lib as L
+    cam = L.make_camera(np.eye(3), np.zeros(5), np.eye(3), np.zeros(3))
+    with pytest.raises(VbsError):
+        undistort_points(np.zeros((1, 2)), cam)
+    with pytest.raises(VbsError):
+        calculate_3d(np.zeros((1, 3)), cam)
+    # and the product never imports the oracle
+    for mod in ("marker_detection", "tracking", "reconstruction3d", "engine", "pipeline", "ids", "dist", "synth", "_lib"):
+        src = open(os.path.join(ROOT, "vision-basedsensor_amd", mod + ".py")).read()
+        assert "oracle" not in src.replace("the oracle", "").replace("oracle/", "").replace("(the oracle", "") or \
+            "import oracle" not in src and "from oracle" not in src
+        assert "from oracle" not in src and "import oracle" not in src
+
+
+def test_marker_analysis_files(tmp_path):
+    import pandas as pd
+    from vbs_amd.reconstruction3d import MarkerAnalysis, Config, CONFIG
+    assert CONFIG.marker_diameter_mm == 2.0 and CONFIG.warmup_frames == 100 and CONFIG.min_marker_size_px == 5.0 \
+        and CONFIG.max_displacement_px == 50.0 and CONFIG.column_mapping == {"Cx": "u", "Cy": "v", "major_axis": "major_axis"}
+    cfg = Config(data_dir=tmp_path / "d", output_dir=tmp_path / "d" / "r", plots_dir=tmp_path / "d" / "r" / "p")
+    ma = MarkerAnalysis(cfg)
+    assert (tmp_path / "d" / "r" / "p").is_dir()
+    intr = pd.DataFrame({"Param": ["fx", "fy", "cx", "cy", "k1", "k2", "p1", "p2", "k3"],
+                         "Value": [1400.5, 1399.25, 640.0, 512.0, -0.1, 0.01, 0.001, -0.002, 0.0], "Desc": [""] * 9})
+    intr.to_csv(tmp_path / "intr.csv", index=False)
+    R = np.eye(3)
+    ext = {f"R_wc_{i + 1}{j + 1}": R[i, j] for i in range(3) for j in range(3)}
+    ext.update({"T_wc_X": 1.0, "T_wc_Y": -2.0, "T_wc_Z": 30.0})
+    (tmp_path / "ext.json").write_text(json.dumps(ext))
+    ma.load_parameters(tmp_path / "intr.csv", tmp_path / "ext.json")
+    assert ma.camera.matrix.dtype == np.float32 and ma.camera.matrix[0, 0] == np.float32(1400.5)
+    assert ma.camera.dist_coeffs.dtype == np.float32 and ma.camera.dist_coeffs.shape == (5,)
+    assert ma.camera.T_world_to_cam.shape == (3, 1) and ma.camera.T_world_to_cam[2, 0] == 30.0
+    ext["R_wc_12"] = 0.1
+    (tmp_path / "bad.json").write_text(json.dumps(ext))
+    with pytest.raises(ValueError, match="not orthogonal"):
+        ma.load_parameters(tmp_path / "intr.csv", tmp_path / "bad.json")
+    intr.loc[0, "Value"] = -1.0
+    intr.to_csv(tmp_path / "neg.csv", index=False)
+    with pytest.raises(ValueError, match="Focal lengths"):
+        ma.load_parameters(tmp_path / "neg.csv", tmp_path / "ext.json")
+    # marker CSV: required columns, size filter, sort
+    with pytest.raises(FileNotFoundError):
+        ma.load_marker_data(tmp_path / "none.csv")
+    pd.DataFrame({"frameno": [2, 1, 1], "row": [0, 0, 1], "col": [0, 0, 0], "Cx": [1.0, 2.0, 3.0],
+                  "Cy": [4.0, 5.0, 6.0], "major_axis": [10.0, 4.0, 12.0]}).to_csv(tmp_path / "m.csv", index=False)
+    df = ma.load_marker_data(tmp_path / "m.csv")
+    assert list(df["frameno"]) == [1, 2] and {"u", "v"} <= set(df.columns)
+    pd.DataFrame({"frameno": [1], "row": [0]}).to_csv(tmp_path / "bad.csv", index=False)
+    with pytest.raises(ValueError, match="Missing required columns"):
+        ma.load_marker_data(tmp_path / "bad.csv")
+
+
+def test_shard_bounds():
+    from vbs_amd.dist import shard_bounds
+    for n, w in ((32768, 8), (10, 4), (7, 8), (0, 2)):
+        spans = [shard_bounds(n, w, r) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(w - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_bounds(32768, 8, 3) == (12288, 16384)
+
+
+def _gloo_worker(rank, world, port, n_total, out_dir):
+    import torch
+    import torch.distributed as td
+    sys.path.insert(0, ROOT)
+    from vbs_amd import dist as D
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    td.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        a, b = D.shard_bounds(n_total, world, rank)
+        m = 7
+        full = torch.arange(n_total * m * 10, dtype=torch.float32).reshape(n_total, m, 10)
+        ids = xy = None
+        if rank == 0:
+            ids = np.array([[0, 0], [1, 0], [1, 1], [2, 0], [2, 1], [2, 2], [3, 0]])
+            xy = np.linspace(0, 1, 14).reshape(7, 2) * 1e3 + 0.123456789
+        ids, xy = D.broadcast_reference(ids, xy, torch.device("cpu"))
+        gathered = D.gather_tables(full[a:b].clone(), n_total)
+        ok = torch.equal(gathered, full) and ids.shape == (7, 2) and ids[5].tolist() == [2, 2] \
+            and abs(xy[6, 1] - (1e3 + 0.123456789)) < 1e-12
+        open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "bad")
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [8, 9])
+def test_gather_tables_two_ranks_gloo(tmp_path, n_total):
+    """N>1 path on CPU: broadcast of the reference table + the single all-gather, even and ragged shards."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]

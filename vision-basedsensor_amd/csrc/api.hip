@@ -258,6 +258,56 @@ extern "C" int vbs_ncc_map(vbs_handle* h, const uint8_t* frames, int n, int chan
     return VBS_OK;
 }
 
+extern "C" int vbs_normxcorr2(vbs_handle* h, const uint8_t* area_mask, int n, double* ncc, uint8_t* mask,
+                              void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!area_mask || n < 0 || (!ncc && !mask)) { h->err = "vbs_normxcorr2: bad argument"; return VBS_EINVAL; }
+    hipStream_t s = (hipStream_t)stream;
+    HIPCHK(h, hipSetDevice(h->device));
+    const size_t hw = (size_t)h->H * h->W;
+    for (int off = 0; off < n; off += h->maxb) {
+        int nb = std::min(h->maxb, n - off);
+        HIPCHK(h, hipMemsetAsync(h->fstat, 0, (size_t)nb * 8 * sizeof(u32), s));
+        launch_threshold(h, area_mask + off * hw, area_mask + off * hw, nb, s);
+        launch_popcount(h, nb, s);
+        launch_ncc(h, nb, mask ? mask + off * hw : nullptr, ncc ? ncc + off * hw : nullptr, s);
+        int rc = check_launch(h);
+        if (rc != VBS_OK) return rc;
+    }
+    return VBS_OK;
+}
+
+extern "C" int vbs_profile(vbs_handle* h, int enable) {
+    if (!h) return VBS_EINVAL;
+    for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    h->recs.clear();
+    h->prof = enable != 0;
+    return VBS_OK;
+}
+
+extern "C" int vbs_profile_read(vbs_handle* h, char* buf, int cap) {
+    if (!h || !buf || cap < 2) return VBS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    std::vector<std::string> names;
+    std::vector<double> tot;
+    std::vector<long> cnt;
+    for (auto& r : h->recs) {
+        float ms = 0;
+        HIPCHK(h, hipEventElapsedTime(&ms, r.a, r.b));
+        size_t i = 0;
+        for (; i < names.size(); ++i) if (names[i] == r.name) break;
+        if (i == names.size()) { names.push_back(r.name); tot.push_back(0); cnt.push_back(0); }
+        tot[i] += ms; cnt[i] += 1;
+    }
+    std::string out;
+    for (size_t i = 0; i < names.size(); ++i)
+        out += names[i] + " " + std::to_string(cnt[i]) + " " + std::to_string(tot[i]) + "\n";
+    if ((int)out.size() + 1 > cap) { h->err = "vbs_profile_read: buffer too small"; return VBS_EINVAL; }
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return VBS_OK;
+}
+
 extern "C" int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n) {
     if (!h || !out || n < 0 || n > h->maxb) return VBS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
@@ -367,6 +417,16 @@ extern "C" int vbs_displacement(vbs_handle* h, const float* table, int n, int m_
     if (n) launch_displacement(h, table, n, m_ref, warmup_frames, min_marker_size_px, max_displacement, disp,
                                (hipStream_t)stream);
     return check_launch(h);
+}
+
+extern "C" int vbs_displacement_f64(int device, const double* table, int n, int m_ref, int warmup_frames,
+                                    double min_marker_size_px, double max_displacement, double* disp,
+                                    void* stream) {
+    if (!table || !disp || n < 0 || m_ref < 1) return VBS_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return VBS_EHIP;
+    if (n) launch_displacement64(table, n, m_ref, warmup_frames, min_marker_size_px, max_displacement, disp,
+                                 (hipStream_t)stream);
+    return hipGetLastError() == hipSuccess ? VBS_OK : VBS_EHIP;
 }
 
 extern "C" int vbs_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane, void* stream) {

@@ -40,7 +40,11 @@ struct NccConst {
     double tbar, T2, l2, thr2;     // mean(template), sum((t-tbar)^2), l*l, 0.1*0.1
 };
 
+struct ProfRec { const char* name; hipEvent_t a, b; };
+
 struct vbs_handle {
+    bool prof = false;                     // record a HIP event pair around every kernel launch
+    std::vector<ProfRec> recs;
     int device, H, W, P, WW, maxm, maxb;   // P = row pitch (mult. of 64), WW = P/64 words per row
     int QE;                                // extended row-quads of the blur planes
     BranchParams bp;
@@ -86,6 +90,17 @@ struct vbs_handle {
         }                                                                                 \
     } while (0)
 
+// kernel launch with optional event bracketing on the launch stream (vbs_profile / vbs_profile_read)
+#define VBS_LAUNCH(h, s, name, ...)                                                       \
+    do {                                                                                  \
+        hipEvent_t a_ = nullptr, b_ = nullptr;                                            \
+        if ((h)->prof) {                                                                  \
+            (void)hipEventCreate(&a_); (void)hipEventCreate(&b_); (void)hipEventRecord(a_, s); \
+        }                                                                                 \
+        hipLaunchKernelGGL(__VA_ARGS__);                                                  \
+        if ((h)->prof) { (void)hipEventRecord(b_, s); (h)->recs.push_back({name, a_, b_}); } \
+    } while (0)
+
 // ---- launchers (each enqueues on `s`; nb = frames in this pass) --------------------------------
 void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
                  int64_t stride_row, hipStream_t s);
@@ -109,3 +124,6 @@ void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float
 void make_contour_lut(u8 out[256]);
 void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s);
+void launch_popcount(vbs_handle* h, int nb, hipStream_t s);
+void launch_displacement64(const double* table, int n, int m_ref, int warmup, double min_size, double max_disp,
+                           double* disp, hipStream_t s);

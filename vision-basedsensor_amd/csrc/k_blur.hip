@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_blur_v(const u32* __restrict__ planes, 
 void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
                  int64_t stride_row, hipStream_t s) {
     dim3 grid((h->P / 4 + 255) / 256, h->H, nb);
-    hipLaunchKernelGGL(k_gray, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row, h->gray,
+    VBS_LAUNCH(h, s, "k_gray", k_gray, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row, h->gray,
                        h->H, h->W, h->P);
 }
 
@@ -152,15 +152,15 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
     dim3 gh((h->P + 255) / 256, h->QE, nb);
     dim3 gv(h->WW, (h->H + 15) / 16, nb);
     if (!h->bp.small) {
-        hipLaunchKernelGGL((k_blur_h<11, 27, 20, 52>), gh, dim3(64), 0, s, gray, gstride_n, gstride_row,
+        VBS_LAUNCH(h, s, "k_blur_h", (k_blur_h<11, 27, 20, 52>), gh, dim3(64), 0, s, gray, gstride_n, gstride_row,
                            h->planes, h->H, h->W, h->P, h->QE, h->taps);
-        hipLaunchKernelGGL((k_blur_v<11, 27, 20, 52>), gv, dim3(256), 0, s, h->planes, h->area_bits,
+        VBS_LAUNCH(h, s, "k_blur_v", (k_blur_v<11, 27, 20, 52>), gv, dim3(256), 0, s, h->planes, h->area_bits,
                            area_u8, h->fstat, h->H, h->W, h->P, h->WW, h->QE, h->bp.thresh, h->bp.hi,
                            h->taps);
     } else {
-        hipLaunchKernelGGL((k_blur_h<7, 11, 12, 20>), gh, dim3(64), 0, s, gray, gstride_n, gstride_row,
+        VBS_LAUNCH(h, s, "k_blur_h", (k_blur_h<7, 11, 12, 20>), gh, dim3(64), 0, s, gray, gstride_n, gstride_row,
                            h->planes, h->H, h->W, h->P, h->QE, h->taps);
-        hipLaunchKernelGGL((k_blur_v<7, 11, 12, 20>), gv, dim3(256), 0, s, h->planes, h->area_bits,
+        VBS_LAUNCH(h, s, "k_blur_v", (k_blur_v<7, 11, 12, 20>), gv, dim3(256), 0, s, h->planes, h->area_bits,
                            area_u8, h->fstat, h->H, h->W, h->P, h->WW, h->QE, h->bp.thresh, h->bp.hi,
                            h->taps);
     }

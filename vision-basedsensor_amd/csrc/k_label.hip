@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void k_threshold(const u8* __restrict__ mask,
 void launch_threshold(vbs_handle* h, const u8* mask, const u8* area, int nb, hipStream_t s) {
     int64_t total = (int64_t)nb * h->H * (h->P / 16);
     int vec_ok = (h->W % 16 == 0) && (((uintptr_t)mask | (uintptr_t)area) % 16 == 0);
-    hipLaunchKernelGGL(k_threshold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mask, area,
+    VBS_LAUNCH(h, s, "k_threshold", k_threshold, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, mask, area,
                        h->mask_bits, h->area_bits, nb, h->H, h->W, h->P, h->WW, vec_ok);
 }
 
@@ -134,9 +134,9 @@ __global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits,
 
 void launch_morph(vbs_handle* h, int nb, hipStream_t s) {
     dim3 grid((h->H * h->WW + 255) / 256, nb);
-    hipLaunchKernelGGL(k_morph, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits,
+    VBS_LAUNCH(h, s, "k_morph", k_morph, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits,
                        h->er_bits, h->open_bits, h->H, h->W, h->WW, h->bp.ns, 0);
-    hipLaunchKernelGGL(k_morph, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits,
+    VBS_LAUNCH(h, s, "k_morph", k_morph, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits,
                        h->er_bits, h->open_bits, h->H, h->W, h->WW, h->bp.ns, 1);
 }
 
@@ -474,7 +474,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
 }
 
 void launch_label(vbs_handle* h, int nb, hipStream_t s) {
-    hipLaunchKernelGGL(k_label, dim3(nb, 2), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
+    VBS_LAUNCH(h, s, "k_label", k_label, dim3(nb, 2), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
                        h->node_pos, h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first,
                        h->area_sums, h->fstat, h->lut, h->H, h->W, h->WW, h->maxm);
 }
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
 }
 
 void launch_finalize(vbs_handle* h, int nb, float* det, int32_t* counts, hipStream_t s) {
-    hipLaunchKernelGGL(k_finalize, dim3(nb), dim3(256), 0, s, h->ncomp, h->band_sums, h->area_first,
+    VBS_LAUNCH(h, s, "k_finalize", k_finalize, dim3(nb), dim3(256), 0, s, h->ncomp, h->band_sums, h->area_first,
                        h->area_sums, h->open_bits, h->wbase, h->node_comp, h->fstat, h->ell, h->det64,
                        h->cnt, det, counts, h->H, h->W, h->WW, h->maxm);
 }

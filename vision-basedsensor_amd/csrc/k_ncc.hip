@@ -131,18 +131,34 @@ __global__ __launch_bounds__(256) void k_ncc_v(const double* __restrict__ hx, co
     if (amb) atomicAdd(&fstat[n * 8 + 1], amb);
 }
 
+// area popcount per frame (feeds the global mean of _normxcorr2 :153) when the bits did not come from k_blur_v
+__global__ __launch_bounds__(256) void k_popcount(const u64* __restrict__ bits, u32* __restrict__ fstat, int NW) {
+    __shared__ u32 part[4];
+    const int n = blockIdx.x;
+    u32 c = 0;
+    for (int i = threadIdx.x; i < NW; i += 256) c += __popcll(bits[(int64_t)n * NW + i]);
+    for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) fstat[n * 8 + 0] = part[0] + part[1] + part[2] + part[3];
+}
+
+void launch_popcount(vbs_handle* h, int nb, hipStream_t s) {
+    VBS_LAUNCH(h, s, "k_popcount", k_popcount, dim3(nb), dim3(256), 0, s, h->area_bits, h->fstat, h->H * h->WW);
+}
+
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s) {
     dim3 gh(((h->P / 8) * h->H + 255) / 256, nb);
     dim3 gv(h->WW, (h->H + 31) / 32, nb);
     if (!h->bp.small) {
-        hipLaunchKernelGGL((k_ncc_h<80, -40>), gh, dim3(256), 0, s, h->area_bits, h->hx, h->cx, h->H, h->P,
+        VBS_LAUNCH(h, s, "k_ncc_h", (k_ncc_h<80, -40>), gh, dim3(256), 0, s, h->area_bits, h->hx, h->cx, h->H, h->P,
                            h->WW, h->ncc);
-        hipLaunchKernelGGL((k_ncc_v<80, -40>), gv, dim3(256), 0, s, h->hx, h->cx, h->ncc_rx, h->ncc_ry,
+        VBS_LAUNCH(h, s, "k_ncc_v", (k_ncc_v<80, -40>), gv, dim3(256), 0, s, h->hx, h->cx, h->ncc_rx, h->ncc_ry,
                            h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->P, h->WW, h->ncc);
     } else {
-        hipLaunchKernelGGL((k_ncc_h<33, -16>), gh, dim3(256), 0, s, h->area_bits, h->hx, h->cx, h->H, h->P,
+        VBS_LAUNCH(h, s, "k_ncc_h", (k_ncc_h<33, -16>), gh, dim3(256), 0, s, h->area_bits, h->hx, h->cx, h->H, h->P,
                            h->WW, h->ncc);
-        hipLaunchKernelGGL((k_ncc_v<33, -16>), gv, dim3(256), 0, s, h->hx, h->cx, h->ncc_rx, h->ncc_ry,
+        VBS_LAUNCH(h, s, "k_ncc_v", (k_ncc_v<33, -16>), gv, dim3(256), 0, s, h->hx, h->cx, h->ncc_rx, h->ncc_ry,
                            h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->P, h->WW, h->ncc);
     }
 }

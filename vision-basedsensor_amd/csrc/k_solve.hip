@@ -136,9 +136,10 @@ __global__ __launch_bounds__(256) void k_solve3d(float* __restrict__ table, int6
 }
 
 // one workgroup; thread per reference ID walks the frames in order
-__global__ __launch_bounds__(1024) void k_displacement(const float* __restrict__ table, int n, int m_ref,
+template <typename TT>
+__global__ __launch_bounds__(1024) void k_displacement(const TT* __restrict__ table, int n, int m_ref,
                                                        int warmup, double min_size, double max_disp,
-                                                       float* __restrict__ disp) {
+                                                       TT* __restrict__ disp) {
     __shared__ int fmin_s;
     if (threadIdx.x == 0) fmin_s = 0x7fffffff;
     __syncthreads();
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(1024) void k_displacement(const float* __restrict__
     int myfirst = 0x7fffffff;
     for (int r = threadIdx.x; r < m_ref; r += blockDim.x) {
         for (int f = 0; f < n; ++f) {
-            const float* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
+            const TT* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
             if (((int)row[0] & VBS_FLAG_TRACKED) && (double)row[3] >= min_size) { myfirst = min(myfirst, f); break; }
         }
     }
@@ -158,9 +159,9 @@ __global__ __launch_bounds__(1024) void k_displacement(const float* __restrict__
         bool have = false, last_ok = false;
         double L[3] = {0, 0, 0};
         for (int f = 0; f < n; ++f) {
-            const float* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
-            float* o = disp + ((int64_t)f * m_ref + r) * VBS_DISP_COLS;
-            float out[VBS_DISP_COLS] = {0, 0, 0, 0, 0};
+            const TT* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
+            TT* o = disp + ((int64_t)f * m_ref + r) * VBS_DISP_COLS;
+            TT out[VBS_DISP_COLS] = {0, 0, 0, 0, 0};
             int flags = (int)row[0];
             bool present = (flags & VBS_FLAG_TRACKED) && (double)row[3] >= min_size && f >= fstart;
             if (present) {
@@ -170,7 +171,7 @@ __global__ __launch_bounds__(1024) void k_displacement(const float* __restrict__
                     double dx = C[0] - L[0], dy = C[1] - L[1], dz = C[2] - L[2];
                     double mm = sqrt(dx * dx + dy * dy + dz * dz);
                     if (!(mm > max_disp)) {
-                        out[0] = 1.f; out[1] = (float)dx; out[2] = (float)dy; out[3] = (float)dz; out[4] = (float)mm;
+                        out[0] = (TT)1; out[1] = (TT)dx; out[2] = (TT)dy; out[3] = (TT)dz; out[4] = (TT)mm;
                     }
                 }
                 have = true; last_ok = ok;
@@ -244,7 +245,7 @@ void launch_points(int which, const double* in, int n, const vbs_camera& cam, do
 void launch_track(vbs_handle* h, const float* det32, const int32_t* counts32, int nb,
                   const double* ref_xy, int m_ref, double min_dist, float* table, hipStream_t s) {
     CamD cam{};
-    hipLaunchKernelGGL(k_track, dim3(nb), dim3(256), 0, s, (const double*)nullptr, det32, counts32, h->maxm,
+    VBS_LAUNCH(h, s, "k_track", k_track, dim3(nb), dim3(256), 0, s, (const double*)nullptr, det32, counts32, h->maxm,
                        ref_xy, m_ref, min_dist, table, 0, cam, 0.0);
 }
 
@@ -252,23 +253,29 @@ void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, 
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s) {
     CamD c{};
     if (cam) c = make_cam(*cam);
-    hipLaunchKernelGGL(k_track, dim3(nb), dim3(256), 0, s, (const double*)h->det64, (const float*)nullptr,
+    VBS_LAUNCH(h, s, "k_track", k_track, dim3(nb), dim3(256), 0, s, (const double*)h->det64, (const float*)nullptr,
                        (const int32_t*)h->cnt, h->maxm, ref_xy, m_ref, min_dist, table, cam ? 1 : 0, c, min_size);
 }
 
 void launch_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_camera& cam, double min_size,
                     hipStream_t s) {
     int64_t rows = (int64_t)n * m_ref;
-    hipLaunchKernelGGL(k_solve3d, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, table, rows,
+    VBS_LAUNCH(h, s, "k_solve3d", k_solve3d, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, s, table, rows,
                        make_cam(cam), min_size);
 }
 
 void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup, double min_size,
                          double max_disp, float* disp, hipStream_t s) {
-    hipLaunchKernelGGL(k_displacement, dim3(1), dim3(1024), 0, s, table, n, m_ref, warmup, min_size, max_disp,
-                       disp);
+    VBS_LAUNCH(h, s, "k_displacement", k_displacement<float>, dim3(1), dim3(1024), 0, s, table, n, m_ref, warmup, min_size,
+                       max_disp, disp);
+}
+
+void launch_displacement64(const double* table, int n, int m_ref, int warmup, double min_size, double max_disp,
+                           double* disp, hipStream_t s) {
+    hipLaunchKernelGGL(k_displacement<double>, dim3(1), dim3(1024), 0, s, table, n, m_ref, warmup, min_size,
+                       max_disp, disp);
 }
 
 void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane, hipStream_t s) {
-    hipLaunchKernelGGL(k_plane_fit, dim3(n), dim3(64), 0, s, table, m_ref, plane);
+    VBS_LAUNCH(h, s, "k_plane_fit", k_plane_fit, dim3(n), dim3(64), 0, s, table, m_ref, plane);
 }

@@ -1,0 +1,64 @@
+"""Multi-GPU sharding of the frame axis: one process per GPU, `torch.distributed`
+(backend "nccl" == RCCL over xGMI on ROCm; "gloo" on CPU for tests).
+
+After frame 0 has fixed the reference table, frames are independent, so rank r takes the contiguous
+block [r*N/G, (r+1)*N/G).  The only exchanges are a broadcast of the reference table (a few KB, once)
+and ONE all-gather of the fixed-slot per-frame tables [N/G, M_ref, 10] float32; the last-seen
+displacement scan (`3d_reconstruction.py:277-314`) then runs on the gathered table.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as td
+
+
+def world():
+    if td.is_available() and td.is_initialized():
+        return td.get_rank(), td.get_world_size()
+    return 0, 1
+
+
+def shard_bounds(n_total: int, world_size: int, rank: int):
+    """Contiguous block of rank `rank`; the first n_total % world_size ranks get one frame more."""
+    base, extra = divmod(int(n_total), int(world_size))
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def broadcast_reference(ids, ref_xy, device, src: int = 0):
+    """Broadcast (ids int64 [M,2], ref_xy float64 [M,2]) from `src`; other ranks pass None."""
+    rank, ws = world()
+    if ws == 1:
+        return np.asarray(ids), np.asarray(ref_xy)
+    m = torch.zeros(1, dtype=torch.int64, device=device)
+    if rank == src:
+        m[0] = len(ids)
+    td.broadcast(m, src)
+    M = int(m.item())
+    buf = torch.zeros((M, 4), dtype=torch.float64, device=device)
+    if rank == src:
+        buf[:, :2] = torch.as_tensor(np.asarray(ids, dtype=np.float64), device=device)
+        buf[:, 2:] = torch.as_tensor(np.asarray(ref_xy, dtype=np.float64), device=device)
+    td.broadcast(buf, src)
+    out = buf.cpu().numpy()
+    return out[:, :2].astype(np.int64), out[:, 2:].copy()
+
+
+def gather_tables(local: torch.Tensor, n_total: int) -> torch.Tensor:
+    """All-gather the per-rank tables [n_r, M, C] into [n_total, M, C] (frame order).  Shards may differ
+    by one frame; they are padded to the largest shard so that a single collective is enough."""
+    rank, ws = world()
+    if ws == 1:
+        return local
+    per = [shard_bounds(n_total, ws, r) for r in range(ws)]
+    nmax = max(b - a for a, b in per)
+    pad = local
+    if local.shape[0] < nmax:
+        pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        pad[:local.shape[0]] = local
+    out = torch.empty((ws * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    td.all_gather_into_tensor(out, pad.contiguous())
+    if all(b - a == nmax for a, b in per):
+        return out
+    return torch.cat([out[r * nmax:r * nmax + (b - a)] for r, (a, b) in enumerate(per)], dim=0)

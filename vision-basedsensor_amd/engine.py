@@ -98,6 +98,34 @@ class Engine:
                         "vbs_ncc_map")
         return out
 
+    def normxcorr2(self, area_mask, want_mask=False):
+        """NCC of a two-valued uint8 area_mask [n,H,W] with the branch template -> float64 map."""
+        if area_mask.dim() == 2:
+            area_mask = area_mask.unsqueeze(0)
+        if area_mask.dtype != torch.uint8 or area_mask.device != self.device or not area_mask.is_contiguous() \
+                or tuple(area_mask.shape[1:]) != (self.H, self.W):
+            raise ValueError("area_mask must be a contiguous uint8 [n,H,W] tensor on the engine's device")
+        n = area_mask.shape[0]
+        out = torch.empty((n, self.H, self.W), dtype=torch.float64, device=self.device)
+        mask = torch.empty((n, self.H, self.W), dtype=torch.uint8, device=self.device) if want_mask else None
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_normxcorr2(self._h, _ptr(area_mask), n, _ptr(out), _ptr(mask),
+                                                self._stream()), "vbs_normxcorr2")
+        return (out, mask) if want_mask else out
+
+    def profile(self, enable: bool):
+        self._check(self.lib.vbs_profile(self._h, 1 if enable else 0), "vbs_profile")
+
+    def profile_read(self):
+        """{kernel: (launches, total_ms)} from the HIP events recorded since profile(True)."""
+        buf = C.create_string_buffer(8192)
+        self._check(self.lib.vbs_profile_read(self._h, buf, len(buf)), "vbs_profile_read")
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, cnt, ms = line.split()
+            out[name] = (int(cnt), float(ms))
+        return out
+
     def frame_stats(self, n):
         out = np.zeros((n, 8), dtype=np.uint32)
         self._check(self.lib.vbs_frame_stats(self._h, out.ctypes.data_as(C.c_void_p), n), "vbs_frame_stats")
@@ -179,12 +207,18 @@ class Engine:
         return plane
 
 
+def _dev_f64(x, dev, cols):
+    if isinstance(x, torch.Tensor):
+        return x.to(device=dev, dtype=torch.float64).reshape(-1, cols).contiguous()
+    return torch.as_tensor(np.asarray(x, dtype=np.float64).reshape(-1, cols), device=dev).contiguous()
+
+
 def undistort_points(points, cam: L.Camera, device=None):
     """float64 [n,2] -> [n,2] on the GPU (`MarkerAnalysis._undistort_points`)."""
     if not torch.cuda.is_available():
         raise L.VbsError("no GPU visible: vbs_amd has no CPU path")
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-    p = torch.as_tensor(np.asarray(points, dtype=np.float64).reshape(-1, 2), device=dev).contiguous()
+    p = _dev_f64(points, dev, 2)
     out = torch.empty_like(p)
     rc = L.lib().vbs_undistort_points(dev.index, _ptr(p), p.shape[0], C.byref(cam), _ptr(out),
                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
@@ -198,7 +232,7 @@ def calculate_3d(uvd, cam: L.Camera, device=None):
     if not torch.cuda.is_available():
         raise L.VbsError("no GPU visible: vbs_amd has no CPU path")
     dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
-    p = torch.as_tensor(np.asarray(uvd, dtype=np.float64).reshape(-1, 3), device=dev).contiguous()
+    p = _dev_f64(uvd, dev, 3)
     xyz = torch.empty_like(p)
     ok = torch.empty((p.shape[0],), dtype=torch.int32, device=dev)
     rc = L.lib().vbs_calculate_3d(dev.index, _ptr(p), p.shape[0], C.byref(cam), _ptr(xyz), _ptr(ok),
@@ -208,3 +242,19 @@ def calculate_3d(uvd, cam: L.Camera, device=None):
     if rc != L.VBS_OK:
         raise L.VbsError(f"vbs_calculate_3d failed ({rc})")
     return xyz, ok
+
+
+def displacement_f64(table64, warmup_frames=0, min_marker_size_px=0.0, max_displacement=50.0, device=None):
+    """float64 table [n,m,10] (host or device) -> disp float64 [n,m,5] on the GPU (`vbs_displacement_f64`)."""
+    if not torch.cuda.is_available():
+        raise L.VbsError("no GPU visible: vbs_amd has no CPU path")
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    t = torch.as_tensor(table64, dtype=torch.float64, device=dev).contiguous()
+    n, m = t.shape[0], t.shape[1]
+    disp = torch.empty((n, m, L.DISP_COLS), dtype=torch.float64, device=dev)
+    rc = L.lib().vbs_displacement_f64(dev.index, _ptr(t), n, m, int(warmup_frames), float(min_marker_size_px),
+                                      float(max_displacement), _ptr(disp),
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != L.VBS_OK:
+        raise L.VbsError(f"vbs_displacement_f64 failed ({rc})")
+    return disp

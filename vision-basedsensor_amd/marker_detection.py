@@ -1,0 +1,295 @@
+"""Drop-in for the reference's `code/Marker_Tracking/marker_detection.py`: same class, method names,
+argument meaning and exceptions; the per-frame work runs in HIP kernels on the MI355X (libvbs.so).
+
+    tracker = MarkerTracker(config)      # config keys as `marker_detection.py:478-489`
+    tracker.process()                    # video -> <name>_markers.csv        (`:429-462`)
+
+Differences a maintainer should know (all deliberate):
+ * frames are processed in device batches through the fused `vbs_track_to_3d`; the static per-stage
+   methods (`_find_markers`, `_marker_center`, `_normxcorr2`) are kept with NumPy in / NumPy out;
+ * video decode needs OpenCV, which is outside this path: `video_path` may also be a `.npy` / `.npz`
+   array of frames [N,H,W(,3)] uint8, and `process_frames(frames)` takes frames already in memory;
+   the annotated AVI (`:69-76,453`) and the drawing calls are not produced (visual only);
+ * extra optional config keys: `id_mode` ("as_written" | "full"), `kmeans` ("optimal" | "sklearn"),
+   `device` (GPU index), `batch` (frames per device batch).
+There is no CPU fallback: without a GPU or without the built library every compute call raises.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import ids as _ids
+
+CSV_COLUMNS = ["frameno", "row", "col", "Ox", "Oy", "Cx", "Cy", "major_axis", "minor_axis", "angle"]
+
+_ENGINES = {}
+
+
+def _engine(height, width, device=None, max_batch=16):
+    import torch
+    from .engine import Engine
+    dev = torch.cuda.current_device() if (device is None and torch.cuda.is_available()) else (device or 0)
+    key = (int(height), int(width), int(dev))
+    eng = _ENGINES.get(key)
+    if eng is None or eng.max_batch < max_batch:
+        eng = Engine(height, width, max_markers=1024, max_batch=max_batch, device=int(dev))
+        _ENGINES[key] = eng
+    return eng
+
+
+def _to_device(arr, eng):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(arr)).to(eng.device)
+
+
+def _crop_box(width, height, crop_ratios):
+    """`marker_detection.py:81-84` (int() truncation)."""
+    left = int(width * crop_ratios[0])
+    right = width - int(width * crop_ratios[1])
+    top = int(height * crop_ratios[2])
+    bottom = height - int(height * crop_ratios[3])
+    return left, right, top, bottom
+
+
+def _det_to_markers(det, count):
+    """det rows [x, y, major, minor, angle, label] -> the reference's marker dicts (`:238-243`)."""
+    return [{"center": (float(r[0]), float(r[1])), "major_axis": float(r[2]), "minor_axis": float(r[3]),
+             "angle": float(r[4])} for r in det[:count]]
+
+
+class MarkerTracker:
+    """A comprehensive marker tracking system for video analysis (GPU implementation)."""
+
+    def __init__(self, config):
+        self.config = config
+        self._validate_config()
+        self._setup_paths()
+        self.frame_count = 0
+        self.first_frame_markers = {}
+
+    # ---- configuration (`:33-48`) ------------------------------------------------------------
+    def _validate_config(self):
+        for key in ("video_path", "output_dir", "crop_ratios"):
+            if key not in self.config:
+                raise ValueError(f"Missing required config key: {key}")
+        if not os.path.exists(self.config["video_path"]):
+            raise FileNotFoundError(f"Video file not found: {self.config['video_path']}")
+
+    def _setup_paths(self):
+        os.makedirs(self.config["output_dir"], exist_ok=True)
+        video_name = os.path.splitext(os.path.basename(self.config["video_path"]))[0]
+        self.output_csv = os.path.join(self.config["output_dir"], f"{video_name}_markers.csv")
+        self.output_video = os.path.join(self.config["output_dir"], f"{video_name}_tracked.avi")
+
+    # ---- video source (`:50-76`) ---------------------------------------------------------------
+    def _init_video(self):
+        path = self.config["video_path"]
+        self._frames = None
+        self.cap = None
+        if path.endswith(".npy") or path.endswith(".npz"):
+            data = np.load(path)                     # allow_pickle=False (default)
+            if hasattr(data, "files"):
+                data = data[data.files[0]]
+            if data.dtype != np.uint8 or data.ndim not in (3, 4):
+                raise IOError(f"Could not open video: {path}")
+            self._frames = data
+            self.fps = float(self.config.get("fps", 0.0))
+            self.height, self.width = int(data.shape[1]), int(data.shape[2])
+        else:
+            try:
+                import cv2
+            except ImportError as e:
+                raise IOError(f"Could not open video: {path} (OpenCV is not installed; pass a .npy/.npz "
+                              f"frame array or call process_frames)") from e
+            self.cap = cv2.VideoCapture(path)
+            if not self.cap.isOpened():
+                raise IOError(f"Could not open video: {path}")
+            self.fps = self.cap.get(cv2.CAP_PROP_FPS)
+            self.width = int(self.cap.get(cv2.CAP_PROP_FRAME_WIDTH))
+            self.height = int(self.cap.get(cv2.CAP_PROP_FRAME_HEIGHT))
+        left, right, top, bottom = _crop_box(self.width, self.height, self.config["crop_ratios"])
+        self.crop_width, self.crop_height = right - left, bottom - top
+
+    def _preprocess_frame(self, frame):
+        """Crop (a view, `:80-85`); frame undistortion (`:93-109`) is not part of this build."""
+        left, right, top, bottom = _crop_box(self.width, self.height, self.config["crop_ratios"])
+        cropped = frame[top:bottom, left:right]
+        if "calibration_params" in self.config:
+            raise NotImplementedError("frame undistortion (marker_detection.py:93-109) is outside the "
+                                      "built hot path (SURVEY.md §8 f3); drop 'calibration_params'")
+        return cropped
+
+    # ---- per-stage static methods, NumPy in / NumPy out ------------------------------------------
+    @staticmethod
+    def _find_markers(frame):
+        """`:112-135` -> (mask uint8 {0,1}, area_mask uint8 {0,255}), both [h, w]."""
+        frame = np.asarray(frame)
+        if frame.dtype != np.uint8 or frame.ndim not in (2, 3):
+            raise ValueError("frame must be a uint8 image [h,w,3] (BGR) or [h,w]")
+        eng = _engine(frame.shape[0], frame.shape[1])
+        mask, area = eng.find_markers(_to_device(frame[None], eng))
+        return mask[0].cpu().numpy(), area[0].cpu().numpy()
+
+    @staticmethod
+    def _gkern(l=5, sig=1.0):
+        """`:138-143`: l x l Gaussian, sum 1 (host table)."""
+        ax = np.linspace(-(l - 1) / 2.0, (l - 1) / 2.0, l)
+        xx, yy = np.meshgrid(ax, ax)
+        k = np.exp(-0.5 * (np.square(xx) + np.square(yy)) / np.square(sig))
+        return k / np.sum(k)
+
+    @staticmethod
+    def _normxcorr2(template, image, mode="same"):
+        """`:146-164` for the operands the pipeline uses: `image` a two-valued uint8 area_mask and
+        `template` the `_gkern` of that image size's branch (80/13 above 480 rows, 33/7.4 otherwise)."""
+        image = np.asarray(image)
+        template = np.asarray(template)
+        small = image.shape[0] <= 480
+        l, sig = (33, 7.4) if small else (80, 13.0)
+        if mode != "same" or template.shape != (l, l) or \
+                not np.allclose(template, MarkerTracker._gkern(l, sig), rtol=1e-12, atol=0):
+            raise ValueError("the GPU _normxcorr2 supports mode='same' with the pipeline's template "
+                             f"_gkern({l}, {sig}) for this image height")
+        if image.dtype != np.uint8:
+            raise ValueError("image must be the uint8 area_mask")
+        eng = _engine(image.shape[0], image.shape[1])
+        return eng.normxcorr2(_to_device(image[None], eng))[0].cpu().numpy()
+
+    @staticmethod
+    def _marker_center(mask, area_mask, frame=None):
+        """`:166-249` -> list of {'center': (x, y), 'major_axis', 'minor_axis', 'angle'} in the
+        reference's order.  `frame` (drawing target) is ignored."""
+        mask = np.asarray(mask)
+        area_mask = np.asarray(area_mask)
+        if mask.shape != area_mask.shape or mask.ndim != 2:
+            raise ValueError("mask and area_mask must be 2-D arrays of the same shape")
+        eng = _engine(mask.shape[0], mask.shape[1])
+        det, counts = eng.marker_center(_to_device(mask.astype(np.uint8)[None], eng),
+                                        _to_device(area_mask.astype(np.uint8)[None], eng))
+        n = int(counts[0].item())
+        if n < 0:
+            from ._lib import VbsError
+            raise VbsError(f"_marker_center: device status {n} (capacity exceeded)")
+        return _det_to_markers(det[0].cpu().numpy(), n)
+
+    # ---- identities and tracking -----------------------------------------------------------------
+    def _process_first_frame(self, markers):
+        """`:275-347`.  Raises ValueError when no marker was found."""
+        table = _ids.assign_ids(markers, self.config.get("num_layers", 5),
+                                self.config.get("id_mode", "as_written"), self.config.get("kmeans", "optimal"))
+        self.first_frame_markers.update(table)
+
+    def _track_markers(self, frame, markers):
+        """`:349-396` -> list of row dicts (CSV_COLUMNS) for this frame."""
+        if not self.first_frame_markers or not markers:
+            return []
+        import torch
+        shape = getattr(frame, "shape", None)
+        h, w = (shape[0], shape[1]) if shape is not None else (self.crop_height, self.crop_width)
+        eng = _engine(h, w, self.config.get("device"))
+        det = np.zeros((1, eng.max_markers, 6), dtype=np.float32)
+        k = min(len(markers), eng.max_markers)
+        for i, m in enumerate(markers[:k]):
+            det[0, i, :5] = (m["center"][0], m["center"][1], m["major_axis"], m["minor_axis"], m["angle"])
+        _, ref_xy = _ids.reference_arrays(self.first_frame_markers)
+        table = eng.track(_to_device(det, eng), torch.tensor([k], dtype=torch.int32, device=eng.device), ref_xy,
+                          self.config.get("min_marker_distance", 20)).cpu().numpy()[0]
+        rows = []
+        for slot, ((layer, idx), ref) in enumerate(self.first_frame_markers.items()):
+            if int(table[slot, 0]) & 1:
+                cur = markers[int(table[slot, 9])]
+                rows.append({"frameno": self.frame_count, "row": layer, "col": idx, "Ox": ref["Ox"],
+                             "Oy": ref["Oy"], "Cx": cur["center"][0], "Cy": cur["center"][1],
+                             "major_axis": cur["major_axis"], "minor_axis": cur["minor_axis"],
+                             "angle": cur["angle"]})
+        return rows
+
+    # ---- main loop (`:429-462`) ---------------------------------------------------------------------
+    def process(self):
+        self._init_video()
+        if self._frames is not None:
+            data = self.process_frames(self._frames)
+        else:
+            batch = int(self.config.get("batch", 16))
+            data, buf = [], []
+            while True:
+                ret, frame = self.cap.read()
+                if ret:
+                    buf.append(frame)
+                if buf and (len(buf) == batch or not ret):
+                    data.extend(self._process_batch(np.stack(buf)))
+                    buf = []
+                if not ret:
+                    break
+        self._save_results(data)
+        self._cleanup()
+
+    def process_frames(self, frames):
+        """In-memory variant of `process`: frames uint8 [N,H,W(,3)] (NumPy or a torch device tensor)."""
+        if not hasattr(self, "width"):
+            self.height, self.width = int(frames.shape[1]), int(frames.shape[2])
+            left, right, top, bottom = _crop_box(self.width, self.height, self.config["crop_ratios"])
+            self.crop_width, self.crop_height = right - left, bottom - top
+        batch = int(self.config.get("batch", 16))
+        data = []
+        for s in range(0, frames.shape[0], batch):
+            data.extend(self._process_batch(frames[s:s + batch]))
+        return data
+
+    def _process_batch(self, frames):
+        import torch
+        left, right, top, bottom = _crop_box(self.width, self.height, self.config["crop_ratios"])
+        eng = _engine(bottom - top, right - left, self.config.get("device"), int(self.config.get("batch", 16)))
+        ft = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames))
+        ft = ft.to(eng.device)[:, top:bottom, left:right]           # crop = strided view, no copy
+        rows = []
+        if self.frame_count == 0:
+            _, det, counts = eng.track_to_3d(ft[:1], None, want_det=True)
+            n0 = int(counts[0].item())
+            if n0 < 0:
+                from ._lib import VbsError
+                raise VbsError(f"device status {n0} in frame 0")
+            self._process_first_frame(_det_to_markers(det[0].cpu().numpy(), n0))
+        ids, ref_xy = _ids.reference_arrays(self.first_frame_markers)
+        table, _, counts = eng.track_to_3d(ft, ref_xy, self.config.get("min_marker_distance", 20))
+        table = table.cpu().numpy().astype(np.float64)
+        refs = list(self.first_frame_markers.values())
+        for f in range(table.shape[0]):
+            for slot in np.nonzero(table[f, :, 0].astype(np.int64) & 1)[0]:
+                t = table[f, slot]
+                rows.append({"frameno": self.frame_count, "row": int(ids[slot, 0]), "col": int(ids[slot, 1]),
+                             "Ox": refs[slot]["Ox"], "Oy": refs[slot]["Oy"], "Cx": t[1], "Cy": t[2],
+                             "major_axis": t[3], "minor_axis": t[4], "angle": t[5]})
+            self.frame_count += 1
+            if self.frame_count % 100 == 0:
+                print(f"Processed frame {self.frame_count}")
+        return rows
+
+    def _save_results(self, data):
+        """`:464-468`."""
+        import pandas as pd
+        df = pd.DataFrame(data, columns=CSV_COLUMNS if not data else None)
+        df.to_csv(self.output_csv, index=False)
+        print(f"Saved tracking data to {self.output_csv}")
+
+    def _cleanup(self):
+        if getattr(self, "cap", None) is not None:
+            self.cap.release()
+
+
+# Names `tracking.py:7` imports (absent from the published module)
+find_marker = MarkerTracker._find_markers
+marker_center = MarkerTracker._marker_center
+
+
+if __name__ == "__main__":
+    config = {
+        "video_path": "./video/test2.avi",
+        "output_dir": "./results",
+        "crop_ratios": (1 / 8, 1 / 8, 1 / 16, 0),
+        "num_layers": 5,
+        "min_marker_distance": 20,
+    }
+    MarkerTracker(config).process()

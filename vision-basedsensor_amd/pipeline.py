@@ -1,0 +1,57 @@
+"""Batch driver: frames resident on the device -> fixed-slot tables -> (all-gather) -> displacement
+-> plane-fit pose.  This is what `bench.py` times and what the multi-GPU path runs per rank."""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import dist as D
+from . import ids as _ids
+from .engine import Engine
+from .marker_detection import _det_to_markers
+
+
+@dataclass
+class TrackResult:
+    ids: np.ndarray            # [M,2] (row, col) per slot
+    ref_xy: np.ndarray         # [M,2]
+    table: torch.Tensor        # [N,M,10] float32 (gathered when distributed)
+    disp: Optional[torch.Tensor]     # [N,M,5]
+    plane: Optional[torch.Tensor]    # [N,5]
+
+
+def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mode="full", kmeans="optimal"):
+    """Detect frame 0 on the device and run the host-side ID assignment (once per video)."""
+    _, det, counts = eng.track_to_3d(frame0[:1], None, want_det=True)
+    n0 = int(counts[0].item())
+    if n0 < 0:
+        raise L.VbsError(f"device status {n0} in frame 0")
+    table = _ids.assign_ids(_det_to_markers(det[0].cpu().numpy(), n0), num_layers, id_mode, kmeans)
+    return _ids.reference_arrays(table)
+
+
+def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None, cam: L.Camera = None,
+                min_dist=20.0, min_marker_size_px=5.0, warmup_frames=0, max_displacement=50.0,
+                num_layers=5, id_mode="full", kmeans="optimal", with_plane=True) -> TrackResult:
+    """One rank's part of a sequence of `n_total` frames (`frames_local` = this rank's contiguous block).
+    `ref` = (ids, ref_xy) if already known; otherwise the rank holding frame 0 computes and broadcasts it."""
+    rank, ws = D.world()
+    if ref is None:
+        ids = xy = None
+        if rank == 0:
+            ids, xy = reference_from_frame0(eng, frames_local, num_layers, id_mode, kmeans)
+        ids, xy = D.broadcast_reference(ids, xy, eng.device)
+    else:
+        ids, xy = ref
+    table, _, counts = eng.track_to_3d(frames_local, xy, min_dist, cam, min_marker_size_px)
+    table = D.gather_tables(table, n_total)
+    disp = plane = None
+    if cam is not None:
+        disp = eng.displacement(table, warmup_frames, min_marker_size_px, max_displacement)
+        if with_plane:
+            plane = eng.plane_fit(table)
+    return TrackResult(ids, xy, table, disp, plane)
