@@ -155,7 +155,7 @@ def main():
         elapsed = float(t.item())
     table, disp, counts = out
     tracked = int((table[..., 0].int() & 1).sum().item())
-    solved = int((table[..., 0].int() & 2).sum().item())
+    solved = int(((table[..., 0].int() & 2) > 0).sum().item())
     assert int(counts.min().item()) >= 0, "a frame reported a device status"
     assert tracked == n_total * M, f"tracked {tracked} of {n_total * M} marker observations"
 

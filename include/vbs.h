@@ -114,16 +114,18 @@ int vbs_calculate_3d(int device, const double* uvd, int n, const vbs_camera* cam
  * (maximum/minimum_filter :171-174) -> 4-connected labels (:176) -> centroids (:181); 5x5 open
  * (:195) -> external contours (:196) -> fitEllipse (:208) -> contour/centre matching (:222-243).
  * mask, area_mask [dev] uint8 [n,h,w] dense, two-valued (0 / non-zero).
- * det [dev] float32 [n,max_markers,VBS_DET_COLS], rows in the reference's output order;
+ * det [dev] float64 [n,max_markers,VBS_DET_COLS], rows in the reference's output order (centroids are
+ * integer sums / count in float64, bit-identical to ndimage.center_of_mass; axes and angle are the
+ * float32 values cv2.fitEllipse would return, widened);
  * counts [dev] int32 [n] = number of rows, or a negative status for that frame. */
 int vbs_marker_center(vbs_handle* h, const uint8_t* mask, const uint8_t* area_mask, int n,
-                      float* det, int32_t* counts, void* stream);
+                      double* det, int32_t* counts, void* stream);
 
 /* MarkerTracker._track_markers (marker_detection.py:349-396): per reference ID the nearest
  * detection (first on ties), dropped when farther than min_dist.  ref_xy [dev] float64 [m_ref,2]
  * = (Ox, Oy) in reference-dict order; table [dev] float32 [n,m_ref,VBS_TABLE_COLS]; XYZ columns
  * are left 0 and VBS_FLAG_XYZ clear. */
-int vbs_track(vbs_handle* h, const float* det, const int32_t* counts, int n, const double* ref_xy,
+int vbs_track(vbs_handle* h, const double* det, const int32_t* counts, int n, const double* ref_xy,
               int m_ref, double min_dist, float* table, void* stream);
 
 /* MarkerAnalysis._undistort_points + _calculate_3d_position (3d_reconstruction.py:185-238) on the
@@ -137,7 +139,7 @@ int vbs_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_camera*
 int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
                     int64_t stride_row, const double* ref_xy, int m_ref, double min_dist,
                     const vbs_camera* cam, double min_marker_size_px, float* table,
-                    float* det, int32_t* counts, void* stream);
+                    double* det, int32_t* counts, void* stream);
 
 /* MarkerAnalysis._track_markers (3d_reconstruction.py:240-316) on a (gathered) table of n
  * consecutive frames: per ID the displacement against the frame where it was LAST SEEN; frames

@@ -4,6 +4,7 @@ same seeded inputs, or against the committed goldens produced by the reference's
 
 Stated tolerances (north_star: IDs bit-exact, centroids / 3-D within an fp32 tolerance):
   masks, labels, counts, IDs          : exact
+  centroids in the float64 det / CSV  : exact (integer sums / count, same IEEE division as SciPy)
   centroids Cx, Cy (float32 tables)   : |d| <= 2.5e-4 px   (2 ulp of float32 at 2048)
   major / minor axis (float32)        : |d| <= 1e-3 px      (observed: identical after float32 rounding)
   ellipse angle                       : compared mod 180 deg, only when major - minor > 1e-2 px
@@ -49,7 +50,7 @@ def angle_close(a, b, tol=0.05):
 def compare_markers(got, want):
     assert len(got) == len(want)
     for g, w in zip(got, want):
-        assert abs(g["center"][0] - w["center"][0]) <= TOL_XY and abs(g["center"][1] - w["center"][1]) <= TOL_XY
+        assert g["center"][0] == w["center"][0] and g["center"][1] == w["center"][1]      # bit-exact
         assert abs(g["major_axis"] - w["major_axis"]) <= TOL_AX
         assert abs(g["minor_axis"] - w["minor_axis"]) <= TOL_AX
         if w["major_axis"] - w["minor_axis"] > 1e-2:
@@ -117,9 +118,7 @@ def test_normxcorr2_golden_from_reference_body(golden_dir):
     """`MarkerTracker._normxcorr2` against the output of the reference's own `_normxcorr2` (golden)."""
     from vbs_amd.marker_detection import MarkerTracker
     G = np.load(os.path.join(golden_dir, "stages.npz"))
-    img = np.zeros((120, 192), dtype=np.uint8)          # golden image is 120 x 130: pad the width, compare inside
-    big = G["ncc_big_image"]
-    eng_img = big
+    eng_img = G["ncc_big_image"]                        # 120 x 130, small-image branch (l = 33)
     t = MarkerTracker._gkern(33, 7.4)
     out = MarkerTracker._normxcorr2(t, eng_img)
     ref = G["ncc_big_out_l33"]
@@ -128,7 +127,6 @@ def test_normxcorr2_golden_from_reference_body(golden_dir):
     assert np.array_equal(out > 0.1, ref > 0.1)
     with pytest.raises(ValueError):
         MarkerTracker._normxcorr2(MarkerTracker._gkern(9, 2.0), eng_img)
-    del img
 
 
 # ------------------------------------------------------------------------------------------------
@@ -160,12 +158,14 @@ def test_band_centroids_golden(golden_dir, tag):
     n = int(counts[0])
     det = det[0].cpu().numpy()[:n]
     assert n > 0
+    want = O.marker_center(mask, mask)               # blobs cut by the crop border may stay unmatched
+    assert n == len(want)
     if tag != "rand":
-        assert n == centers.shape[0]
+        assert n >= 0.9 * centers.shape[0]
     lab = det[:, 5].astype(int) - 1
     assert len(set(lab.tolist())) == n
-    assert np.max(np.abs(det[:, 0] - centers[lab, 1])) <= TOL_XY
-    assert np.max(np.abs(det[:, 1] - centers[lab, 0])) <= TOL_XY
+    assert np.array_equal(det[:, 0], centers[lab, 1])        # bit-exact vs ndimage.center_of_mass
+    assert np.array_equal(det[:, 1], centers[lab, 0])
     eng.close()
 
 
@@ -214,14 +214,14 @@ def test_marker_tracker_process_frames(tmp_path, tag, id_mode):
            "num_layers": 5, "min_marker_distance": 20, "id_mode": id_mode, "batch": 3}
     trk = MarkerTracker(cfg)
     trk.process()
-    df = pd.read_csv(trk.output_csv)
+    df = pd.read_csv(trk.output_csv, float_precision="round_trip")     # the default parser is 1 ulp lossy
     assert list(df.columns) == CSV_COLUMNS
     rows, ref = O.process_frames(list(frames), crop_ratios=crop, id_mode=id_mode)
     assert list(trk.first_frame_markers.keys()) == list(ref.keys())
     assert len(df) == len(rows)
     want = pd.DataFrame(rows, columns=CSV_COLUMNS)
     assert (df[["frameno", "row", "col"]].to_numpy() == want[["frameno", "row", "col"]].to_numpy()).all()
-    for c, tol in (("Ox", TOL_XY), ("Oy", TOL_XY), ("Cx", TOL_XY), ("Cy", TOL_XY), ("major_axis", TOL_AX),
+    for c, tol in (("Ox", 0.0), ("Oy", 0.0), ("Cx", 0.0), ("Cy", 0.0), ("major_axis", TOL_AX),
                    ("minor_axis", TOL_AX)):
         assert np.max(np.abs(df[c].to_numpy() - want[c].to_numpy())) <= tol, c
     if id_mode == "as_written":
@@ -323,7 +323,8 @@ def test_fused_track_to_3d_displacement_plane(tag, nframes):
     K, dist, R, T = S.default_camera(spec)
     dist = np.array([-0.05, 0.01, 0.0005, -0.0003, 0.0], dtype=np.float32)
     cam = L.make_camera(K, dist, R, T, 2.0)
-    res = track_shard(eng, torch.from_numpy(frames).cuda(), nframes, cam=cam, warmup_frames=1, id_mode="full")
+    warm = 1 if nframes > 2 else 0
+    res = track_shard(eng, torch.from_numpy(frames).cuda(), nframes, cam=cam, warmup_frames=warm, id_mode="full")
     rows, ref = O.process_frames(list(frames), id_mode="full")
     assert [tuple(k) for k in res.ids.tolist()] == list(ref.keys())
     table = res.table.cpu().numpy()
@@ -335,7 +336,7 @@ def test_fused_track_to_3d_displacement_plane(tag, nframes):
         assert int(t[0]) & 1
         assert abs(t[1] - r["Cx"]) <= TOL_XY and abs(t[2] - r["Cy"]) <= TOL_XY
         assert abs(t[3] - r["major_axis"]) <= TOL_AX and abs(t[4] - r["minor_axis"]) <= TOL_AX
-    rows3 = O.track_markers_3d(rows, K, dist, R, T, warmup_frames=1)
+    rows3 = O.track_markers_3d(rows, K, dist, R, T, warmup_frames=warm)
     assert int(disp[..., 0].sum()) == len(rows3) and len(rows3) > 0
     for r in rows3:
         s = slot[(r["row"], r["col"])]

@@ -333,7 +333,7 @@ extern "C" int vbs_calculate_3d(int device, const double* uvd, int n, const vbs_
 }
 
 extern "C" int vbs_marker_center(vbs_handle* h, const uint8_t* mask, const uint8_t* area_mask, int n,
-                                 float* det, int32_t* counts, void* stream) {
+                                 double* det, int32_t* counts, void* stream) {
     if (!h) return VBS_EINVAL;
     if (!mask || !area_mask || !det || !counts || n < 0) { h->err = "vbs_marker_center: bad argument"; return VBS_EINVAL; }
     hipStream_t s = (hipStream_t)stream;
@@ -352,7 +352,7 @@ extern "C" int vbs_marker_center(vbs_handle* h, const uint8_t* mask, const uint8
     return VBS_OK;
 }
 
-extern "C" int vbs_track(vbs_handle* h, const float* det, const int32_t* counts, int n, const double* ref_xy,
+extern "C" int vbs_track(vbs_handle* h, const double* det, const int32_t* counts, int n, const double* ref_xy,
                          int m_ref, double min_dist, float* table, void* stream) {
     if (!h) return VBS_EINVAL;
     if (!det || !counts || !ref_xy || !table || n < 0 || m_ref < 1) { h->err = "vbs_track: bad argument"; return VBS_EINVAL; }
@@ -380,7 +380,7 @@ extern "C" int vbs_solve3d(vbs_handle* h, float* table, int n, int m_ref, const 
 
 extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
                                int64_t stride_row, const double* ref_xy, int m_ref, double min_dist,
-                               const vbs_camera* cam, double min_marker_size_px, float* table, float* det,
+                               const vbs_camera* cam, double min_marker_size_px, float* table, double* det,
                                int32_t* counts, void* stream) {
     if (!h) return VBS_EINVAL;
     if (!frames || n < 0 || (channels != 1 && channels != 3) || stride_row < (int64_t)h->W * channels ||

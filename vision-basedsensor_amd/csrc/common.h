@@ -112,8 +112,8 @@ void launch_points(int which, const double* in, int n, const vbs_camera& cam, do
 void launch_threshold(vbs_handle* h, const u8* mask, const u8* area, int nb, hipStream_t s);
 void launch_morph(vbs_handle* h, int nb, hipStream_t s);
 void launch_label(vbs_handle* h, int nb, hipStream_t s);
-void launch_finalize(vbs_handle* h, int nb, float* det, int32_t* counts, hipStream_t s);
-void launch_track(vbs_handle* h, const float* det32, const int32_t* counts32, int nb,
+void launch_finalize(vbs_handle* h, int nb, double* det, int32_t* counts, hipStream_t s);
+void launch_track(vbs_handle* h, const double* det, const int32_t* counts32, int nb,
                   const double* ref_xy, int m_ref, double min_dist, float* table, hipStream_t s);
 void launch_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_camera& cam,
                     double min_size, hipStream_t s);

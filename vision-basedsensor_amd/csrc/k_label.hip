@@ -639,7 +639,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
                                                   const u32* __restrict__ node_comp_all,
                                                   const u32* __restrict__ fstat, double* __restrict__ ell_all,
                                                   double* __restrict__ det64, int32_t* __restrict__ cnt64,
-                                                  float* __restrict__ det32, int32_t* __restrict__ cnt32,
+                                                  double* __restrict__ det32, int32_t* __restrict__ cnt32,
                                                   int H, int W, int WW, int maxm) {
     __shared__ double bx[1024], by[1024];
     __shared__ u8 unmatched[1024];
@@ -671,7 +671,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
     const u32* wbase = wbase_all + ((int64_t)n * 2 + 1) * NW;
     const u32* node_comp = node_comp_all + ((int64_t)n * 2 + 1) * VBS_RUN_CAP;
     double* d64 = det64 + (int64_t)n * maxm * 6;
-    float* d32 = det32 ? det32 + (int64_t)n * maxm * 6 : nullptr;
+    double* d32 = det32 ? det32 + (int64_t)n * maxm * 6 : nullptr;
     int count = 0;
     for (int ci = na - 1; ci >= 0; --ci) {
         const double* e = ell + ci * 8;
@@ -705,9 +705,8 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
                 double* o = d64 + count * 6;
                 o[0] = bx[bi]; o[1] = by[bi]; o[2] = major; o[3] = minor; o[4] = eang; o[5] = bi + 1;
                 if (d32) {
-                    float* f = d32 + count * 6;
-                    f[0] = (float)bx[bi]; f[1] = (float)by[bi]; f[2] = (float)major; f[3] = (float)minor;
-                    f[4] = (float)eang; f[5] = (float)(bi + 1);
+                    double* f = d32 + count * 6;
+                    f[0] = bx[bi]; f[1] = by[bi]; f[2] = major; f[3] = minor; f[4] = eang; f[5] = bi + 1;
                 }
             }
             ++count;
@@ -717,7 +716,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
     if (tid == 0) { cnt64[n] = count; if (cnt32) cnt32[n] = count; }
 }
 
-void launch_finalize(vbs_handle* h, int nb, float* det, int32_t* counts, hipStream_t s) {
+void launch_finalize(vbs_handle* h, int nb, double* det, int32_t* counts, hipStream_t s) {
     VBS_LAUNCH(h, s, "k_finalize", k_finalize, dim3(nb), dim3(256), 0, s, h->ncomp, h->band_sums, h->area_first,
                        h->area_sums, h->open_bits, h->wbase, h->node_comp, h->fstat, h->ell, h->det64,
                        h->cnt, det, counts, h->H, h->W, h->WW, h->maxm);

@@ -64,7 +64,6 @@ __device__ bool solve_marker(const CamD& c, double u, double v, double d, double
 
 // one workgroup per frame; thread per reference ID
 __global__ __launch_bounds__(256) void k_track(const double* __restrict__ det64,
-                                               const float* __restrict__ det32,
                                                const int32_t* __restrict__ counts, int maxm,
                                                const double* __restrict__ ref_xy, int m_ref, double min_dist,
                                                float* __restrict__ table, int do3d, CamD cam,
@@ -74,8 +73,8 @@ __global__ __launch_bounds__(256) void k_track(const double* __restrict__ det64,
     int cnt = counts[n];
     if (cnt < 0) cnt = 0;
     for (int i = tid; i < cnt; i += blockDim.x) {
-        if (det64) { mx[i] = det64[((int64_t)n * maxm + i) * 6 + 0]; my[i] = det64[((int64_t)n * maxm + i) * 6 + 1]; }
-        else { mx[i] = det32[((int64_t)n * maxm + i) * 6 + 0]; my[i] = det32[((int64_t)n * maxm + i) * 6 + 1]; }
+        mx[i] = det64[((int64_t)n * maxm + i) * 6 + 0];
+        my[i] = det64[((int64_t)n * maxm + i) * 6 + 1];
     }
     __syncthreads();
     for (int r = tid; r < m_ref; r += blockDim.x) {
@@ -90,14 +89,8 @@ __global__ __launch_bounds__(256) void k_track(const double* __restrict__ det64,
         float* row = table + ((int64_t)n * m_ref + r) * VBS_TABLE_COLS;
         float o[VBS_TABLE_COLS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
         if (bi >= 0 && !(best > min_dist)) {
-            double major, minor, ang;
-            if (det64) {
-                const double* d = det64 + ((int64_t)n * maxm + bi) * 6;
-                major = d[2]; minor = d[3]; ang = d[4];
-            } else {
-                const float* d = det32 + ((int64_t)n * maxm + bi) * 6;
-                major = d[2]; minor = d[3]; ang = d[4];
-            }
+            const double* d = det64 + ((int64_t)n * maxm + bi) * 6;
+            double major = d[2], minor = d[3], ang = d[4];
             int flags = VBS_FLAG_TRACKED;
             o[1] = (float)mx[bi]; o[2] = (float)my[bi]; o[3] = (float)major; o[4] = (float)minor;
             o[5] = (float)ang; o[9] = (float)bi;
@@ -242,10 +235,10 @@ void launch_points(int which, const double* in, int n, const vbs_camera& cam, do
     hipLaunchKernelGGL(k_points, dim3((n + 255) / 256), dim3(256), 0, s, which, in, n, make_cam(cam), out, ok);
 }
 
-void launch_track(vbs_handle* h, const float* det32, const int32_t* counts32, int nb,
+void launch_track(vbs_handle* h, const double* det, const int32_t* counts32, int nb,
                   const double* ref_xy, int m_ref, double min_dist, float* table, hipStream_t s) {
     CamD cam{};
-    VBS_LAUNCH(h, s, "k_track", k_track, dim3(nb), dim3(256), 0, s, (const double*)nullptr, det32, counts32, h->maxm,
+    VBS_LAUNCH(h, s, "k_track", k_track, dim3(nb), dim3(256), 0, s, det, counts32, h->maxm,
                        ref_xy, m_ref, min_dist, table, 0, cam, 0.0);
 }
 
@@ -253,7 +246,7 @@ void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, 
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s) {
     CamD c{};
     if (cam) c = make_cam(*cam);
-    VBS_LAUNCH(h, s, "k_track", k_track, dim3(nb), dim3(256), 0, s, (const double*)h->det64, (const float*)nullptr,
+    VBS_LAUNCH(h, s, "k_track", k_track, dim3(nb), dim3(256), 0, s, (const double*)h->det64,
                        (const int32_t*)h->cnt, h->maxm, ref_xy, m_ref, min_dist, table, cam ? 1 : 0, c, min_size);
 }
 

@@ -141,7 +141,7 @@ class Engine:
         n = mask.shape[0]
         if tuple(mask.shape[1:]) != (self.H, self.W) or mask.shape != area_mask.shape:
             raise ValueError("mask shape mismatch")
-        det = torch.zeros((n, self.max_markers, L.DET_COLS), dtype=torch.float32, device=self.device)
+        det = torch.zeros((n, self.max_markers, L.DET_COLS), dtype=torch.float64, device=self.device)
         counts = torch.zeros((n,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):
             self._check(self.lib.vbs_marker_center(self._h, _ptr(mask), _ptr(area_mask), n, _ptr(det),
@@ -151,6 +151,8 @@ class Engine:
     # ---- a15 ---------------------------------------------------------------------------------
     def track(self, det, counts, ref_xy, min_dist=20.0):
         ref = torch.as_tensor(ref_xy, dtype=torch.float64, device=self.device).contiguous().reshape(-1, 2)
+        if det.dtype != torch.float64 or not det.is_contiguous():
+            raise ValueError("det must be a contiguous float64 tensor [n, max_markers, 6]")
         n, m = det.shape[0], ref.shape[0]
         table = torch.empty((n, m, L.TABLE_COLS), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
@@ -176,7 +178,7 @@ class Engine:
             ref = torch.as_tensor(ref_xy, dtype=torch.float64, device=self.device).contiguous().reshape(-1, 2)
             m = ref.shape[0]
             table = torch.empty((n, m, L.TABLE_COLS), dtype=torch.float32, device=self.device)
-        det = torch.zeros((n, self.max_markers, L.DET_COLS), dtype=torch.float32,
+        det = torch.zeros((n, self.max_markers, L.DET_COLS), dtype=torch.float64,
                           device=self.device) if want_det else None
         counts = torch.zeros((n,), dtype=torch.int32, device=self.device)
         with torch.cuda.device(self.device):

@@ -189,7 +189,7 @@ class MarkerTracker:
         shape = getattr(frame, "shape", None)
         h, w = (shape[0], shape[1]) if shape is not None else (self.crop_height, self.crop_width)
         eng = _engine(h, w, self.config.get("device"))
-        det = np.zeros((1, eng.max_markers, 6), dtype=np.float32)
+        det = np.zeros((1, eng.max_markers, 6), dtype=np.float64)
         k = min(len(markers), eng.max_markers)
         for i, m in enumerate(markers[:k]):
             det[0, i, :5] = (m["center"][0], m["center"][1], m["major_axis"], m["minor_axis"], m["angle"])
@@ -253,15 +253,17 @@ class MarkerTracker:
                 raise VbsError(f"device status {n0} in frame 0")
             self._process_first_frame(_det_to_markers(det[0].cpu().numpy(), n0))
         ids, ref_xy = _ids.reference_arrays(self.first_frame_markers)
-        table, _, counts = eng.track_to_3d(ft, ref_xy, self.config.get("min_marker_distance", 20))
-        table = table.cpu().numpy().astype(np.float64)
+        table, det, counts = eng.track_to_3d(ft, ref_xy, self.config.get("min_marker_distance", 20),
+                                             want_det=True)
+        table = table.cpu().numpy()
+        det = det.cpu().numpy()                 # float64 rows: the CSV keeps the reference's precision
         refs = list(self.first_frame_markers.values())
         for f in range(table.shape[0]):
             for slot in np.nonzero(table[f, :, 0].astype(np.int64) & 1)[0]:
-                t = table[f, slot]
+                d = det[f, int(table[f, slot, 9])]
                 rows.append({"frameno": self.frame_count, "row": int(ids[slot, 0]), "col": int(ids[slot, 1]),
-                             "Ox": refs[slot]["Ox"], "Oy": refs[slot]["Oy"], "Cx": t[1], "Cy": t[2],
-                             "major_axis": t[3], "minor_axis": t[4], "angle": t[5]})
+                             "Ox": refs[slot]["Ox"], "Oy": refs[slot]["Oy"], "Cx": d[0], "Cy": d[1],
+                             "major_axis": d[2], "minor_axis": d[3], "angle": d[4]})
             self.frame_count += 1
             if self.frame_count % 100 == 0:
                 print(f"Processed frame {self.frame_count}")
