@@ -188,6 +188,18 @@ def test_marker_center_random_blobs(seed):
     compare_markers(got, want)
 
 
+def test_matching_sequential_replay_equals_parallel(monkeypatch):
+    """The parallel matching and the sequential replay (taken when two contours claim one centre) agree."""
+    from vbs_amd.marker_detection import MarkerTracker
+    spec = S.config2()
+    frame = S.make_frames(spec, [7], seed=8)[0]
+    om, oa = O.find_markers(frame)
+    par = MarkerTracker._marker_center(om, oa)
+    monkeypatch.setenv("VBS_FORCE_SEQ_MATCH", "1")
+    seq = MarkerTracker._marker_center(om, oa)
+    assert par == seq and len(par) == spec.n_markers
+
+
 def test_marker_center_empty_and_capacity():
     from vbs_amd.marker_detection import MarkerTracker
     z = np.zeros((128, 256), dtype=np.uint8)

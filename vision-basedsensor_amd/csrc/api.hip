@@ -59,6 +59,8 @@ static void ncc_consts(int l, double sigma, NccConst* nc) {
     double se = 0;
     for (int i = 0; i < l; ++i) { e[i] = std::exp(-0.5 * ax[i] * ax[i] / (sigma * sigma)); se += e[i]; }
     for (int i = 0; i < VBS_NCC_MAXL; ++i) nc->g[i] = i < l ? e[i] / se : 0.0;
+    nc->cg[0] = 0.0;
+    for (int i = 0; i < VBS_NCC_MAXL; ++i) nc->cg[i + 1] = nc->cg[i] + nc->g[i];
     // template statistics as `_normxcorr2` forms them: t = K / sum(K), tbar = mean(t), T2 = sum((t - tbar)^2)
     std::vector<double> K((size_t)l * l);
     double sk = 0;
@@ -74,6 +76,7 @@ static void ncc_consts(int l, double sigma, NccConst* nc) {
     for (auto& x : K) t2 += (x - nc->tbar) * (x - nc->tbar);
     nc->T2 = t2;
     nc->l2 = (double)l * l;
+    nc->inv_l2 = 1.0 / nc->l2;
     nc->thr2 = 0.1 * 0.1;
 }
 
@@ -168,7 +171,6 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(planes, B * 4 * (size_t)h->QE * h->P);
     ALLOC(area_bits, B * HW); ALLOC(mask_bits, B * HW); ALLOC(band_bits, B * HW);
     ALLOC(er_bits, B * HW); ALLOC(open_bits, B * HW);
-    ALLOC(hx, B * HP); ALLOC(cx, B * HP);
     ALLOC(ncc_rx, (size_t)width); ALLOC(ncc_ry, (size_t)height);
     ALLOC(fstat, B * 8);
     ALLOC(wbase, B * 2 * HW);

@@ -37,7 +37,9 @@ struct BranchParams {              // marker_detection.py:117-126,129,170
 
 struct NccConst {
     double g[VBS_NCC_MAXL];        // 1-D normalised Gaussian, template = g (x) g
+    double cg[VBS_NCC_MAXL + 1];   // cg[k] = g[0] + ... + g[k-1]
     double tbar, T2, l2, thr2;     // mean(template), sum((t-tbar)^2), l*l, 0.1*0.1
+    double inv_l2;
 };
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
@@ -59,8 +61,6 @@ struct vbs_handle {
     u64* band_bits;    // [maxb][H][WW]
     u64* er_bits;      // [maxb][H][WW]
     u64* open_bits;    // [maxb][H][WW]
-    double* hx;        // [maxb][H][P]      horizontal NCC pass
-    u8* cx;            // [maxb][H][P]      horizontal box counts
     double* ncc_rx;    // [W]  sum of g over the in-image part of the window (columns)
     double* ncc_ry;    // [H]
     u32* fstat;        // [maxb][8]  0: area popcount, 1: ambiguous ncc pixels, 2: status

@@ -14,6 +14,8 @@
 //                 contour vertices, classified per border pixel from its 8-neighbourhood by a LUT.
 //   k_finalize  : per frame: centroids, fitEllipse (:208) from the vertex moments via two normal-
 //                 equation solves in float64, then the sequential contour <-> centre matching (:203-243).
+#include <cstdlib>
+
 #include "common.h"
 
 // ------------------------------------------------------------------------------------------------
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                                                 u32* __restrict__ band_first, u64* __restrict__ band_sums,
                                                 u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                 u32* __restrict__ fstat, const u8* __restrict__ lut_g,
-                                                int H, int W, int WW, int maxm) {
+                                                int H, int W, int WW, int maxm, int stop) {
     __shared__ u32 parent[VBS_RUN_CAP];
     __shared__ u32 tmp[32];
     __shared__ u32 acc_cnt[1024];
@@ -293,6 +295,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         }
     }
     __syncthreads();
+    if (stop == 1) return;
 
     // ---- C: unions between row y-1 and row y ------------------------------------------------------
     for (int idx = WW + tid; idx < NW; idx += nthr) {
@@ -334,6 +337,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         }
     }
     __syncthreads();
+    if (stop == 2) return;
 
     // ---- D: flatten -------------------------------------------------------------------------------
     for (u32 i = tid; i < nruns; i += nthr) {
@@ -341,6 +345,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         if (r != i) parent[i] = r;                     // roots keep parent[r] == r throughout
     }
     __syncthreads();
+    if (stop == 3) return;
 
     // ---- E: component ids = rank of the root in raster order ---------------------------------------
     const int chunk2 = (nruns + nthr - 1) / nthr;
@@ -371,14 +376,22 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     }
     if (tid == 0) ncomp_all[n * 2 + m] = ncomp;
     __syncthreads();                                   // node_comp visible to this workgroup below
+    if (stop == 4) return;
 
     // ---- F: per-component sums ----------------------------------------------------------------------
+    // Thread -> (word column j, block of consecutive rows): consecutive words of a thread mostly belong
+    // to the same component, so sums are kept in registers and flushed (LDS atomics) on a change of id.
+    const int colthreads = nthr / WW;
+    const int rows_per = (H + colthreads - 1) / colthreads;
+    const int cj = tid % WW, rb = tid / WW;
+    const int fy0 = rb < colthreads ? rb * rows_per : H, fy1 = min(H, fy0 + rows_per);
     if (m == 0) {
-        for (int idx = tid; idx < NW; idx += nthr) {
-            u64 w = bits[idx];
-            if (!w) continue;
-            int y = idx / WW, j = idx - y * WW;
+        u32 cur = 0xFFFFFFFFu, c_cnt = 0;
+        u64 c_sx = 0, c_sy = 0;
+        for (int y = fy0; y < fy1; ++y) {
             const u64* row = bits + (int64_t)y * WW;
+            u64 w = row[cj];
+            if (!w) continue;
             const u32* wb = wbase + (int64_t)y * WW;
             while (w) {
                 u64 lowbit = w & (~w + 1ull);
@@ -387,14 +400,18 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                 w &= t;
                 int k0 = __ffsll((long long)g) - 1;
                 u32 len = __popcll(g);
-                u32 nd = node_of(row, wb, j, k0);
-                u32 cid = (parent[parent[nd] & 0xFFFFu] >> 16) - 1;
-                u64 x0 = 64 * j + k0;
-                atomicAdd(&acc_cnt[cid], len);
-                atomicAdd(&acc_sx[cid], (u64)len * x0 + (u64)len * (len - 1) / 2);
-                atomicAdd(&acc_sy[cid], (u64)len * (u64)y);
+                u32 cid = node_comp[node_of(row, wb, cj, k0)];
+                if (cid != cur) {
+                    if (c_cnt) { atomicAdd(&acc_cnt[cur], c_cnt); atomicAdd(&acc_sx[cur], c_sx); atomicAdd(&acc_sy[cur], c_sy); }
+                    cur = cid; c_cnt = 0; c_sx = 0; c_sy = 0;
+                }
+                u64 x0 = 64 * cj + k0;
+                c_cnt += len;
+                c_sx += (u64)len * x0 + (u64)len * (len - 1) / 2;
+                c_sy += (u64)len * (u64)y;
             }
         }
+        if (c_cnt) { atomicAdd(&acc_cnt[cur], c_cnt); atomicAdd(&acc_sx[cur], c_sx); atomicAdd(&acc_sy[cur], c_sy); }
         __syncthreads();
         u64* bs = band_sums + (int64_t)n * maxm * 4;
         for (u32 c = tid; c < ncomp; c += nthr) {
@@ -403,14 +420,22 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
             bs[c * 4 + 2] = acc_sy[c];
         }
     } else {
-        i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
-        for (u32 c = tid; c < ncomp * VBS_AREA_SUMS; c += nthr) as[c] = 0;
+        // the union-find table is no longer needed (ids are in node_comp): reuse its LDS as the
+        // [ncomp][15] int64 moment accumulators (1024 x 15 x 8 B == sizeof(parent))
+        u64* acc = reinterpret_cast<u64*>(parent);
+        for (u32 c = tid; c < ncomp * NMOM; c += nthr) acc[c] = 0;
         __syncthreads();
-        for (int idx = tid; idx < NW; idx += nthr) {
-            u64 w = bits[idx];
-            if (!w) continue;
-            int y = idx / WW, j = idx - y * WW;
+        u32 cur = 0xFFFFFFFFu;
+        int ax = 0, ay = 0;
+        bool any = false;
+        i64 s[NMOM];
+#pragma unroll
+        for (int q = 0; q < NMOM; ++q) s[q] = 0;
+        for (int y = fy0; y < fy1; ++y) {
             const u64* row = bits + (int64_t)y * WW;
+            u64 w = row[cj];
+            if (!w) continue;
+            const int j = cj;
             const u32* wb = wbase + (int64_t)y * WW;
             u64 wp = j > 0 ? row[j - 1] : 0ull, wn = (j + 1 < WW) ? row[j + 1] : 0ull;
             u64 up = 0, upp = 0, upn = 0, dn = 0, dnp = 0, dnn = 0;
@@ -434,15 +459,21 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                 rest &= t;
                 u64 bg = border & g;
                 if (!bg) continue;
-                i64 s[NMOM];
-#pragma unroll
-                for (int q = 0; q < NMOM; ++q) s[q] = 0;
                 int k0 = __ffsll((long long)g) - 1;
-                u32 nd = node_of(row, wb, j, k0);
-                u32 cid = (parent[parent[nd] & 0xFFFFu] >> 16) - 1;
-                u32 fp = acc_cnt[cid];
-                int ax = fp % W, ay = fp / W;
-                bool any = false;
+                u32 cid = node_comp[node_of(row, wb, j, k0)];
+                if (cid != cur) {
+                    if (any) {
+#pragma unroll
+                        for (int q = 0; q < NMOM; ++q)
+                            if (s[q]) atomicAdd(&acc[cur * NMOM + q], (u64)s[q]);
+#pragma unroll
+                        for (int q = 0; q < NMOM; ++q) s[q] = 0;
+                        any = false;
+                    }
+                    cur = cid;
+                    u32 fp = acc_cnt[cid];
+                    ax = fp % W; ay = fp / W;
+                }
                 while (bg) {
                     int k = __ffsll((long long)bg) - 1;
                     bg &= bg - 1;
@@ -463,20 +494,24 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                     s[10] += mult * x2 * x2;      s[11] += mult * x2 * dx * dy; s[12] += mult * x2 * y2;
                     s[13] += mult * dx * dy * y2; s[14] += mult * y2 * y2;
                 }
-                if (any) {
-#pragma unroll
-                    for (int q = 0; q < NMOM; ++q)
-                        if (s[q]) atomicAdd((u64*)&as[cid * VBS_AREA_SUMS + q], (u64)s[q]);
-                }
             }
         }
+        if (any) {
+#pragma unroll
+            for (int q = 0; q < NMOM; ++q)
+                if (s[q]) atomicAdd(&acc[cur * NMOM + q], (u64)s[q]);
+        }
+        __syncthreads();
+        i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
+        for (u32 c = tid; c < ncomp * NMOM; c += nthr) as[(c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
     }
 }
 
 void launch_label(vbs_handle* h, int nb, hipStream_t s) {
     VBS_LAUNCH(h, s, "k_label", k_label, dim3(nb, 2), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
                        h->node_pos, h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first,
-                       h->area_sums, h->fstat, h->lut, h->H, h->W, h->WW, h->maxm);
+                       h->area_sums, h->fstat, h->lut, h->H, h->W, h->WW, h->maxm,
+                       getenv("VBS_LABEL_STOP") ? atoi(getenv("VBS_LABEL_STOP")) : 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -640,9 +675,11 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
                                                   const u32* __restrict__ fstat, double* __restrict__ ell_all,
                                                   double* __restrict__ det64, int32_t* __restrict__ cnt64,
                                                   double* __restrict__ det32, int32_t* __restrict__ cnt32,
-                                                  int H, int W, int WW, int maxm) {
+                                                  int H, int W, int WW, int maxm, int stop, int force_seq) {
     __shared__ double bx[1024], by[1024];
     __shared__ u8 unmatched[1024];
+    __shared__ int best_of[1024], claim[1024], wsum[4];
+    __shared__ int dup_s, nout_s;
     const int n = blockIdx.x, tid = threadIdx.x;
     int status = (int)fstat[n * 8 + 2];
     if (status != 0) {
@@ -664,14 +701,78 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
         fit_ellipse_moments(area_sums + ((int64_t)n * maxm + i) * VBS_AREA_SUMS, fp % W, fp / W, ell + i * 8);
     }
     __syncthreads();
-    if (tid >= 64) return;
-    // ---- sequential matching in cv2 contour order (last component found first), one wave ----------
+    if (stop == 1) return;
     const int NW = H * WW;
     const u64* bits = open_bits + (int64_t)n * NW;
     const u32* wbase = wbase_all + ((int64_t)n * 2 + 1) * NW;
     const u32* node_comp = node_comp_all + ((int64_t)n * 2 + 1) * VBS_RUN_CAP;
     double* d64 = det64 + (int64_t)n * maxm * 6;
     double* d32 = det32 ? det32 + (int64_t)n * maxm * 6 : nullptr;
+
+    // ---- matching (:203-243).  The reference walks the contours in order and gives each the nearest
+    // still-unmatched centre inside it.  Every contour first finds its nearest admissible centre among
+    // ALL centres, in parallel; if no centre is claimed twice, the sequential walk would have made exactly
+    // these choices (a contour loses its first choice only to an earlier contour with the same choice).
+    // Otherwise (never seen on marker frames) one wave replays the reference's sequential loop.
+    for (int i = tid; i < nb_; i += blockDim.x) claim[i] = 0;
+    if (tid == 0) { dup_s = force_seq; nout_s = 0; }
+    __syncthreads();
+    for (int ci = tid; ci < na; ci += blockDim.x) {
+        const double* e = ell + ci * 8;
+        int bi = -1;
+        if (e[6] != 0.0 && e[5] >= 5.0) {               // len(contour) >= 5 (:204) and a valid fit
+            double ecx = e[0], ecy = e[1], w = e[2], hh = e[3];
+            double minor = (w > hh) ? hh : w;
+            if (!(minor < 5.0)) {                       // (:219)
+                double thr = (minor / 10.0) * (minor / 10.0);
+                double best = 1e300;
+                for (int i = 0; i < nb_; ++i) {
+                    double dx = bx[i] - ecx, dy = by[i] - ecy;
+                    double d = dx * dx + dy * dy;
+                    if (d < thr && d < best &&
+                        inside_polygon(bits, wbase, node_comp, H, W, WW, bx[i], by[i], (u32)ci)) {
+                        best = d; bi = i;
+                    }
+                }
+            }
+        }
+        best_of[ci] = bi;
+        if (bi >= 0 && atomicAdd(&claim[bi], 1) > 0) dup_s = 1;
+    }
+    __syncthreads();
+    if (!dup_s) {
+        // output order = contour order = descending component id; rank by a block scan over reversed ids
+        const int per = (na + blockDim.x - 1) / blockDim.x;
+        const int r0 = tid * per, r1 = min(r0 + per, na);
+        int mine = 0;
+        for (int r = r0; r < r1; ++r) mine += (best_of[na - 1 - r] >= 0);
+        int inc = mine;
+        const int lane = tid & 63, wave = tid >> 6;
+        for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(inc, d); if (lane >= d) inc += t; }
+        if (lane == 63) wsum[wave] = inc;
+        __syncthreads();
+        int base = inc - mine;
+        for (int w = 0; w < wave; ++w) base += wsum[w];
+        for (int r = r0; r < r1; ++r) {
+            int ci = na - 1 - r, bi = best_of[ci];
+            if (bi < 0) continue;
+            const double* e = ell + ci * 8;
+            double w = e[2], hh = e[3], ang = e[4], major, minor, eang;
+            if (w > hh) { major = w; minor = hh; eang = ang; }
+            else { major = hh; minor = w; eang = ang + 90.0; }
+            double* o = d64 + base * 6;
+            o[0] = bx[bi]; o[1] = by[bi]; o[2] = major; o[3] = minor; o[4] = eang; o[5] = bi + 1;
+            if (d32) {
+                double* f = d32 + base * 6;
+                f[0] = bx[bi]; f[1] = by[bi]; f[2] = major; f[3] = minor; f[4] = eang; f[5] = bi + 1;
+            }
+            ++base;
+        }
+        if (tid == blockDim.x - 1) { cnt64[n] = base; if (cnt32) cnt32[n] = base; }
+        return;
+    }
+    if (tid >= 64) return;
+    // ---- sequential replay in cv2 contour order (last component found first), one wave -------------
     int count = 0;
     for (int ci = na - 1; ci >= 0; --ci) {
         const double* e = ell + ci * 8;
@@ -719,5 +820,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
 void launch_finalize(vbs_handle* h, int nb, double* det, int32_t* counts, hipStream_t s) {
     VBS_LAUNCH(h, s, "k_finalize", k_finalize, dim3(nb), dim3(256), 0, s, h->ncomp, h->band_sums, h->area_first,
                        h->area_sums, h->open_bits, h->wbase, h->node_comp, h->fstat, h->ell, h->det64,
-                       h->cnt, det, counts, h->H, h->W, h->WW, h->maxm);
+                       h->cnt, det, counts, h->H, h->W, h->WW, h->maxm,
+                       getenv("VBS_FINAL_STOP") ? atoi(getenv("VBS_FINAL_STOP")) : 0,
+                       getenv("VBS_FORCE_SEQ_MATCH") ? 1 : 0);     // debug: exercise the sequential replay
 }

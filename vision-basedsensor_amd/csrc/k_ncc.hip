@@ -9,8 +9,7 @@
 //     num = 255 G - tbar 255 c - mu (Rx Ry - n tbar),     G = sum_i g_i sum_j g_j b(y+i, x+j)
 //     var = 255^2 c - 2 mu 255 c + n mu^2 - (255 c - n mu)^2 / l^2
 //     mask = num / sqrt(var * T2) > 0.1   <=>   var > 0, num > 0, num^2 > 0.01 var T2
-// k_ncc_h: horizontal Gaussian pass + horizontal box count straight from the packed bits.
-// k_ncc_v: vertical pass, decision, ballot -> packed mask bits (and optional uint8 mask).
+// k_ncc: both passes in one kernel, the horizontal one from bit runs into LDS (no float64 image in HBM).
 #include "common.h"
 
 __device__ __forceinline__ u64 load_bits(const u64* __restrict__ row, int WW, int start) {
@@ -20,82 +19,83 @@ __device__ __forceinline__ u64 load_bits(const u64* __restrict__ row, int WW, in
     return sh ? ((a >> sh) | (b << (64 - sh))) : a;
 }
 
+// One workgroup = 64 columns x 32 output rows.  Phase 1 fills LDS with the horizontal pass of the 32+L-1
+// rows the tile needs: for a binary row the Gaussian-weighted sum over a window is a sum over the RUNS of
+// 1-bits inside it, each run contributing CG[end] - CG[start] with CG the cumulative template factor
+// (2 table lookups per run instead of L multiply-adds; marker rows have <= 2 runs per window).
+// Phase 2 is the vertical pass out of LDS, 8 rows per lane, then the decision and a ballot per row.
 template <int L, int LO>
-__global__ __launch_bounds__(256) void k_ncc_h(const u64* __restrict__ bits, double* __restrict__ hx,
-                                               u8* __restrict__ cxo, int H, int P, int WW,
-                                               NccConst nc) {
-    const int groups = P / 8;
-    int gid = blockIdx.x * 256 + threadIdx.x;
-    if (gid >= groups * H) return;
-    int y = gid / groups, xg = gid - y * groups;
-    int n = blockIdx.y;
-    int x0 = xg * 8;
-    const u64* row = bits + ((int64_t)n * H + y) * WW;
-    u64 w0 = load_bits(row, WW, x0 + LO);
-    u64 w1 = load_bits(row, WW, x0 + LO + 64);
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (w0 | w1) {
-#pragma unroll
-        for (int i = 0; i < L + 7; ++i) {
-            u32 bit = (i < 64) ? (u32)((w0 >> i) & 1ull) : (u32)((w1 >> (i - 64)) & 1ull);
-            double bd = (double)bit;
+__global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const double* __restrict__ rx,
+                                             const double* __restrict__ ry, u64* __restrict__ mbits,
+                                             u8* __restrict__ mask_u8, double* __restrict__ ncc_out,
+                                             u32* __restrict__ fstat, int H, int W, int WW, NccConst nc) {
+    constexpr int RT = 32, HR = RT + L - 1, HI = L - 1 + LO;
+    __shared__ double hxs[HR][64];
+    __shared__ u8 cxs[HR][64];
+    __shared__ double cg[L + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int x0 = blockIdx.x * 64, yb = blockIdx.y * RT, n = blockIdx.z;
+    for (int i = tid; i <= L; i += 256) cg[i] = nc.cg[i];
+    __syncthreads();
+    // phase 1: work item = (row r, 8 consecutive columns); one 64+(L+7-64)-bit window serves all 8
+    for (int p = tid; p < HR * 8; p += 256) {
+        const int r = p >> 3, c8 = p & 7;
+        const int y = yb + LO + r, xs = x0 + 8 * c8;
+        double h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        u64 packed = 0;
+        if (y >= 0 && y < H) {
+            const u64* row = bits + ((int64_t)n * H + y) * WW;
+            const u64 w0 = load_bits(row, WW, xs + LO);
+            const u64 w1 = load_bits(row, WW, xs + LO + 64) & ((1ull << (L + 7 - 64 > 0 ? L + 7 - 64 : 1)) - 1ull) &
+                           (L + 7 > 64 ? ~0ull : 0ull);
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                const int j = i - s;
-                if (j >= 0 && j < L) acc[s] = __builtin_fma(nc.g[j], bd, acc[s]);
+                u64 lo = s ? ((w0 >> s) | (w1 << (64 - s))) : w0;
+                u32 c;
+                if (L >= 64) c = __popcll(lo) + __popcll((w1 >> s) & ((1ull << (L >= 64 ? L - 64 : 0)) - 1ull));
+                else c = __popcll(lo & ((1ull << (L < 64 ? L : 0)) - 1ull));
+                packed |= (u64)c << (8 * s);
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                u64 w = half ? w1 : ((L + 7 >= 64) ? w0 : (w0 & ((1ull << ((L + 7) & 63)) - 1ull)));
+                const int off = half * 64;
+                while (w) {
+                    int b0 = __ffsll((long long)w) - 1;
+                    u64 t = ~(w >> b0);
+                    int len = t ? __ffsll((long long)t) - 1 : 64 - b0;
+                    w &= (len >= 64) ? 0ull : ~(((1ull << len) - 1ull) << b0);
+                    const int rb = off + b0, re = rb + len;     // run [rb, re) in window coordinates
+#pragma unroll
+                    for (int s = 0; s < 8; ++s) {
+                        int lo_ = max(rb, s), hi_ = max(min(re, s + L), lo_);
+                        h[s] += cg[hi_ - s] - cg[lo_ - s];
+                    }
+                }
             }
         }
-    }
-    int64_t o = ((int64_t)n * H + y) * P + x0;
-    u64 packed = 0;
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        u64 lo = s ? ((w0 >> s) | (w1 << (64 - s))) : w0;
-        u32 c;
-        if (L >= 64) {
-            c = __popcll(lo) + __popcll((w1 >> s) & ((1ull << (L - 64)) - 1ull));
-        } else {
-            c = __popcll(lo & ((1ull << L) - 1ull));
-        }
-        packed |= (u64)c << (8 * s);
-        hx[o + s] = acc[s];
+        for (int s = 0; s < 8; ++s) hxs[r][8 * c8 + s] = h[s];
+        *reinterpret_cast<u64*>(&cxs[r][8 * c8]) = packed;
     }
-    *reinterpret_cast<u64*>(cxo + o) = packed;
-}
-
-template <int L, int LO>
-__global__ __launch_bounds__(256) void k_ncc_v(const double* __restrict__ hx, const u8* __restrict__ cxi,
-                                               const double* __restrict__ rx,
-                                               const double* __restrict__ ry, u64* __restrict__ mbits,
-                                               u8* __restrict__ mask_u8, double* __restrict__ ncc_out,
-                                               u32* __restrict__ fstat, int H, int W, int P, int WW,
-                                               NccConst nc) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int x = blockIdx.x * 64 + lane;
-    const int y0 = (blockIdx.y * 4 + wave) * 8;
-    const int n = blockIdx.z;
+    __syncthreads();
+    const int x = x0 + lane;
+    const int r0 = wave * 8;                             // first LDS row of this lane's 8 output rows
+    const int y0 = yb + r0;
     if (y0 >= H) return;
-    constexpr int HI = L - 1 + LO;
-    const double* hcol = hx + (int64_t)n * H * P + x;
-    const u8* ccol = cxi + (int64_t)n * H * P + x;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    u32 cs[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    u32 cs0 = 0, pre[8] = {0, 0, 0, 0, 0, 0, 0, 0}, post[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < L + 7; ++i) {
-        int yy = y0 + LO + i;
-        double v = 0.0;
-        u32 c = 0;
-        if (yy >= 0 && yy < H) {
-            v = hcol[(int64_t)yy * P];
-            c = ccol[(int64_t)yy * P];
-        }
+        const double v = hxs[r0 + i][lane];
+        const u32 c = cxs[r0 + i][lane];
+        if (i < L) cs0 += c;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
             const int j = i - s;
-            if (j >= 0 && j < L) {
-                acc[s] = __builtin_fma(nc.g[j], v, acc[s]);
-                cs[s] += c;
-            }
+            if (j >= 0 && j < L) acc[s] = __builtin_fma(nc.g[j], v, acc[s]);
+            if (i < s) pre[s] += c;                      // rows above window s
+            if (i >= L && i < L + s) post[s] += c;       // rows that window s gains
         }
     }
     const double mu = (double)(255ull * (u64)fstat[n * 8 + 0]) / (double)((int64_t)H * W);
@@ -109,16 +109,17 @@ __global__ __launch_bounds__(256) void k_ncc_v(const double* __restrict__ hx, co
             int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
             double nn = (double)(ny * nx);
             double sum_t = ry[y] * rx[x];
-            double sum_I = 255.0 * (double)cs[s];
+            double sum_I = 255.0 * (double)(cs0 - pre[s] + post[s]);
             double num = 255.0 * acc[s] - nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
             double s1 = sum_I - nn * mu;
             double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
-            double var = s2 - s1 * s1 / nc.l2;
+            double var = s2 - s1 * s1 * nc.inv_l2;
             double rhs = nc.thr2 * var * nc.T2;
             pred = (var > 0.0) && (num > 0.0) && (num * num > rhs);
             if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
-            if (ncc_out) {                               // the reference's value: non-finite -> 0 (:162-163)
-                double q = num / sqrt((var < 0.0 ? 0.0 : var) * nc.T2);
+            if (ncc_out) {                               // diagnostic map with the reference's exact form (:159-163)
+                double v2 = s2 - s1 * s1 / nc.l2;
+                double q = num / sqrt((v2 < 0.0 ? 0.0 : v2) * nc.T2);
                 ncc_out[((int64_t)n * H + y) * W + x] = isfinite(q) ? q : 0.0;
             }
         }
@@ -148,17 +149,12 @@ void launch_popcount(vbs_handle* h, int nb, hipStream_t s) {
 }
 
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s) {
-    dim3 gh(((h->P / 8) * h->H + 255) / 256, nb);
-    dim3 gv(h->WW, (h->H + 31) / 32, nb);
+    dim3 grid(h->WW, (h->H + 31) / 32, nb);
     if (!h->bp.small) {
-        VBS_LAUNCH(h, s, "k_ncc_h", (k_ncc_h<80, -40>), gh, dim3(256), 0, s, h->area_bits, h->hx, h->cx, h->H, h->P,
-                           h->WW, h->ncc);
-        VBS_LAUNCH(h, s, "k_ncc_v", (k_ncc_v<80, -40>), gv, dim3(256), 0, s, h->hx, h->cx, h->ncc_rx, h->ncc_ry,
-                           h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->P, h->WW, h->ncc);
+        VBS_LAUNCH(h, s, "k_ncc", (k_ncc<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx, h->ncc_ry,
+                   h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->WW, h->ncc);
     } else {
-        VBS_LAUNCH(h, s, "k_ncc_h", (k_ncc_h<33, -16>), gh, dim3(256), 0, s, h->area_bits, h->hx, h->cx, h->H, h->P,
-                           h->WW, h->ncc);
-        VBS_LAUNCH(h, s, "k_ncc_v", (k_ncc_v<33, -16>), gv, dim3(256), 0, s, h->hx, h->cx, h->ncc_rx, h->ncc_ry,
-                           h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->P, h->WW, h->ncc);
+        VBS_LAUNCH(h, s, "k_ncc", (k_ncc<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx, h->ncc_ry,
+                   h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->WW, h->ncc);
     }
 }
