@@ -50,12 +50,21 @@ __global__ __launch_bounds__(64) void k_blur_h(const u8* __restrict__ gray, int6
     const int tile_x0 = blockIdx.x * 256;
     const int qe = blockIdx.y, n = blockIdx.z;
     const u8* g = gray + (int64_t)n * gstride_n;
+    // interior tiles of 4-byte aligned rows are staged with dword loads; tiles that touch the left /
+    // right border (reflect-101) or unaligned inputs (crops) go byte by byte
+    const bool fast = (tile_x0 - C4B >= 0) && (tile_x0 - C4B + ROWB <= W) && ((gstride_row & 3) == 0) &&
+                      ((gstride_n & 3) == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
     for (int r = 0; r < 4; ++r) {
         int e = 4 * qe - C4B + r;
         int sy = reflect101(e, H);
         const u8* row = g + (int64_t)sy * gstride_row;
-        u8* dst = reinterpret_cast<u8*>(&rowbuf[r][0]);
-        for (int i = lane; i < ROWB; i += 64) dst[i] = row[reflect101(tile_x0 - C4B + i, W)];
+        if (fast) {
+            const u32* row32 = reinterpret_cast<const u32*>(row + tile_x0 - C4B);
+            for (int i = lane; i < ROWB / 4; i += 64) rowbuf[r][i] = row32[i];
+        } else {
+            u8* dst = reinterpret_cast<u8*>(&rowbuf[r][0]);
+            for (int i = lane; i < ROWB; i += 64) dst[i] = row[reflect101(tile_x0 - C4B + i, W)];
+        }
     }
     __syncthreads();
     u32 hiA[4] = {0, 0, 0, 0}, loA[4] = {0, 0, 0, 0}, hiB[4] = {0, 0, 0, 0}, loB[4] = {0, 0, 0, 0};

@@ -176,7 +176,22 @@ void make_contour_lut(u8 out[256]) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// find with path halving.  Parents only ever move to a smaller-indexed member of the same set (hooking is an
+// atomicMin on a root, halving stores an ancestor), so the racy 32-bit stores are benign: a lost hook is
+// re-established by uf_union's retry with the value atomicMin returned.
 __device__ __forceinline__ u32 uf_find(volatile u32* parent, u32 x) {
+    for (;;) {
+        u32 p = parent[x];
+        if (p == x) return x;
+        u32 gp = parent[p];
+        if (gp == p) return p;
+        parent[x] = gp;
+        x = gp;
+    }
+}
+
+// read-only walk to the root (flatten phase: there, every store must be a final root)
+__device__ __forceinline__ u32 uf_root(volatile u32* parent, u32 x) {
     u32 p;
     while ((p = parent[x]) != x) x = p;
     return x;
@@ -225,10 +240,16 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* tmp, u32* total)
     }
     if (lane == 63) tmp[wave] = inc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        u32 run = 0;
-        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) { u32 t = tmp[w]; tmp[w] = run; run += t; }
-        tmp[16] = run;
+    if (wave == 0) {                                   // scan of the (<= 16) wave totals by one wave
+        const int nw = blockDim.x >> 6;
+        u32 t = lane < nw ? tmp[lane] : 0u, ti = t;
+#pragma unroll
+        for (int d = 1; d < 16; d <<= 1) {
+            u32 o = __shfl_up(ti, d);
+            if (lane >= d) ti += o;
+        }
+        if (lane < nw) tmp[lane] = ti - t;
+        if (lane == nw - 1) tmp[16] = ti;
     }
     __syncthreads();
     u32 ex = inc - v + tmp[wave];
@@ -248,7 +269,10 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                                                 u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                 u32* __restrict__ fstat, const u8* __restrict__ lut_g,
                                                 int H, int W, int WW, int maxm, int stop) {
+    constexpr int STRIPW = 1024;                       // words of one strip incl. the carried row
     __shared__ u32 parent[VBS_RUN_CAP];
+    __shared__ u64 sbits[STRIPW];
+    __shared__ u32 swb[STRIPW];
     __shared__ u32 tmp[32];
     __shared__ u32 acc_cnt[1024];
     __shared__ u64 acc_sx[1024];
@@ -261,88 +285,98 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     u32* wbase = wbase_all + ((int64_t)n * 2 + m) * NW;
     u32* node_pos = node_pos_all + ((int64_t)n * 2 + m) * VBS_RUN_CAP;
     u32* node_comp = node_comp_all + ((int64_t)n * 2 + m) * VBS_RUN_CAP;
+    if (stop == 9) return;
     if (tid < 256) lut[tid] = lut_g[tid];
     for (int i = tid; i < 1024; i += nthr) { acc_cnt[i] = 0; acc_sx[i] = 0; acc_sy[i] = 0; }
 
-    // ---- A: enumerate runs (nodes) in raster order ------------------------------------------------
-    const int chunk = (NW + nthr - 1) / nthr;
-    const int i0 = tid * chunk, i1 = min(i0 + chunk, NW);
-    u32 cnt = 0;
-    for (int idx = i0; idx < i1; ++idx) {
-        int j = idx % WW;
-        u64 w = bits[idx];
-        u64 prev = (j > 0) ? (bits[idx - 1] >> 63) : 0ull;
-        cnt += __popcll(w & ~((w << 1) | prev));
-    }
-    u32 nruns;
-    u32 base = block_exclusive_scan(cnt, tmp, &nruns);
-    if (nruns > VBS_RUN_CAP) {                          // block-uniform
-        if (tid == 0) { ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
-        return;
-    }
-    for (int idx = i0; idx < i1; ++idx) {
-        int y = idx / WW, j = idx - y * WW;
-        u64 w = bits[idx];
-        u64 prev = (j > 0) ? (bits[idx - 1] >> 63) : 0ull;
-        u64 st = w & ~((w << 1) | prev);
-        wbase[idx] = base;
-        while (st) {
-            int k = __ffsll((long long)st) - 1;
-            st &= st - 1;
-            parent[base] = base;
-            node_pos[base] = (u32)(y * W + 64 * j + k);
-            ++base;
+    // ---- A + C, streamed over strips of rows staged in LDS ------------------------------------------
+    // Every strip: stage its bit rows in LDS (slot 0 keeps the previous strip's last row), enumerate the
+    // runs (= union-find nodes) in raster order, then union each row's runs with the row above.  All the
+    // pointer chasing (run starts, node indices) is LDS-resident; global memory sees one coalesced read
+    // of the bits (prefetched one strip ahead in registers) and the wbase / node_pos writes.
+    const int S = min(64, STRIPW / WW - 1);             // rows per strip, (S + 1) * WW <= STRIPW
+    const int j = tid % WW, rloc = 1 + tid / WW;        // this thread's word inside the strip (slots 1..S)
+    for (int i = tid; i < WW; i += nthr) { sbits[i] = 0; swb[i] = 0; }
+    u32 nruns = 0;
+    u64 cur = (tid < min(S, H) * WW) ? bits[tid] : 0ull;
+    for (int s0 = 0; s0 < H; s0 += S) {
+        const int rows = min(S, H - s0), nwords = rows * WW;
+        const bool live = tid < nwords;
+        if (live) sbits[WW + tid] = cur;
+        const int nrows_next = min(S, H - s0 - S);
+        u64 nxt = (s0 + S < H && tid < nrows_next * WW) ? bits[(int64_t)(s0 + S) * WW + tid] : 0ull;
+        __syncthreads();
+        u64 st = 0;
+        if (live) {
+            u64 prev = (j > 0) ? (sbits[WW + tid - 1] >> 63) : 0ull;
+            st = cur & ~((cur << 1) | prev);
         }
-    }
-    __syncthreads();
-    if (stop == 1) return;
-
-    // ---- C: unions between row y-1 and row y ------------------------------------------------------
-    for (int idx = WW + tid; idx < NW; idx += nthr) {
-        u64 B = bits[idx];
-        if (!B) continue;
-        int y = idx / WW, j = idx - y * WW;
-        const u64* rowA = bits + (int64_t)(y - 1) * WW;
-        const u64* rowB = bits + (int64_t)y * WW;
-        const u32* wbA = wbase + (int64_t)(y - 1) * WW;
-        const u32* wbB = wbase + (int64_t)y * WW;
-        u64 A = rowA[j];
-        u64 Aprev = (j > 0) ? rowA[j - 1] : 0ull, Anext = (j + 1 < WW) ? rowA[j + 1] : 0ull;
-        u64 adj = A;
-        if (m == 1) adj |= (A << 1) | (A >> 1) | (Aprev >> 63) | (Anext << 63);
-        if (!(B & adj)) continue;
-        u64 mB = B;
-        while (mB) {                                   // groups of consecutive 1s of B inside this word
-            u64 lowbit = mB & (~mB + 1ull);
-            u64 t = mB + lowbit;
-            u64 g = mB & ~t;
-            mB &= t;
-            if (!(g & adj)) continue;
-            int k0 = __ffsll((long long)g) - 1;
-            u32 nb_ = node_of(rowB, wbB, j, k0);
-            u64 rm = g;
-            if (m == 1) rm |= (g << 1) | (g >> 1);
-            u64 mA = A & rm;
-            while (mA) {
-                u64 lb = mA & (~mA + 1ull);
-                u64 t2 = mA + lb;
-                u64 ga = mA & ~t2;
-                mA &= t2;
-                uf_union(parent, node_of(rowA, wbA, j, __ffsll((long long)ga) - 1), nb_);
-            }
-            if (m == 1) {
-                if ((g & 1ull) && (Aprev >> 63)) uf_union(parent, node_of(rowA, wbA, j - 1, 63), nb_);
-                if ((g >> 63) && (Anext & 1ull)) uf_union(parent, node_of(rowA, wbA, j + 1, 0), nb_);
+        u32 total;
+        u32 base = nruns + block_exclusive_scan(__popcll(st), tmp, &total);
+        nruns += total;
+        if (nruns > VBS_RUN_CAP) {                      // block-uniform
+            if (tid == 0) { ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
+            return;
+        }
+        const int y = s0 + rloc - 1;
+        if (live) {
+            swb[WW + tid] = base;
+            wbase[(int64_t)s0 * WW + tid] = base;
+            u32 nd = base;
+            while (st) {
+                int k = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                parent[nd] = nd;
+                node_pos[nd] = (u32)(y * W + 64 * j + k);
+                ++nd;
             }
         }
+        __syncthreads();
+        if (live && cur && (s0 + rloc - 1) > 0) {
+            const u64* rowA = sbits + (rloc - 1) * WW;
+            const u64* rowB = sbits + rloc * WW;
+            const u32* wbA = swb + (rloc - 1) * WW;
+            const u32* wbB = swb + rloc * WW;
+            const u64 B = cur, A = rowA[j];
+            const u64 Aprev = (j > 0) ? rowA[j - 1] : 0ull, Anext = (j + 1 < WW) ? rowA[j + 1] : 0ull;
+            u64 adj = A;
+            if (m == 1) adj |= (A << 1) | (A >> 1) | (Aprev >> 63) | (Anext << 63);
+            u64 mB = (B & adj) ? B : 0ull;
+            while (mB) {                               // groups of consecutive 1s of B inside this word
+                u64 lowbit = mB & (~mB + 1ull);
+                u64 t = mB + lowbit;
+                u64 g = mB & ~t;
+                mB &= t;
+                if (!(g & adj)) continue;
+                int k0 = __ffsll((long long)g) - 1;
+                u32 nb_ = node_of(rowB, wbB, j, k0);
+                u64 rm = g;
+                if (m == 1) rm |= (g << 1) | (g >> 1);
+                u64 mA = A & rm;
+                while (mA) {
+                    u64 lb = mA & (~mA + 1ull);
+                    u64 t2 = mA + lb;
+                    u64 ga = mA & ~t2;
+                    mA &= t2;
+                    uf_union(parent, node_of(rowA, wbA, j, __ffsll((long long)ga) - 1), nb_);
+                }
+                if (m == 1) {
+                    if ((g & 1ull) && (Aprev >> 63)) uf_union(parent, node_of(rowA, wbA, j - 1, 63), nb_);
+                    if ((g >> 63) && (Anext & 1ull)) uf_union(parent, node_of(rowA, wbA, j + 1, 0), nb_);
+                }
+            }
+        }
+        __syncthreads();
+        if (live && rloc == rows) { sbits[j] = cur; swb[j] = base; }   // last row -> slot 0 of the next strip
+        cur = nxt;
     }
     __syncthreads();
     if (stop == 2) return;
 
     // ---- D: flatten -------------------------------------------------------------------------------
     for (u32 i = tid; i < nruns; i += nthr) {
-        u32 r = uf_find(parent, i);
-        if (r != i) parent[i] = r;                     // roots keep parent[r] == r throughout
+        u32 r = uf_root(parent, i);                    // no halving here: a late halving store could
+        if (r != i) parent[i] = r;                     // overwrite another thread's final root
     }
     __syncthreads();
     if (stop == 3) return;

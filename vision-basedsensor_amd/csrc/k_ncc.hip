@@ -10,6 +10,8 @@
 //     var = 255^2 c - 2 mu 255 c + n mu^2 - (255 c - n mu)^2 / l^2
 //     mask = num / sqrt(var * T2) > 0.1   <=>   var > 0, num > 0, num^2 > 0.01 var T2
 // k_ncc: both passes in one kernel, the horizontal one from bit runs into LDS (no float64 image in HBM).
+#include <cstdlib>
+
 #include "common.h"
 
 __device__ __forceinline__ u64 load_bits(const u64* __restrict__ row, int WW, int start) {
@@ -28,14 +30,16 @@ template <int L, int LO>
 __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const double* __restrict__ rx,
                                              const double* __restrict__ ry, u64* __restrict__ mbits,
                                              u8* __restrict__ mask_u8, double* __restrict__ ncc_out,
-                                             u32* __restrict__ fstat, int H, int W, int WW, NccConst nc) {
+                                             u32* __restrict__ fstat, int H, int W, int WW, int stop, NccConst nc) {
     constexpr int RT = 32, HR = RT + L - 1, HI = L - 1 + LO;
     __shared__ double hxs[HR][64];
     __shared__ u8 cxs[HR][64];
     __shared__ double cg[L + 1];
+    __shared__ double gsh[L];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * 64, yb = blockIdx.y * RT, n = blockIdx.z;
     for (int i = tid; i <= L; i += 256) cg[i] = nc.cg[i];
+    for (int i = tid; i < L; i += 256) gsh[i] = nc.g[i];
     __syncthreads();
     // phase 1: work item = (row r, 8 consecutive columns); one 64+(L+7-64)-bit window serves all 8
     for (int p = tid; p < HR * 8; p += 256) {
@@ -68,7 +72,8 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
                     const int rb = off + b0, re = rb + len;     // run [rb, re) in window coordinates
 #pragma unroll
                     for (int s = 0; s < 8; ++s) {
-                        int lo_ = max(rb, s), hi_ = max(min(re, s + L), lo_);
+                        // clip the run to window s = [s, s+L); an empty intersection gives cg[k] - cg[k] = 0
+                        int lo_ = min(max(rb, s), s + L), hi_ = max(min(re, s + L), lo_);
                         h[s] += cg[hi_ - s] - cg[lo_ - s];
                     }
                 }
@@ -79,21 +84,42 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
         *reinterpret_cast<u64*>(&cxs[r][8 * c8]) = packed;
     }
     __syncthreads();
+    if (stop == 1) return;
     const int x = x0 + lane;
     const int r0 = wave * 8;                             // first LDS row of this lane's 8 output rows
     const int y0 = yb + r0;
     if (y0 >= H) return;
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // tap-outer order: one scalar weight g[j] feeds the 8 outputs, the 8 LDS values slide by one per tap
+    // (per output the products are still added in ascending j, as in the oracle's direct evaluation)
+    double vw[8];
+#pragma unroll
+    for (int i = 0; i < 7; ++i) vw[i] = hxs[r0 + i][lane];
+#pragma unroll 1
+    for (int jb = 0; jb < L / 8; ++jb) {                 // rolled: keeps the weights' live ranges to one block
+#pragma unroll
+        for (int jj = 0; jj < 8; ++jj) {
+            const int j = 8 * jb + jj;
+            vw[(jj + 7) & 7] = hxs[r0 + j + 7][lane];
+            const double gj = gsh[j];                    // LDS broadcast read
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc[s] = __builtin_fma(gj, vw[(jj + s) & 7], acc[s]);
+        }
+    }
+#pragma unroll
+    for (int j = (L / 8) * 8; j < L; ++j) {              // tail taps (L = 33)
+        vw[(j + 7) & 7] = hxs[r0 + j + 7][lane];
+        const double gj = gsh[j];
+#pragma unroll
+        for (int s = 0; s < 8; ++s) acc[s] = __builtin_fma(gj, vw[(j + s) & 7], acc[s]);
+    }
     u32 cs0 = 0, pre[8] = {0, 0, 0, 0, 0, 0, 0, 0}, post[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int i = 0; i < L + 7; ++i) {
-        const double v = hxs[r0 + i][lane];
         const u32 c = cxs[r0 + i][lane];
         if (i < L) cs0 += c;
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const int j = i - s;
-            if (j >= 0 && j < L) acc[s] = __builtin_fma(nc.g[j], v, acc[s]);
             if (i < s) pre[s] += c;                      // rows above window s
             if (i >= L && i < L + s) post[s] += c;       // rows that window s gains
         }
@@ -150,11 +176,12 @@ void launch_popcount(vbs_handle* h, int nb, hipStream_t s) {
 
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s) {
     dim3 grid(h->WW, (h->H + 31) / 32, nb);
+    const int stop = getenv("VBS_NCC_STOP") ? atoi(getenv("VBS_NCC_STOP")) : 0;   // debug: phase timing
     if (!h->bp.small) {
         VBS_LAUNCH(h, s, "k_ncc", (k_ncc<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx, h->ncc_ry,
-                   h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->WW, h->ncc);
+                   h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->WW, stop, h->ncc);
     } else {
         VBS_LAUNCH(h, s, "k_ncc", (k_ncc<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx, h->ncc_ry,
-                   h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->WW, h->ncc);
+                   h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->WW, stop, h->ncc);
     }
 }
