@@ -21,25 +21,54 @@ __device__ __forceinline__ u64 load_bits(const u64* __restrict__ row, int WW, in
     return sh ? ((a >> sh) | (b << (64 - sh))) : a;
 }
 
-// One workgroup = 64 columns x 32 output rows.  Phase 1 fills LDS with the horizontal pass of the 32+L-1
-// rows the tile needs: for a binary row the Gaussian-weighted sum over a window is a sum over the RUNS of
-// 1-bits inside it, each run contributing CG[end] - CG[start] with CG the cumulative template factor
-// (2 table lookups per run instead of L multiply-adds; marker rows have <= 2 runs per window).
-// Phase 2 is the vertical pass out of LDS, 8 rows per lane, then the decision and a ballot per row.
+// Horizontal Gaussian sum of one pixel from the runs of 1-bits in its window (float64): a run [b, e) in
+// window coordinates contributes CG[e] - CG[b], CG the cumulative template factor.
+template <int L, int LO>
+__device__ __forceinline__ double ncc_row_exact(const u64* __restrict__ row, int WW, int x, const double* cg,
+                                                u32* cnt) {
+    u64 w0 = load_bits(row, WW, x + LO), w1 = 0;
+    if (L > 64) w1 = load_bits(row, WW, x + LO + 64) & ((1ull << (L > 64 ? L - 64 : 1)) - 1ull);
+    else w0 &= (1ull << (L < 64 ? L : 0)) - 1ull;
+    *cnt += __popcll(w0) + __popcll(w1);
+    double h = 0.0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        u64 w = half ? w1 : w0;
+        while (w) {
+            int b0 = __ffsll((long long)w) - 1;
+            u64 t = ~(w >> b0);
+            int len = t ? __ffsll((long long)t) - 1 : 64 - b0;
+            w &= (len >= 64) ? 0ull : ~(((1ull << len) - 1ull) << b0);
+            h += cg[half * 64 + b0 + len] - cg[half * 64 + b0];
+        }
+    }
+    return h;
+}
+
+// One workgroup = 64 columns x 64 output rows.
+// Phase 1 fills LDS with the horizontal pass of the 64+L-1 rows the tile needs, 8 px per work item from one
+// shared bit window, computed in float64 from runs (2 table lookups per run instead of L multiply-adds) and
+// stored as float32.  Phase 2 is the vertical pass out of LDS in float32 (tap-outer, 8 rows per lane).
+// float32 is only a filter: with e = 1e-5 bounding the relative error of the float32 sum (80 positive
+// products, worst case (L+2) 2^-24 = 4.9e-6 plus the two input roundings), a pixel whose decision is the
+// same for G (1 - e) and G (1 + e) is decided; the others (a handful per frame, on the ncc = 0.1 contour)
+// recompute G in float64 straight from the bits (ncc_row_exact), so every decision equals the float64 one.
 template <int L, int LO>
 __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const double* __restrict__ rx,
                                              const double* __restrict__ ry, u64* __restrict__ mbits,
                                              u8* __restrict__ mask_u8, double* __restrict__ ncc_out,
                                              u32* __restrict__ fstat, int H, int W, int WW, int stop, NccConst nc) {
-    constexpr int RT = 32, HR = RT + L - 1, HI = L - 1 + LO;
-    __shared__ double hxs[HR][64];
-    __shared__ u8 cxs[HR][64];
+    constexpr int RT = 64, HR = RT + L - 1, HI = L - 1 + LO;
+    __shared__ float hxs[HR][64];
+    __shared__ __attribute__((aligned(8))) u8 cxs[HR][64];
     __shared__ double cg[L + 1];
     __shared__ double gsh[L];
+    __shared__ float g32[L];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int x0 = blockIdx.x * 64, yb = blockIdx.y * RT, n = blockIdx.z;
+    const u64* fbits = bits + (int64_t)n * H * WW;
     for (int i = tid; i <= L; i += 256) cg[i] = nc.cg[i];
-    for (int i = tid; i < L; i += 256) gsh[i] = nc.g[i];
+    for (int i = tid; i < L; i += 256) { gsh[i] = nc.g[i]; g32[i] = (float)nc.g[i]; }
     __syncthreads();
     // phase 1: work item = (row r, 8 consecutive columns); one 64+(L+7-64)-bit window serves all 8
     for (int p = tid; p < HR * 8; p += 256) {
@@ -48,7 +77,7 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
         double h[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         u64 packed = 0;
         if (y >= 0 && y < H) {
-            const u64* row = bits + ((int64_t)n * H + y) * WW;
+            const u64* row = fbits + (int64_t)y * WW;
             const u64 w0 = load_bits(row, WW, xs + LO);
             const u64 w1 = load_bits(row, WW, xs + LO + 64) & ((1ull << (L + 7 - 64 > 0 ? L + 7 - 64 : 1)) - 1ull) &
                            (L + 7 > 64 ? ~0ull : 0ull);
@@ -80,82 +109,103 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
             }
         }
 #pragma unroll
-        for (int s = 0; s < 8; ++s) hxs[r][8 * c8 + s] = h[s];
+        for (int s = 0; s < 8; ++s) hxs[r][8 * c8 + s] = (float)h[s];
         *reinterpret_cast<u64*>(&cxs[r][8 * c8]) = packed;
     }
     __syncthreads();
     if (stop == 1) return;
     const int x = x0 + lane;
-    const int r0 = wave * 8;                             // first LDS row of this lane's 8 output rows
-    const int y0 = yb + r0;
-    if (y0 >= H) return;
-    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    // tap-outer order: one scalar weight g[j] feeds the 8 outputs, the 8 LDS values slide by one per tap
-    // (per output the products are still added in ascending j, as in the oracle's direct evaluation)
-    double vw[8];
-#pragma unroll
-    for (int i = 0; i < 7; ++i) vw[i] = hxs[r0 + i][lane];
-#pragma unroll 1
-    for (int jb = 0; jb < L / 8; ++jb) {                 // rolled: keeps the weights' live ranges to one block
-#pragma unroll
-        for (int jj = 0; jj < 8; ++jj) {
-            const int j = 8 * jb + jj;
-            vw[(jj + 7) & 7] = hxs[r0 + j + 7][lane];
-            const double gj = gsh[j];                    // LDS broadcast read
-#pragma unroll
-            for (int s = 0; s < 8; ++s) acc[s] = __builtin_fma(gj, vw[(jj + s) & 7], acc[s]);
-        }
-    }
-#pragma unroll
-    for (int j = (L / 8) * 8; j < L; ++j) {              // tail taps (L = 33)
-        vw[(j + 7) & 7] = hxs[r0 + j + 7][lane];
-        const double gj = gsh[j];
-#pragma unroll
-        for (int s = 0; s < 8; ++s) acc[s] = __builtin_fma(gj, vw[(j + s) & 7], acc[s]);
-    }
-    u32 cs0 = 0, pre[8] = {0, 0, 0, 0, 0, 0, 0, 0}, post[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-    for (int i = 0; i < L + 7; ++i) {
-        const u32 c = cxs[r0 + i][lane];
-        if (i < L) cs0 += c;
-#pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            if (i < s) pre[s] += c;                      // rows above window s
-            if (i >= L && i < L + s) post[s] += c;       // rows that window s gains
-        }
-    }
     const double mu = (double)(255ull * (u64)fstat[n * 8 + 0]) / (double)((int64_t)H * W);
-    u32 amb = 0;
+    u32 amb = 0, nexact = 0;
+    for (int oct = 0; oct < RT / 32; ++oct) {
+        const int r0 = wave * (RT / 4) + oct * 8;        // first LDS row of this lane's 8 output rows
+        const int y0 = yb + r0;
+        if (y0 >= H) break;                              // wave-uniform
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        float vw[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-        int y = y0 + s;
-        bool pred = false;
-        if (y < H && x < W) {
-            int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
-            int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
-            double nn = (double)(ny * nx);
-            double sum_t = ry[y] * rx[x];
-            double sum_I = 255.0 * (double)(cs0 - pre[s] + post[s]);
-            double num = 255.0 * acc[s] - nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
-            double s1 = sum_I - nn * mu;
-            double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
-            double var = s2 - s1 * s1 * nc.inv_l2;
-            double rhs = nc.thr2 * var * nc.T2;
-            pred = (var > 0.0) && (num > 0.0) && (num * num > rhs);
-            if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
-            if (ncc_out) {                               // diagnostic map with the reference's exact form (:159-163)
-                double v2 = s2 - s1 * s1 / nc.l2;
-                double q = num / sqrt((v2 < 0.0 ? 0.0 : v2) * nc.T2);
-                ncc_out[((int64_t)n * H + y) * W + x] = isfinite(q) ? q : 0.0;
+        for (int i = 0; i < 7; ++i) vw[i] = hxs[r0 + i][lane];
+#pragma unroll 1
+        for (int jb = 0; jb < L / 8; ++jb) {             // rolled: keeps the weights' live ranges to one block
+#pragma unroll
+            for (int jj = 0; jj < 8; ++jj) {
+                const int j = 8 * jb + jj;
+                vw[(jj + 7) & 7] = hxs[r0 + j + 7][lane];
+                const float gj = g32[j];                 // LDS broadcast read
+#pragma unroll
+                for (int s = 0; s < 8; ++s) acc[s] = __builtin_fmaf(gj, vw[(jj + s) & 7], acc[s]);
             }
         }
-        u64 word = __ballot(pred);
-        if (y < H) {
-            if (lane == 0) mbits[((int64_t)n * H + y) * WW + blockIdx.x] = word;
-            if (mask_u8 && x < W) mask_u8[((int64_t)n * H + y) * W + x] = pred ? 1 : 0;
+#pragma unroll
+        for (int j = (L / 8) * 8; j < L; ++j) {          // tail taps (L = 33)
+            vw[(j + 7) & 7] = hxs[r0 + j + 7][lane];
+            const float gj = g32[j];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) acc[s] = __builtin_fmaf(gj, vw[(j + s) & 7], acc[s]);
+        }
+        u32 cs0 = 0, pre[8] = {0, 0, 0, 0, 0, 0, 0, 0}, post[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int i = 0; i < L + 7; ++i) {
+            const u32 c = cxs[r0 + i][lane];
+            if (i < L) cs0 += c;
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                if (i < s) pre[s] += c;                  // rows above window s
+                if (i >= L && i < L + s) post[s] += c;   // rows that window s gains
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            const int y = y0 + s;
+            bool pred = false;
+            if (y < H && x < W) {
+                int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
+                int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
+                double nn = (double)(ny * nx);
+                double sum_t = ry[y] * rx[x];
+                double sum_I = 255.0 * (double)(cs0 - pre[s] + post[s]);
+                double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);       // num = 255 G + rest
+                double s1 = sum_I - nn * mu;
+                double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
+                double var = s2 - s1 * s1 * nc.inv_l2;
+                double rhs = nc.thr2 * var * nc.T2;
+                if (var > 0.0) {
+                    double G = (double)acc[s];
+                    double nlo = 255.0 * G * (1.0 - 1e-5) + rest, nhi = 255.0 * G * (1.0 + 1e-5) + rest;
+                    bool plo = (nlo > 0.0) && (nlo * nlo > rhs), phi = (nhi > 0.0) && (nhi * nhi > rhs);
+                    pred = plo;
+                    if (plo != phi || ncc_out) {          // undecided by float32 (or a map was asked for): exact
+                        u32 dummy = 0;
+                        double Ge = 0.0;
+                        for (int i = 0; i < L; ++i) {
+                            int yy = y + LO + i;
+                            double hrow = (yy >= 0 && yy < H)
+                                              ? ncc_row_exact<L, LO>(fbits + (int64_t)yy * WW, WW, x, cg, &dummy) : 0.0;
+                            Ge = __builtin_fma(gsh[i], hrow, Ge);
+                        }
+                        double num = 255.0 * Ge + rest;
+                        pred = (num > 0.0) && (num * num > rhs);
+                        if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
+                        nexact++;
+                        if (ncc_out) {                   // diagnostic map in the reference's form (:159-163)
+                            double v2 = s2 - s1 * s1 / nc.l2;
+                            double q = num / sqrt((v2 < 0.0 ? 0.0 : v2) * nc.T2);
+                            ncc_out[((int64_t)n * H + y) * W + x] = isfinite(q) ? q : 0.0;
+                        }
+                    }
+                } else if (ncc_out) {
+                    ncc_out[((int64_t)n * H + y) * W + x] = 0.0;      // 0/0 or x/0 -> non-finite -> 0 (:163)
+                }
+            }
+            u64 word = __ballot(pred);
+            if (y < H) {
+                if (lane == 0) mbits[((int64_t)n * H + y) * WW + blockIdx.x] = word;
+                if (mask_u8 && x < W) mask_u8[((int64_t)n * H + y) * W + x] = pred ? 1 : 0;
+            }
         }
     }
     if (amb) atomicAdd(&fstat[n * 8 + 1], amb);
+    if (nexact) atomicAdd(&fstat[n * 8 + 3], nexact);
 }
 
 // area popcount per frame (feeds the global mean of _normxcorr2 :153) when the bits did not come from k_blur_v
@@ -175,7 +225,7 @@ void launch_popcount(vbs_handle* h, int nb, hipStream_t s) {
 }
 
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s) {
-    dim3 grid(h->WW, (h->H + 31) / 32, nb);
+    dim3 grid(h->WW, (h->H + 63) / 64, nb);
     const int stop = getenv("VBS_NCC_STOP") ? atoi(getenv("VBS_NCC_STOP")) : 0;   // debug: phase timing
     if (!h->bp.small) {
         VBS_LAUNCH(h, s, "k_ncc", (k_ncc<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx, h->ncc_ry,
