@@ -201,9 +201,17 @@ def main():
         ncomp = 2 * M
         alg_bytes_frame = 2 * H * W + ncomp * 24
         achieved = alg_bytes_frame * nk / (stage_ms * 1e-3) / 1e9
+        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
+        # the newest profiles/*_pmc_traffic.json, scaled to this run's frames per launch
+        traffic = None
+        import glob
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+        if pm:
+            pj = json.load(open(pm[-1]))
+            traffic = round(pj["traffic_bytes_per_frame"] * nk / n_passes)
         result["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
             "kernel": "+".join(stage), "stage": "threshold+CCL (vbs_marker_center on uint8 mask+area_mask)",
             "algorithmic_bytes_per_frame": alg_bytes_frame, "frames_per_launch": round(nk / n_passes, 1),
             "stage_ms_per_launch": round(stage_ms / n_passes, 4),

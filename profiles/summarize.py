@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Turn the raw rocprofv3 output merged back under gpurun_out/ into the small files kept in profiles/:
+   <tag>_rocprofv3_kernel_stats.csv  rows of this repo's kernels from `--kernel-trace --stats`
+   <tag>_pmc_traffic.json            HBM traffic per launch of the threshold+CCL stage from the FETCH_SIZE / WRITE_SIZE passes
+usage: python profiles/summarize.py <tag> [frames_per_launch=256]"""
+import csv, glob, json, os, sys, collections
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = sys.argv[1]
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+G = os.path.join(ROOT, "gpurun_out")
+
+def one(pattern):
+    f = sorted(glob.glob(os.path.join(G, pattern), recursive=True))
+    if not f:
+        raise SystemExit(f"missing {pattern}")
+    return f[-1]
+
+rows = list(csv.reader(open(one(f"prof_{tag}/**/*kernel_stats.csv"))))
+with open(os.path.join(ROOT, "profiles", f"{tag}_rocprofv3_kernel_stats.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(rows[0])
+    for r in rows[1:]:
+        if r[0].startswith(("void k_", "k_")):
+            w.writerow(r)
+
+def counter(pattern):
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(one(pattern))):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        if k.startswith("k_"):
+            agg[k].append(float(r["Counter_Value"]))
+    return agg
+
+fetch, write = counter(f"pmc_fetch_{tag}/**/*counter_collection.csv"), counter(f"pmc_write_{tag}/**/*counter_collection.csv")
+stage = ("k_threshold", "k_morph", "k_label", "k_finalize")
+per_kernel = {}
+total = 0.0
+for k in stage:
+    n_launch = {"k_morph": 2}.get(k, 1)              # launches per stage call
+    # steady-state launches only (the script runs the stage 4x after one find_markers pass): take the last ones
+    fk = sum(fetch[k][-n_launch:]) * 1024.0          # FETCH_SIZE / WRITE_SIZE are in KiB
+    wk = sum(write[k][-n_launch:]) * 1024.0
+    corr = 2.0 if k == "k_threshold" else 1.0         # gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide
+    per_kernel[k] = {"fetch_bytes_raw": fk, "fetch_correction": corr, "write_bytes": wk,
+                     "bytes": fk * corr + wk}         # (16 B/lane) streaming loads; calibrated for k_threshold only
+    total += fk * corr + wk
+out = {"tag": tag, "frames_per_launch": frames, "stage": "+".join(stage),
+       "traffic_bytes_per_launch": total, "traffic_bytes_per_frame": total / frames,
+       "per_kernel": per_kernel,
+       "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); k_threshold's FETCH_SIZE doubled per MI355X_MICROARCH.md "
+               "(verified: 2 x raw == 2*H*W*frames exactly); the other kernels' narrow / LDS-staged accesses are uncalibrated and "
+               "taken at face value"}
+json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out)[:400])

@@ -98,52 +98,76 @@ __global__ __launch_bounds__(64) void k_blur_h(const u8* __restrict__ gray, int6
     }
 }
 
+// Vertical pass: lane = (column x, TQ consecutive row-quads).  A plane word loaded for the window of one
+// output quad is also tap word q-1 of the next one, so two quads per lane nearly halve the loads.
 template <int NWA, int NWB, int C4A, int C4B>
 __global__ __launch_bounds__(256) void k_blur_v(const u32* __restrict__ planes, u64* __restrict__ bits,
                                                 u8* __restrict__ area_u8, u32* __restrict__ fstat,
                                                 int H, int W, int P, int WW, int QE, int thresh,
                                                 int hi, BlurTaps taps) {
+    constexpr int TQ = 2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int x = blockIdx.x * 64 + lane;
-    const int yq = blockIdx.y * 4 + wave;
+    const int yq0 = (blockIdx.y * 4 + wave) * TQ;
     const int n = blockIdx.z;
-    if (4 * yq >= H) return;                       // wave-uniform
+    if (4 * yq0 >= H) return;                      // wave-uniform
     const int64_t plane_sz = (int64_t)QE * P;
     const u32* pl = planes + (int64_t)n * 4 * plane_sz + x;
-    u32 va_hi[4] = {0, 0, 0, 0}, va_lo[4] = {0, 0, 0, 0}, vb_hi[4] = {0, 0, 0, 0}, vb_lo[4] = {0, 0, 0, 0};
+    u32 va_hi[TQ][4], va_lo[TQ][4], vb_hi[TQ][4], vb_lo[TQ][4];
 #pragma unroll
-    for (int q = 0; q < NWA; ++q) {
-        int64_t off = (int64_t)(yq + (C4B - C4A) / 4 + q) * P;
+    for (int o = 0; o < TQ; ++o)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) va_hi[o][s] = va_lo[o][s] = vb_hi[o][s] = vb_lo[o][s] = 0;
+#pragma unroll
+    for (int q = 0; q < NWA + TQ - 1; ++q) {
+        int qq = min(yq0 + (C4B - C4A) / 4 + q, QE - 1);
+        int64_t off = (int64_t)qq * P;
         u32 ph = pl[0 * plane_sz + off], plo = pl[1 * plane_sz + off];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            va_hi[s] = __builtin_amdgcn_udot4(ph, taps.a[s][q], va_hi[s], false);
-            va_lo[s] = __builtin_amdgcn_udot4(plo, taps.a[s][q], va_lo[s], false);
+        for (int o = 0; o < TQ; ++o) {
+            const int t = q - o;
+            if (t >= 0 && t < NWA) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    va_hi[o][s] = __builtin_amdgcn_udot4(ph, taps.a[s][t], va_hi[o][s], false);
+                    va_lo[o][s] = __builtin_amdgcn_udot4(plo, taps.a[s][t], va_lo[o][s], false);
+                }
+            }
         }
     }
 #pragma unroll
-    for (int q = 0; q < NWB; ++q) {
-        int64_t off = (int64_t)(yq + q) * P;
+    for (int q = 0; q < NWB + TQ - 1; ++q) {
+        int qq = min(yq0 + q, QE - 1);
+        int64_t off = (int64_t)qq * P;
         u32 ph = pl[2 * plane_sz + off], plo = pl[3 * plane_sz + off];
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            vb_hi[s] = __builtin_amdgcn_udot4(ph, taps.b[s][q], vb_hi[s], false);
-            vb_lo[s] = __builtin_amdgcn_udot4(plo, taps.b[s][q], vb_lo[s], false);
+        for (int o = 0; o < TQ; ++o) {
+            const int t = q - o;
+            if (t >= 0 && t < NWB) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    vb_hi[o][s] = __builtin_amdgcn_udot4(ph, taps.b[s][t], vb_hi[o][s], false);
+                    vb_lo[o][s] = __builtin_amdgcn_udot4(plo, taps.b[s][t], vb_lo[o][s], false);
+                }
+            }
         }
     }
     u32 total = 0;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-        int y = 4 * yq + s;
-        u32 b3 = (((va_hi[s] << 8) + va_lo[s]) + 32768u) >> 16;    // im_blur_3 (small kernel)
-        u32 b8 = (((vb_hi[s] << 8) + vb_lo[s]) + 32768u) >> 16;    // im_blur_8 (large kernel)
-        u32 dog = (b8 - b3 + 15u) & 255u;                          // uint8 arithmetic wraps (:128)
-        bool pred = (dog >= (u32)thresh) && (dog <= (u32)hi) && (x < W) && (y < H);
-        u64 word = __ballot(pred);
-        if (y < H) {
-            if (lane == 0) bits[((int64_t)n * H + y) * WW + blockIdx.x] = word;
-            if (area_u8 && x < W) area_u8[((int64_t)n * H + y) * W + x] = pred ? 255 : 0;
-            total += __popcll(word);
+    for (int o = 0; o < TQ; ++o) {
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int y = 4 * (yq0 + o) + s;
+            u32 b3 = (((va_hi[o][s] << 8) + va_lo[o][s]) + 32768u) >> 16;    // im_blur_3 (small kernel)
+            u32 b8 = (((vb_hi[o][s] << 8) + vb_lo[o][s]) + 32768u) >> 16;    // im_blur_8 (large kernel)
+            u32 dog = (b8 - b3 + 15u) & 255u;                                // uint8 arithmetic wraps (:128)
+            bool pred = (dog >= (u32)thresh) && (dog <= (u32)hi) && (x < W) && (y < H);
+            u64 word = __ballot(pred);
+            if (y < H) {
+                if (lane == 0) bits[((int64_t)n * H + y) * WW + blockIdx.x] = word;
+                if (area_u8 && x < W) area_u8[((int64_t)n * H + y) * W + x] = pred ? 255 : 0;
+                total += __popcll(word);
+            }
         }
     }
     if (lane == 0 && total) atomicAdd(&fstat[n * 8 + 0], total);
@@ -159,7 +183,7 @@ void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t 
 void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,
                  u8* area_u8, hipStream_t s) {
     dim3 gh((h->P + 255) / 256, h->QE, nb);
-    dim3 gv(h->WW, (h->H + 15) / 16, nb);
+    dim3 gv(h->WW, (h->H + 31) / 32, nb);
     if (!h->bp.small) {
         VBS_LAUNCH(h, s, "k_blur_h", (k_blur_h<11, 27, 20, 52>), gh, dim3(64), 0, s, gray, gstride_n, gstride_row,
                            h->planes, h->H, h->W, h->P, h->QE, h->taps);
