@@ -200,6 +200,35 @@ def test_matching_sequential_replay_equals_parallel(monkeypatch):
     assert par == seq and len(par) == spec.n_markers
 
 
+def test_holes_are_reported_not_silent():
+    """Euler-number check: a ring-shaped area blob (one hole) is flagged, hole-free frames report 0."""
+    import warnings
+    from vbs_amd.marker_detection import MarkerTracker
+    yy, xx = np.mgrid[0:256, 0:320]
+    r2 = (yy - 120) ** 2 + (xx - 150) ** 2
+    area = ((r2 <= 40 ** 2) & (r2 >= 15 ** 2)).astype(np.uint8) * 255
+    area[200:230, 20:60] = 255                           # a second, hole-free blob
+    mask = (r2 <= 30 ** 2).astype(np.uint8)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        MarkerTracker._marker_center(mask, area)
+    assert any("1 hole(s)" in str(x.message) for x in w)
+    eng = engine(256, 320, max_batch=1)
+    eng.marker_center(torch.from_numpy(mask).cuda(), torch.from_numpy(area).cuda())
+    assert eng.frame_stats(1)[0, 4] == 1
+    filled = (r2 <= 40 ** 2).astype(np.uint8) * 255
+    filled[0:20, 0:30] = 255                             # touches the image corner: zero padding matters
+    filled[236:256, 300:320] = 255
+    eng.marker_center(torch.from_numpy(mask).cuda(), torch.from_numpy(filled).cuda())
+    assert eng.frame_stats(1)[0, 4] == 0
+    spec = S.config2()
+    om, oa = O.find_markers(S.make_frames(spec, [1], seed=4)[0])
+    e2 = engine(spec.height, spec.width, max_batch=1)
+    e2.marker_center(torch.from_numpy(om).cuda(), torch.from_numpy(oa).cuda())
+    assert e2.frame_stats(1)[0, 4] == 0
+    eng.close(); e2.close()
+
+
 def test_marker_center_empty_and_capacity():
     from vbs_amd.marker_detection import MarkerTracker
     z = np.zeros((128, 256), dtype=np.uint8)

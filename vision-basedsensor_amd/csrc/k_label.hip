@@ -278,6 +278,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     __shared__ u64 acc_sx[1024];
     __shared__ u64 acc_sy[1024];
     __shared__ u8 lut[256];
+    __shared__ int euler4;                             // 4 x Euler number of the opened mask (bit quads)
     const int n = blockIdx.x, m = blockIdx.y;          // m = 0 band (4-conn), 1 open (8-conn)
     const int tid = threadIdx.x, nthr = blockDim.x;
     const int NW = H * WW;
@@ -287,6 +288,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     u32* node_comp = node_comp_all + ((int64_t)n * 2 + m) * VBS_RUN_CAP;
     if (stop == 9) return;
     if (tid < 256) lut[tid] = lut_g[tid];
+    if (tid == 0) euler4 = 0;
     for (int i = tid; i < 1024; i += nthr) { acc_cnt[i] = 0; acc_sx[i] = 0; acc_sy[i] = 0; }
 
     // ---- A + C, streamed over strips of rows staged in LDS ------------------------------------------
@@ -465,6 +467,24 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         i64 s[NMOM];
 #pragma unroll
         for (int q = 0; q < NMOM; ++q) s[q] = 0;
+        // Euler number by bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of
+        // the zero-padded image; window (x, y) = pixels (x..x+1, y..y+1).  holes = components - E, reported so
+        // that a frame whose RETR_EXTERNAL contours could differ from this kernel's is never silent.
+        int e4 = 0;
+        for (int y = (fy0 == 0 ? -1 : fy0); y < fy1; ++y) {
+            u64 a = 0, an = 0, b = 0, bn = 0;
+            if (y >= 0) { a = bits[(int64_t)y * WW + cj]; an = (cj + 1 < WW) ? bits[(int64_t)y * WW + cj + 1] : 0ull; }
+            if (y + 1 < H) { b = bits[(int64_t)(y + 1) * WW + cj]; bn = (cj + 1 < WW) ? bits[(int64_t)(y + 1) * WW + cj + 1] : 0ull; }
+            if (!(a | b | (an & 1ull) | (bn & 1ull))) continue;
+            u64 a1 = (a >> 1) | (an << 63), b1 = (b >> 1) | (bn << 63);
+            u64 x2 = (a ^ a1) ^ (b ^ b1);                                   // odd count: 1 or 3
+            u64 pairs = (a & a1) | (a & b) | (a & b1) | (a1 & b) | (a1 & b1) | (b & b1);   // count >= 2
+            u64 q1 = x2 & ~pairs, q3 = x2 & pairs;
+            u64 qd = (a & b1 & ~a1 & ~b) | (a1 & b & ~a & ~b1);
+            e4 += __popcll(q1) - __popcll(q3) - 2 * __popcll(qd);
+            if (cj == 0) e4 += (int)((a ^ b) & 1ull);                      // window x = -1: only (0,y), (0,y+1)
+        }
+        if (e4) atomicAdd(&euler4, e4);
         for (int y = fy0; y < fy1; ++y) {
             const u64* row = bits + (int64_t)y * WW;
             u64 w = row[cj];
@@ -538,6 +558,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         __syncthreads();
         i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
         for (u32 c = tid; c < ncomp * NMOM; c += nthr) as[(c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
+        if (tid == 0) fstat[n * 8 + 4] = (u32)((int)ncomp - euler4 / 4);       // holes in the opened mask
     }
 }
 

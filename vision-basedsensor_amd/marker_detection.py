@@ -172,6 +172,11 @@ class MarkerTracker:
         if n < 0:
             from ._lib import VbsError
             raise VbsError(f"_marker_center: device status {n} (capacity exceeded)")
+        holes = int(eng.frame_stats(1)[0, 4])
+        if holes:
+            import warnings
+            warnings.warn(f"{holes} hole(s) in the opened area mask: contour vertices include hole borders, "
+                          "cv2.findContours(RETR_EXTERNAL) would ignore them (DESIGN.md section 7)", RuntimeWarning)
         return _det_to_markers(det[0].cpu().numpy(), n)
 
     # ---- identities and tracking -----------------------------------------------------------------
