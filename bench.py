@@ -133,7 +133,7 @@ def main():
     def step():
         table, _, counts = eng.track_to_3d(frames, xy, 20.0, cam, 5.0)
         table = D.gather_tables(table, n_total)
-        disp = eng.displacement(table, 0, 5.0, 50.0)
+        disp = eng.displacement(table, 0, 5.0, 50.0, frame_range=(a, b))    # this rank's frames of the gathered table
         return table, disp, counts
 
     def barrier():

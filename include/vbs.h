@@ -150,6 +150,13 @@ int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int channels, i
 int vbs_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup_frames,
                      double min_marker_size_px, double max_displacement, float* disp, void* stream);
 
+/* The same, emitting only frames [frame_begin, frame_end) of a table holding frames [0, n): what a rank of a
+ * multi-GPU run calls on the gathered table for its own shard (disp [dev] float32 [frame_end-frame_begin, m_ref, 5]).
+ * The look-back for the last-seen frame may reach before frame_begin. */
+int vbs_displacement_range(vbs_handle* h, const float* table, int n, int m_ref, int warmup_frames,
+                           double min_marker_size_px, double max_displacement, int frame_begin, int frame_end,
+                           float* disp, void* stream);
+
 /* The same on float64 tables (same column layout, no handle): what `MarkerAnalysis._track_markers(df)`
  * uses so that the DataFrame interface keeps the reference's float64 results. */
 int vbs_displacement_f64(int device, const double* table, int n, int m_ref, int warmup_frames,

@@ -395,6 +395,51 @@ def test_fused_track_to_3d_displacement_plane(tag, nframes):
     eng.close()
 
 
+def test_displacement_range_and_gaps():
+    """a21 on a synthetic table with gaps, invalid 3-D rows, a jump and a warm-up: the chunk-parallel kernel
+    equals a plain sequential restatement of `3d_reconstruction.py:263-314`, and a rank's frame range of the
+    gathered table equals the same rows of the full result (look-back across the range start)."""
+    rng = np.random.default_rng(0)
+    n, m = 301, 37
+    tab = np.zeros((n, m, 10), dtype=np.float32)
+    present = rng.random((n, m)) < 0.8
+    present[:3] = False
+    present[40:120, 5] = False                      # long gap for one ID
+    ok = rng.random((n, m)) < 0.95
+    tab[..., 0] = present * (1 + 2 * ok)
+    tab[..., 3] = np.where(rng.random((n, m)) < 0.03, 4.0, 20.0)      # some rows fail the size filter
+    xyz = np.cumsum(rng.normal(0, 0.3, (n, m, 3)), axis=0) + 30
+    xyz[200, 7] += 80.0                            # > 50 mm jump
+    tab[..., 6:9] = xyz
+    warm, minsz, lim = 10, 5.0, 50.0
+    want = np.zeros((n, m, 5), dtype=np.float64)
+    seen = (tab[..., 0].astype(int) & 1 > 0) & (tab[..., 3] >= minsz)
+    fmin = int(np.nonzero(seen.any(1))[0][0])
+    for r in range(m):
+        last = None
+        for f in range(fmin + warm, n):
+            if not seen[f, r]:
+                continue
+            good = int(tab[f, r, 0]) & 2
+            cur = tab[f, r, 6:9].astype(np.float64)
+            if last is not None and last[0] and good:
+                d = cur - last[1]
+                mm = np.sqrt((d * d).sum())
+                if not mm > lim:
+                    want[f, r] = [1, d[0], d[1], d[2], mm]
+            last = (good, cur)
+    eng = engine(480, 640)
+    tt = torch.from_numpy(tab).cuda()
+    full = eng.displacement(tt, warm, minsz, lim).cpu().numpy()
+    assert np.array_equal(full[..., 0], want[..., 0])
+    np.testing.assert_allclose(full[..., 1:], want[..., 1:], rtol=1e-6, atol=1e-6)
+    assert want[200, 7, 0] == 0 and want[..., 0].sum() > 1000
+    for a, b in ((0, 64), (64, 200), (150, 301), (117, 123)):
+        part = eng.displacement(tt, warm, minsz, lim, frame_range=(a, b)).cpu().numpy()
+        assert np.array_equal(part, full[a:b])
+    eng.close()
+
+
 def test_batch_and_chunk_independence():
     """Size-independent property at batch scale: a frame's table row does not depend on the batch it
     travels in, nor on the engine's internal chunking (frames are independent units)."""

@@ -13,7 +13,7 @@ FLAG_TRACKED, FLAG_XYZ = 1, 2
 SYMBOLS = ("vbs_create", "vbs_destroy", "vbs_last_error", "vbs_version", "vbs_contour_lut",
            "vbs_gaussian_taps_q8", "vbs_ncc_template", "vbs_find_markers", "vbs_ncc_map", "vbs_normxcorr2",
            "vbs_profile", "vbs_profile_read", "vbs_frame_stats", "vbs_undistort_points", "vbs_calculate_3d", "vbs_marker_center",
-           "vbs_track", "vbs_solve3d", "vbs_track_to_3d", "vbs_displacement", "vbs_displacement_f64",
+           "vbs_track", "vbs_solve3d", "vbs_track_to_3d", "vbs_displacement", "vbs_displacement_range", "vbs_displacement_f64",
            "vbs_plane_fit")
 
 
@@ -62,6 +62,7 @@ def lib():
         "vbs_solve3d": (i32, [vp, vp, i32, i32, cam_p, f64, vp]),
         "vbs_track_to_3d": (i32, [vp, vp, i32, i32, i64, i64, vp, i32, f64, cam_p, f64, vp, vp, vp, vp]),
         "vbs_displacement": (i32, [vp, vp, i32, i32, i32, f64, f64, vp, vp]),
+        "vbs_displacement_range": (i32, [vp, vp, i32, i32, i32, f64, f64, i32, i32, vp, vp]),
         "vbs_displacement_f64": (i32, [i32, vp, i32, i32, i32, f64, f64, vp, vp]),
         "vbs_plane_fit": (i32, [vp, vp, i32, i32, vp, vp]),
     }

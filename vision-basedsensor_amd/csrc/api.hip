@@ -172,7 +172,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(area_bits, B * HW); ALLOC(mask_bits, B * HW); ALLOC(band_bits, B * HW);
     ALLOC(er_bits, B * HW); ALLOC(open_bits, B * HW);
     ALLOC(ncc_rx, (size_t)width); ALLOC(ncc_ry, (size_t)height);
-    ALLOC(fstat, B * 8);
+    ALLOC(fstat, B * 8 + 8);                           // + one spare word (displacement's first-frame cell)
     ALLOC(wbase, B * 2 * HW);
     ALLOC(node_pos, B * 2 * VBS_RUN_CAP); ALLOC(node_comp, B * 2 * VBS_RUN_CAP);
     ALLOC(ncomp, B * 2);
@@ -411,14 +411,25 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
     return VBS_OK;
 }
 
+extern "C" int vbs_displacement_range(vbs_handle* h, const float* table, int n, int m_ref, int warmup_frames,
+                                      double min_marker_size_px, double max_displacement, int frame_begin,
+                                      int frame_end, float* disp, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!table || !disp || n < 0 || m_ref < 1 || frame_begin < 0 || frame_end > n || frame_begin > frame_end) {
+        h->err = "vbs_displacement: bad argument";
+        return VBS_EINVAL;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (frame_end > frame_begin)
+        launch_displacement(h, table, n, m_ref, warmup_frames, min_marker_size_px, max_displacement, frame_begin,
+                            frame_end, disp, (hipStream_t)stream);
+    return check_launch(h);
+}
+
 extern "C" int vbs_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup_frames,
                                 double min_marker_size_px, double max_displacement, float* disp, void* stream) {
-    if (!h) return VBS_EINVAL;
-    if (!table || !disp || n < 0 || m_ref < 1) { h->err = "vbs_displacement: bad argument"; return VBS_EINVAL; }
-    HIPCHK(h, hipSetDevice(h->device));
-    if (n) launch_displacement(h, table, n, m_ref, warmup_frames, min_marker_size_px, max_displacement, disp,
-                               (hipStream_t)stream);
-    return check_launch(h);
+    return vbs_displacement_range(h, table, n, m_ref, warmup_frames, min_marker_size_px, max_displacement, 0, n, disp,
+                                  stream);
 }
 
 extern "C" int vbs_displacement_f64(int device, const double* table, int n, int m_ref, int warmup_frames,
@@ -426,8 +437,13 @@ extern "C" int vbs_displacement_f64(int device, const double* table, int n, int 
                                     void* stream) {
     if (!table || !disp || n < 0 || m_ref < 1) return VBS_EINVAL;
     if (hipSetDevice(device) != hipSuccess) return VBS_EHIP;
-    if (n) launch_displacement64(table, n, m_ref, warmup_frames, min_marker_size_px, max_displacement, disp,
-                                 (hipStream_t)stream);
+    if (n) {
+        int* cell = nullptr;                            // first-frame cell: a small stream-ordered allocation
+        if (hipMallocAsync((void**)&cell, sizeof(int), (hipStream_t)stream) != hipSuccess) return VBS_ENOMEM;
+        launch_displacement64(table, n, m_ref, warmup_frames, min_marker_size_px, max_displacement, disp, cell,
+                              (hipStream_t)stream);
+        (void)hipFreeAsync(cell, (hipStream_t)stream);
+    }
     return hipGetLastError() == hipSuccess ? VBS_OK : VBS_EHIP;
 }
 

@@ -118,7 +118,7 @@ void launch_track(vbs_handle* h, const double* det, const int32_t* counts32, int
 void launch_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_camera& cam,
                     double min_size, hipStream_t s);
 void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup,
-                         double min_size, double max_disp, float* disp, hipStream_t s);
+                         double min_size, double max_disp, int f0, int f1, float* disp, hipStream_t s);
 void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane,
                       hipStream_t s);
 void make_contour_lut(u8 out[256]);
@@ -126,4 +126,4 @@ void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, 
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s);
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s);
 void launch_displacement64(const double* table, int n, int m_ref, int warmup, double min_size, double max_disp,
-                           double* disp, hipStream_t s);
+                           double* disp, int* fmin_scratch, hipStream_t s);

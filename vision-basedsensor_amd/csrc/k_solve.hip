@@ -128,50 +128,63 @@ __global__ __launch_bounds__(256) void k_solve3d(float* __restrict__ table, int6
     row[0] = (float)flags;
 }
 
-// one workgroup; thread per reference ID walks the frames in order
+// first frame that holds any row surviving load_marker_data's size filter (:172-176) -> *fmin
 template <typename TT>
-__global__ __launch_bounds__(1024) void k_displacement(const TT* __restrict__ table, int n, int m_ref,
-                                                       int warmup, double min_size, double max_disp,
-                                                       TT* __restrict__ disp) {
-    __shared__ int fmin_s;
-    if (threadIdx.x == 0) fmin_s = 0x7fffffff;
-    __syncthreads();
-    // first frame holding any row that survives load_marker_data's size filter (:172-176)
-    int myfirst = 0x7fffffff;
-    for (int r = threadIdx.x; r < m_ref; r += blockDim.x) {
-        for (int f = 0; f < n; ++f) {
-            const TT* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
-            if (((int)row[0] & VBS_FLAG_TRACKED) && (double)row[3] >= min_size) { myfirst = min(myfirst, f); break; }
+__global__ __launch_bounds__(256) void k_disp_first(const TT* __restrict__ table, int n, int m_ref, double min_size,
+                                                    int* __restrict__ fmin) {
+    int f = blockIdx.x;
+    bool any = false;
+    for (int r = threadIdx.x; r < m_ref && !any; r += 256) {
+        const TT* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
+        any = ((int)row[0] & VBS_FLAG_TRACKED) && (double)row[3] >= min_size;
+    }
+    if (__syncthreads_or(any) && threadIdx.x == 0) atomicMin(fmin, f);
+}
+
+// Last-seen displacement (:263-314), chunk-parallel: block = (chunk of CH frames) x (256 reference IDs).  A lane
+// first looks BACK from its chunk for the frame in which its ID was last seen (the reference's marker_dict entry),
+// then walks its chunk forward.  Emits frames [f0, f1) of a table that holds frames [0, n).
+template <typename TT>
+__global__ __launch_bounds__(256) void k_displacement(const TT* __restrict__ table, int n, int m_ref, int warmup,
+                                                      double min_size, double max_disp, int f0, int f1,
+                                                      const int* __restrict__ fmin_p, TT* __restrict__ disp) {
+    constexpr int CH = 32;
+    const int r = blockIdx.y * 256 + threadIdx.x;
+    if (r >= m_ref) return;
+    const int fmin = *fmin_p;
+    const int64_t fstart = (fmin >= 0x7f7f7f7f) ? (int64_t)n : (int64_t)fmin + max(warmup, 0);
+    const int c0 = f0 + blockIdx.x * CH, c1 = min(c0 + CH, f1);
+    bool have = false, last_ok = false;
+    double L[3] = {0, 0, 0};
+    for (int f = c0 - 1; f >= 0 && f >= fstart; --f) {             // carry-in
+        const TT* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
+        int flags = (int)row[0];
+        if ((flags & VBS_FLAG_TRACKED) && (double)row[3] >= min_size) {
+            have = true; last_ok = flags & VBS_FLAG_XYZ;
+            L[0] = (double)row[6]; L[1] = (double)row[7]; L[2] = (double)row[8];
+            break;
         }
     }
-    atomicMin(&fmin_s, myfirst);
-    __syncthreads();
-    const int fmin = fmin_s;
-    const int64_t fstart = (fmin == 0x7fffffff) ? (int64_t)n : (int64_t)fmin + max(warmup, 0);
-    for (int r = threadIdx.x; r < m_ref; r += blockDim.x) {
-        bool have = false, last_ok = false;
-        double L[3] = {0, 0, 0};
-        for (int f = 0; f < n; ++f) {
-            const TT* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
-            TT* o = disp + ((int64_t)f * m_ref + r) * VBS_DISP_COLS;
-            TT out[VBS_DISP_COLS] = {0, 0, 0, 0, 0};
-            int flags = (int)row[0];
-            bool present = (flags & VBS_FLAG_TRACKED) && (double)row[3] >= min_size && f >= fstart;
-            if (present) {
-                bool ok = flags & VBS_FLAG_XYZ;
-                double C[3] = {(double)row[6], (double)row[7], (double)row[8]};
-                if (have && last_ok && ok) {
-                    double dx = C[0] - L[0], dy = C[1] - L[1], dz = C[2] - L[2];
-                    double mm = sqrt(dx * dx + dy * dy + dz * dz);
-                    if (!(mm > max_disp)) {
-                        out[0] = (TT)1; out[1] = (TT)dx; out[2] = (TT)dy; out[3] = (TT)dz; out[4] = (TT)mm;
-                    }
+    for (int f = c0; f < c1; ++f) {
+        const TT* row = table + ((int64_t)f * m_ref + r) * VBS_TABLE_COLS;
+        TT* o = disp + ((int64_t)(f - f0) * m_ref + r) * VBS_DISP_COLS;
+        TT out[VBS_DISP_COLS] = {0, 0, 0, 0, 0};
+        int flags = (int)row[0];
+        bool present = (flags & VBS_FLAG_TRACKED) && (double)row[3] >= min_size && f >= fstart;
+        if (present) {
+            bool ok = flags & VBS_FLAG_XYZ;
+            double C[3] = {(double)row[6], (double)row[7], (double)row[8]};
+            if (have && last_ok && ok) {
+                double dx = C[0] - L[0], dy = C[1] - L[1], dz = C[2] - L[2];
+                double mm = sqrt(dx * dx + dy * dy + dz * dz);
+                if (!(mm > max_disp)) {
+                    out[0] = (TT)1; out[1] = (TT)dx; out[2] = (TT)dy; out[3] = (TT)dz; out[4] = (TT)mm;
                 }
-                have = true; last_ok = ok;
-                L[0] = C[0]; L[1] = C[1]; L[2] = C[2];
             }
-            for (int c = 0; c < VBS_DISP_COLS; ++c) o[c] = out[c];
+            have = true; last_ok = ok;
+            L[0] = C[0]; L[1] = C[1]; L[2] = C[2];
         }
+        for (int c = 0; c < VBS_DISP_COLS; ++c) o[c] = out[c];
     }
 }
 
@@ -258,15 +271,22 @@ void launch_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_cam
 }
 
 void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup, double min_size,
-                         double max_disp, float* disp, hipStream_t s) {
-    VBS_LAUNCH(h, s, "k_displacement", k_displacement<float>, dim3(1), dim3(1024), 0, s, table, n, m_ref, warmup, min_size,
-                       max_disp, disp);
+                         double max_disp, int f0, int f1, float* disp, hipStream_t s) {
+    int* fmin = reinterpret_cast<int*>(h->fstat + (size_t)h->maxb * 8);      // one spare word behind the counters
+    (void)hipMemsetAsync(fmin, 0x7f, sizeof(int), s);                         // 0x7f7f7f7f: "no frame"
+    VBS_LAUNCH(h, s, "k_disp_first", k_disp_first<float>, dim3(n), dim3(256), 0, s, table, n, m_ref, min_size, fmin);
+    dim3 grid((f1 - f0 + 31) / 32, (m_ref + 255) / 256);
+    VBS_LAUNCH(h, s, "k_displacement", k_displacement<float>, grid, dim3(256), 0, s, table, n, m_ref, warmup, min_size,
+               max_disp, f0, f1, fmin, disp);
 }
 
 void launch_displacement64(const double* table, int n, int m_ref, int warmup, double min_size, double max_disp,
-                           double* disp, hipStream_t s) {
-    hipLaunchKernelGGL(k_displacement<double>, dim3(1), dim3(1024), 0, s, table, n, m_ref, warmup, min_size,
-                       max_disp, disp);
+                           double* disp, int* fmin_scratch, hipStream_t s) {
+    (void)hipMemsetAsync(fmin_scratch, 0x7f, sizeof(int), s);
+    hipLaunchKernelGGL(k_disp_first<double>, dim3(n), dim3(256), 0, s, table, n, m_ref, min_size, fmin_scratch);
+    dim3 grid((n + 31) / 32, (m_ref + 255) / 256);
+    hipLaunchKernelGGL(k_displacement<double>, grid, dim3(256), 0, s, table, n, m_ref, warmup, min_size, max_disp, 0, n,
+                       fmin_scratch, disp);
 }
 
 void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane, hipStream_t s) {

@@ -189,14 +189,17 @@ class Engine:
         return table, det, counts
 
     # ---- a21, f1 -------------------------------------------------------------------------------
-    def displacement(self, table, warmup_frames=100, min_marker_size_px=5.0, max_displacement=50.0):
+    def displacement(self, table, warmup_frames=100, min_marker_size_px=5.0, max_displacement=50.0,
+                     frame_range=None):
+        """Last-seen displacement of `table` [n,m,10]; `frame_range=(a, b)` emits only frames [a, b)."""
         table = table.contiguous()
         n, m = table.shape[0], table.shape[1]
-        disp = torch.empty((n, m, L.DISP_COLS), dtype=torch.float32, device=self.device)
+        a, b = (0, n) if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
+        disp = torch.empty((b - a, m, L.DISP_COLS), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):
-            self._check(self.lib.vbs_displacement(self._h, _ptr(table), n, m, int(warmup_frames),
-                                                  float(min_marker_size_px), float(max_displacement), _ptr(disp),
-                                                  self._stream()), "vbs_displacement")
+            self._check(self.lib.vbs_displacement_range(self._h, _ptr(table), n, m, int(warmup_frames),
+                                                        float(min_marker_size_px), float(max_displacement), a, b,
+                                                        _ptr(disp), self._stream()), "vbs_displacement")
         return disp
 
     def plane_fit(self, table):

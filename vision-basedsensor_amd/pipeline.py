@@ -20,8 +20,10 @@ class TrackResult:
     ids: np.ndarray            # [M,2] (row, col) per slot
     ref_xy: np.ndarray         # [M,2]
     table: torch.Tensor        # [N,M,10] float32 (gathered when distributed)
-    disp: Optional[torch.Tensor]     # [N,M,5]
-    plane: Optional[torch.Tensor]    # [N,5]
+    disp: Optional[torch.Tensor]     # [n_local,M,5]  this rank's frames [frame_begin, frame_end)
+    plane: Optional[torch.Tensor]    # [n_local,5]
+    frame_begin: int = 0
+    frame_end: int = 0
 
 
 def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mode="full", kmeans="optimal"):
@@ -47,11 +49,14 @@ def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None,
         ids, xy = D.broadcast_reference(ids, xy, eng.device)
     else:
         ids, xy = ref
-    table, _, counts = eng.track_to_3d(frames_local, xy, min_dist, cam, min_marker_size_px)
-    table = D.gather_tables(table, n_total)
+    local, _, counts = eng.track_to_3d(frames_local, xy, min_dist, cam, min_marker_size_px)
+    table = D.gather_tables(local, n_total)
+    a, b = D.shard_bounds(n_total, ws, rank)
     disp = plane = None
     if cam is not None:
-        disp = eng.displacement(table, warmup_frames, min_marker_size_px, max_displacement)
+        # every rank scans only its own frames of the gathered table (the look-back may cross into the previous
+        # rank's block), so the per-rank work does not grow with the number of GPUs
+        disp = eng.displacement(table, warmup_frames, min_marker_size_px, max_displacement, frame_range=(a, b))
         if with_plane:
-            plane = eng.plane_fit(table)
-    return TrackResult(ids, xy, table, disp, plane)
+            plane = eng.plane_fit(local)
+    return TrackResult(ids, xy, table, disp, plane, a, b)
