@@ -131,7 +131,8 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
                           vbs_handle** out) {
     if (!out) return VBS_EINVAL;
     *out = nullptr;
-    if (height < 64 || width < 128 || max_markers < 1 || max_markers > 1024 || max_batch < 1) return VBS_EINVAL;
+    if (height < 64 || width < 128 || width > 4096 || max_markers < 1 || max_markers > 1024 || max_batch < 1)
+        return VBS_EINVAL;                                  // k_label keeps one row (<= 64 words) per wave
     vbs_handle* h = new (std::nothrow) vbs_handle();
     if (!h) return VBS_ENOMEM;
     *out = h;                                           // returned even on failure so the text can be read

@@ -260,7 +260,147 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* tmp, u32* total)
 
 #define NMOM 15
 // moment index of x^a y^b, a+b <= 4:  (0,0) (1,0) (0,1) (2,0) (1,1) (0,2) (3,0) (2,1) (1,2) (0,3) (4,0) (3,1) (2,2) (1,3) (0,4)
+#define NONE32 0xFFFFFFFFu
 
+// ---- wave64 cross-lane primitives on DPP (gfx9: wave_shr/wave_shl/row_shr/row_bcast), a few cycles each;
+//      __shfl_* would go through ds_bpermute and its LDS-crossbar latency on every step of a row ----------
+__device__ __forceinline__ u32 dpp_shr1(u32 x) {        // lane i <- lane i-1, lane 0 <- 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u32 dpp_shl1(u32 x) {        // lane i <- lane i+1, lane 63 <- 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64 dpp_shr1(u64 x) {
+    return ((u64)dpp_shr1((u32)(x >> 32)) << 32) | dpp_shr1((u32)x);
+}
+__device__ __forceinline__ u64 dpp_shl1(u64 x) {
+    return ((u64)dpp_shl1((u32)(x >> 32)) << 32) | dpp_shl1((u32)x);
+}
+__device__ __forceinline__ u32 wave_scan_incl(u32 x) {   // inclusive prefix sum over the 64 lanes
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);   // row_shr:4
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);   // row_shr:8
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);   // row_bcast:15 -> rows 1, 3
+    x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);   // row_bcast:31 -> rows 2, 3
+    return x;
+}
+__device__ __forceinline__ u32 wave_last(u32 x) { return (u32)__builtin_amdgcn_readlane((int)x, 63); }
+
+
+// Per-lane view of one image row: lane j holds word j (64 px), the run-start bits in it, the node index of
+// the first run that starts in it, and the node of the run that enters it from the left (NONE32 if none).
+struct RowState {
+    u64 w, st;
+    u32 base, cin;
+};
+
+// Build the RowState of a row from its words (lane j < WW holds word j, other lanes 0).  `rowbase` is the node
+// index of the row's first run (wave-uniform) and is advanced past the row.
+__device__ __forceinline__ RowState make_row_state(u64 w, u32& rowbase) {
+    const int lane = threadIdx.x & 63;
+    RowState s;
+    s.w = w;
+    const u64 msb = (u64)(dpp_shr1((u32)(w >> 32)) >> 31);                 // bit 63 of word j-1 (0 for lane 0)
+    s.st = w & ~((w << 1) | msb);
+    const u32 c = __popcll(s.st);
+    const u32 inc = wave_scan_incl(c);
+    s.base = rowbase + inc - c;
+    rowbase += wave_last(inc);
+    // node entering from the left = last run of word j-1, which is that word's last start, or - when word j-1 is
+    // all ones inside one long run - the run entering IT (resolved by iterating; one pass unless runs span > 64 px)
+    const bool cont = (w & 1ull) && msb;
+    const bool full = cont && (w == ~0ull);
+    const u32 last_here = c ? s.base + c - 1 : NONE32;
+    u32 lastnode = last_here;
+    s.cin = NONE32;
+    for (int it = 0; it < 64; ++it) {
+        u32 upn = dpp_shr1(lastnode);
+        if (lane == 0) upn = NONE32;
+        u32 ncin = cont ? upn : NONE32;
+        u32 nlast = c ? last_here : (full ? ncin : NONE32);
+        bool changed = (ncin != s.cin) || (nlast != lastnode);
+        s.cin = ncin;
+        lastnode = nlast;
+        if (!__any(changed)) break;
+    }
+    return s;
+}
+
+__device__ __forceinline__ RowState shfl_state_up(const RowState& s) {       // state of lane j-1 (zeros for lane 0)
+    RowState r;
+    r.w = dpp_shr1(s.w); r.st = dpp_shr1(s.st); r.base = dpp_shr1(s.base); r.cin = dpp_shr1(s.cin);
+    if ((threadIdx.x & 63) == 0) r.cin = NONE32;
+    return r;
+}
+
+__device__ __forceinline__ RowState shfl_state_down(const RowState& s) {     // state of lane j+1 (zeros for lane 63)
+    RowState r;
+    r.w = dpp_shl1(s.w); r.st = dpp_shl1(s.st); r.base = dpp_shl1(s.base); r.cin = dpp_shl1(s.cin);
+    if ((threadIdx.x & 63) == 63) r.cin = NONE32;
+    return r;
+}
+
+// node (run) index of the run containing bit k of this lane's word
+__device__ __forceinline__ u32 node_in_row(const RowState& s, int k) {
+    const u64 below = k ? ((1ull << k) - 1ull) : 0ull;
+    const u64 z = ~s.w & below;
+    if (z) {
+        const int stpos = 64 - __clzll(z);
+        return s.base + (u32)__popcll(s.st & ((1ull << stpos) - 1ull));
+    }
+    if ((s.w & 1ull) && s.cin != NONE32) return s.cin;
+    return s.base;
+}
+
+// unions of the runs of row `cur` with the runs of the row above (`prev`): 4-connectivity (m = 0) or 8 (m = 1)
+__device__ __forceinline__ void link_rows(u32* parent, const RowState& cur, const RowState& prev, int m) {
+    const RowState pl = shfl_state_up(prev), pr = shfl_state_down(prev);       // every lane takes part in the shuffles
+    const u64 B = cur.w, A = prev.w;
+    u64 adj = A;
+    if (m == 1) adj |= (A << 1) | (A >> 1) | (pl.w >> 63) | (pr.w << 63);
+    u64 mB = (B & adj) ? B : 0ull;
+    while (mB) {                                       // groups of consecutive 1s of B inside this word
+        u64 lowbit = mB & (~mB + 1ull);
+        u64 t = mB + lowbit;
+        u64 g = mB & ~t;
+        mB &= t;
+        if (!(g & adj)) continue;
+        const u32 nb_ = node_in_row(cur, __ffsll((long long)g) - 1);
+        u64 rm = g;
+        if (m == 1) rm |= (g << 1) | (g >> 1);
+        u64 mA = A & rm;
+        while (mA) {
+            u64 lb = mA & (~mA + 1ull);
+            u64 t2 = mA + lb;
+            u64 ga = mA & ~t2;
+            mA &= t2;
+            uf_union(parent, node_in_row(prev, __ffsll((long long)ga) - 1), nb_);
+        }
+        if (m == 1) {
+            if ((g & 1ull) && (pl.w >> 63)) uf_union(parent, node_in_row(pl, 63), nb_);
+            if ((g >> 63) && (pr.w & 1ull)) uf_union(parent, node_in_row(pr, 0), nb_);
+        }
+    }
+}
+
+// 4-deep register ring of row words: PF_INIT issues the loads of rows y0..y0+3, PF_NEXT hands out row y and
+// issues row y+4, so a row-step never waits for a load it has just issued.  (lane j < WW holds word j.)
+#define PF_INIT(ptr, y0, ylim)                                                                      \
+    u64 pf0 = (act && (y0) + 0 < (ylim)) ? (ptr)[(int64_t)((y0) + 0) * WW + lane] : 0ull;          \
+    u64 pf1 = (act && (y0) + 1 < (ylim)) ? (ptr)[(int64_t)((y0) + 1) * WW + lane] : 0ull;          \
+    u64 pf2 = (act && (y0) + 2 < (ylim)) ? (ptr)[(int64_t)((y0) + 2) * WW + lane] : 0ull;          \
+    u64 pf3 = (act && (y0) + 3 < (ylim)) ? (ptr)[(int64_t)((y0) + 3) * WW + lane] : 0ull;
+#define PF_NEXT(ptr, y, ylim, out)                                                                  \
+    out = pf0; pf0 = pf1; pf1 = pf2; pf2 = pf3;                                                     \
+    pf3 = (act && (y) + 4 < (ylim)) ? (ptr)[(int64_t)((y) + 4) * WW + lane] : 0ull;
+
+// One workgroup (16 waves) per (frame, mask).  Wave w owns the strip of rows [w R, (w+1) R), R = ceil(H / 16),
+// and walks it top-down with lane j holding word j of the row: run starts, node indices and the links to the row
+// above come from registers and wave shuffles, the union-find table lives in LDS.  Because a row is linked only
+// after the rows above it, the trees stay shallow (path halving keeps them flat); the 15 strip boundaries are
+// linked at the end.  Node indices follow raster order, so the root (minimum) of a component is its first run and
+// component ids come out in ndimage.label order.
 __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bits,
                                                 const u64* __restrict__ open_bits,
                                                 u32* __restrict__ wbase_all, u32* __restrict__ node_pos_all,
@@ -269,18 +409,17 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                                                 u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                 u32* __restrict__ fstat, const u8* __restrict__ lut_g,
                                                 int H, int W, int WW, int maxm, int stop) {
-    constexpr int STRIPW = 1024;                       // words of one strip incl. the carried row
-    __shared__ u32 parent[VBS_RUN_CAP];
-    __shared__ u64 sbits[STRIPW];
-    __shared__ u32 swb[STRIPW];
+    __shared__ u32 parent[VBS_RUN_CAP];                // union-find parents; later [m=1] the moment accumulators
+    __shared__ u64 bnd_w[16][64];                      // last row of every strip: words,
+    __shared__ u32 bnd_base[16][64], bnd_cin[16][64];  //   first-node indices, entering nodes
+    __shared__ u32 wtot[16], wfirst[16];               // runs per strip, node index of the strip's first run
+    __shared__ u32 acc_cnt[1024];                      // band: pixel counts;  open: first pixel (anchor) per component
+    __shared__ u64 acc_sx[1024], acc_sy[1024];
     __shared__ u32 tmp[32];
-    __shared__ u32 acc_cnt[1024];
-    __shared__ u64 acc_sx[1024];
-    __shared__ u64 acc_sy[1024];
     __shared__ u8 lut[256];
     __shared__ int euler4;                             // 4 x Euler number of the opened mask (bit quads)
     const int n = blockIdx.x, m = blockIdx.y;          // m = 0 band (4-conn), 1 open (8-conn)
-    const int tid = threadIdx.x, nthr = blockDim.x;
+    const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int NW = H * WW;
     const u64* bits = (m == 0 ? band_bits : open_bits) + (int64_t)n * NW;
     u32* wbase = wbase_all + ((int64_t)n * 2 + m) * NW;
@@ -290,90 +429,68 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     if (tid < 256) lut[tid] = lut_g[tid];
     if (tid == 0) euler4 = 0;
     for (int i = tid; i < 1024; i += nthr) { acc_cnt[i] = 0; acc_sx[i] = 0; acc_sy[i] = 0; }
+    const int R = (H + 15) / 16;
+    const int ya = min(H, wave * R), yb = min(H, ya + R);                  // this wave's rows
+    const bool act = lane < WW;
 
-    // ---- A + C, streamed over strips of rows staged in LDS ------------------------------------------
-    // Every strip: stage its bit rows in LDS (slot 0 keeps the previous strip's last row), enumerate the
-    // runs (= union-find nodes) in raster order, then union each row's runs with the row above.  All the
-    // pointer chasing (run starts, node indices) is LDS-resident; global memory sees one coalesced read
-    // of the bits (prefetched one strip ahead in registers) and the wbase / node_pos writes.
-    const int S = min(64, STRIPW / WW - 1);             // rows per strip, (S + 1) * WW <= STRIPW
-    const int j = tid % WW, rloc = 1 + tid / WW;        // this thread's word inside the strip (slots 1..S)
-    for (int i = tid; i < WW; i += nthr) { sbits[i] = 0; swb[i] = 0; }
-    u32 nruns = 0;
-    u64 cur = (tid < min(S, H) * WW) ? bits[tid] : 0ull;
-    for (int s0 = 0; s0 < H; s0 += S) {
-        const int rows = min(S, H - s0), nwords = rows * WW;
-        const bool live = tid < nwords;
-        if (live) sbits[WW + tid] = cur;
-        const int nrows_next = min(S, H - s0 - S);
-        u64 nxt = (s0 + S < H && tid < nrows_next * WW) ? bits[(int64_t)(s0 + S) * WW + tid] : 0ull;
-        __syncthreads();
-        u64 st = 0;
-        if (live) {
-            u64 prev = (j > 0) ? (sbits[WW + tid - 1] >> 63) : 0ull;
-            st = cur & ~((cur << 1) | prev);
+    // ---- 1: runs per strip -> first node index of every strip ---------------------------------------
+    {
+        u32 c = 0;
+        PF_INIT(bits, ya, yb)
+        for (int y = ya; y < yb; ++y) {
+            u64 w; PF_NEXT(bits, y, yb, w)
+            c += __popcll(w & ~((w << 1) | (u64)(dpp_shr1((u32)(w >> 32)) >> 31)));
         }
-        u32 total;
-        u32 base = nruns + block_exclusive_scan(__popcll(st), tmp, &total);
-        nruns += total;
-        if (nruns > VBS_RUN_CAP) {                      // block-uniform
-            if (tid == 0) { ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
-            return;
-        }
-        const int y = s0 + rloc - 1;
-        if (live) {
-            swb[WW + tid] = base;
-            wbase[(int64_t)s0 * WW + tid] = base;
-            u32 nd = base;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
+        if (lane == 0) wtot[wave] = c;
+    }
+    __syncthreads();
+    u32 nruns = 0, mybase = 0;
+    for (int w = 0; w < 16; ++w) { if (w == wave) mybase = nruns; nruns += wtot[w]; }
+    if (lane == 0) wfirst[wave] = mybase;
+    if (nruns > VBS_RUN_CAP) {                          // block-uniform
+        if (tid == 0) { ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
+        return;
+    }
+
+    // ---- 2: label the strip, row by row ---------------------------------------------------------------
+    RowState first_row = {0, 0, 0, NONE32};
+    {
+        u32 rowbase = mybase;
+        RowState prev = {0, 0, 0, NONE32};
+        PF_INIT(bits, ya, yb)
+        for (int y = ya; y < yb; ++y) {
+            u64 w; PF_NEXT(bits, y, yb, w)
+            RowState cur = make_row_state(w, rowbase);
+            if (act) wbase[(int64_t)y * WW + lane] = cur.base;
+            u64 st = cur.st;
+            u32 nd = cur.base;
             while (st) {
                 int k = __ffsll((long long)st) - 1;
                 st &= st - 1;
                 parent[nd] = nd;
-                node_pos[nd] = (u32)(y * W + 64 * j + k);
+                node_pos[nd] = (u32)(y * W + 64 * lane + k);
                 ++nd;
             }
+            if (y == ya) first_row = cur;
+            else if (!(stop & 32)) link_rows(parent, cur, prev, m);
+            prev = cur;
         }
-        __syncthreads();
-        if (live && cur && (s0 + rloc - 1) > 0) {
-            const u64* rowA = sbits + (rloc - 1) * WW;
-            const u64* rowB = sbits + rloc * WW;
-            const u32* wbA = swb + (rloc - 1) * WW;
-            const u32* wbB = swb + rloc * WW;
-            const u64 B = cur, A = rowA[j];
-            const u64 Aprev = (j > 0) ? rowA[j - 1] : 0ull, Anext = (j + 1 < WW) ? rowA[j + 1] : 0ull;
-            u64 adj = A;
-            if (m == 1) adj |= (A << 1) | (A >> 1) | (Aprev >> 63) | (Anext << 63);
-            u64 mB = (B & adj) ? B : 0ull;
-            while (mB) {                               // groups of consecutive 1s of B inside this word
-                u64 lowbit = mB & (~mB + 1ull);
-                u64 t = mB + lowbit;
-                u64 g = mB & ~t;
-                mB &= t;
-                if (!(g & adj)) continue;
-                int k0 = __ffsll((long long)g) - 1;
-                u32 nb_ = node_of(rowB, wbB, j, k0);
-                u64 rm = g;
-                if (m == 1) rm |= (g << 1) | (g >> 1);
-                u64 mA = A & rm;
-                while (mA) {
-                    u64 lb = mA & (~mA + 1ull);
-                    u64 t2 = mA + lb;
-                    u64 ga = mA & ~t2;
-                    mA &= t2;
-                    uf_union(parent, node_of(rowA, wbA, j, __ffsll((long long)ga) - 1), nb_);
-                }
-                if (m == 1) {
-                    if ((g & 1ull) && (Aprev >> 63)) uf_union(parent, node_of(rowA, wbA, j - 1, 63), nb_);
-                    if ((g >> 63) && (Anext & 1ull)) uf_union(parent, node_of(rowA, wbA, j + 1, 0), nb_);
-                }
-            }
-        }
-        __syncthreads();
-        if (live && rloc == rows) { sbits[j] = cur; swb[j] = base; }   // last row -> slot 0 of the next strip
-        cur = nxt;
+        bnd_w[wave][lane] = prev.w; bnd_base[wave][lane] = prev.base; bnd_cin[wave][lane] = prev.cin;
     }
     __syncthreads();
-    if (stop == 2) return;
+    // ---- 3: link every strip's first row with the last row of the strip above --------------------------
+    if (wave > 0 && ya < yb && !(stop & 32)) {
+        RowState prev;
+        prev.w = bnd_w[wave - 1][lane];
+        prev.base = bnd_base[wave - 1][lane];
+        prev.cin = bnd_cin[wave - 1][lane];
+        prev.st = prev.w & ~((prev.w << 1) | (u64)(dpp_shr1((u32)(prev.w >> 32)) >> 31));
+        link_rows(parent, first_row, prev, m);
+    }
+    __syncthreads();
+    if ((stop & 15) == 2) return;
 
     // ---- D: flatten -------------------------------------------------------------------------------
     for (u32 i = tid; i < nruns; i += nthr) {
@@ -381,7 +498,6 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         if (r != i) parent[i] = r;                     // overwrite another thread's final root
     }
     __syncthreads();
-    if (stop == 3) return;
 
     // ---- E: component ids = rank of the root in raster order ---------------------------------------
     const int chunk2 = (nruns + nthr - 1) / nthr;
@@ -390,45 +506,60 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     for (u32 i = r0; i < r1; ++i) nroot += (parent[i] == i);
     u32 ncomp;
     u32 cbase = block_exclusive_scan(nroot, tmp, &ncomp);
-    if (ncomp > (u32)maxm) {
+    if (ncomp > (u32)maxm || (m == 1 && ncomp * NMOM * 8u > sizeof(parent) / 2)) {
         if (tid == 0) { ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
         return;
     }
     u32* first = (m == 0 ? band_first : area_first) + (int64_t)n * maxm;
     for (u32 i = r0; i < r1; ++i) {
         if (parent[i] == i) {
-            first[cbase] = node_pos[i];
-            if (m == 1) acc_cnt[cbase] = node_pos[i];  // LDS copy of the anchor for phase F
+            const u32 pos = node_pos[i];                // first pixel of the component = start of its root run
+            first[cbase] = pos;
+            if (m == 1) acc_cnt[cbase] = pos;          // LDS copy of the anchor for phase F
             parent[i] = i | ((cbase + 1) << 16);       // root: id in the high half
             ++cbase;
         }
     }
     __syncthreads();
-    for (u32 i = tid; i < nruns; i += nthr) {
-        u32 p = parent[i];
-        u32 root = p & 0xFFFFu;
-        u32 cid = (parent[root] >> 16) - 1;
-        node_comp[i] = cid;
+    // component id of every node: to global (k_finalize's polygon test) and, as uint16, into the lower half of
+    // the parent table (read the ids into registers first: the uint16 table overwrites the parents in place)
+    constexpr int PER = (VBS_RUN_CAP + 1023) / 1024;
+    unsigned short cids[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        u32 i = tid + k * 1024;
+        u32 cid = 0;
+        if (i < nruns) {
+            u32 root = parent[i] & 0xFFFFu;
+            cid = (parent[root] >> 16) - 1;
+            node_comp[i] = cid;
+        }
+        cids[k] = (unsigned short)cid;
     }
     if (tid == 0) ncomp_all[n * 2 + m] = ncomp;
-    __syncthreads();                                   // node_comp visible to this workgroup below
-    if (stop == 4) return;
+    __syncthreads();
+    unsigned short* cid16 = reinterpret_cast<unsigned short*>(parent);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        u32 i = tid + k * 1024;
+        if (i < nruns) cid16[i] = cids[k];
+    }
+    u64* acc = reinterpret_cast<u64*>(parent) + VBS_RUN_CAP / 4;           // upper half: [ncomp][15] moments (m = 1)
+    if (m == 1) for (u32 c = tid; c < ncomp * NMOM; c += nthr) acc[c] = 0;
+    __syncthreads();
+    if ((stop & 15) == 4) return;
 
-    // ---- F: per-component sums ----------------------------------------------------------------------
-    // Thread -> (word column j, block of consecutive rows): consecutive words of a thread mostly belong
-    // to the same component, so sums are kept in registers and flushed (LDS atomics) on a change of id.
-    const int colthreads = nthr / WW;
-    const int rows_per = (H + colthreads - 1) / colthreads;
-    const int cj = tid % WW, rb = tid / WW;
-    const int fy0 = rb < colthreads ? rb * rows_per : H, fy1 = min(H, fy0 + rows_per);
+    // ---- F: per-component sums, same walk: wave = strip, lane = word column, sums kept in registers and
+    //         flushed with LDS atomics when the component under the lane changes -------------------------------
     if (m == 0) {
-        u32 cur = 0xFFFFFFFFu, c_cnt = 0;
+        u32 rowbase = wfirst[wave];
+        u32 curc = NONE32, c_cnt = 0;
         u64 c_sx = 0, c_sy = 0;
-        for (int y = fy0; y < fy1; ++y) {
-            const u64* row = bits + (int64_t)y * WW;
-            u64 w = row[cj];
-            if (!w) continue;
-            const u32* wb = wbase + (int64_t)y * WW;
+        PF_INIT(bits, ya, yb)
+        for (int y = ya; y < yb; ++y) {
+            u64 wv; PF_NEXT(bits, y, yb, wv)
+            RowState cur = make_row_state(wv, rowbase);
+            u64 w = wv;
             while (w) {
                 u64 lowbit = w & (~w + 1ull);
                 u64 t = w + lowbit;
@@ -436,18 +567,18 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                 w &= t;
                 int k0 = __ffsll((long long)g) - 1;
                 u32 len = __popcll(g);
-                u32 cid = node_comp[node_of(row, wb, cj, k0)];
-                if (cid != cur) {
-                    if (c_cnt) { atomicAdd(&acc_cnt[cur], c_cnt); atomicAdd(&acc_sx[cur], c_sx); atomicAdd(&acc_sy[cur], c_sy); }
-                    cur = cid; c_cnt = 0; c_sx = 0; c_sy = 0;
+                u32 cid = cid16[node_in_row(cur, k0)];
+                if (cid != curc) {
+                    if (c_cnt) { atomicAdd(&acc_cnt[curc], c_cnt); atomicAdd(&acc_sx[curc], c_sx); atomicAdd(&acc_sy[curc], c_sy); }
+                    curc = cid; c_cnt = 0; c_sx = 0; c_sy = 0;
                 }
-                u64 x0 = 64 * cj + k0;
+                u64 x0 = 64 * lane + k0;
                 c_cnt += len;
                 c_sx += (u64)len * x0 + (u64)len * (len - 1) / 2;
                 c_sy += (u64)len * (u64)y;
             }
         }
-        if (c_cnt) { atomicAdd(&acc_cnt[cur], c_cnt); atomicAdd(&acc_sx[cur], c_sx); atomicAdd(&acc_sy[cur], c_sy); }
+        if (c_cnt) { atomicAdd(&acc_cnt[curc], c_cnt); atomicAdd(&acc_sx[curc], c_sx); atomicAdd(&acc_sy[curc], c_sy); }
         __syncthreads();
         u64* bs = band_sums + (int64_t)n * maxm * 4;
         for (u32 c = tid; c < ncomp; c += nthr) {
@@ -456,105 +587,98 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
             bs[c * 4 + 2] = acc_sy[c];
         }
     } else {
-        // the union-find table is no longer needed (ids are in node_comp): reuse its LDS as the
-        // [ncomp][15] int64 moment accumulators (1024 x 15 x 8 B == sizeof(parent))
-        u64* acc = reinterpret_cast<u64*>(parent);
-        for (u32 c = tid; c < ncomp * NMOM; c += nthr) acc[c] = 0;
-        __syncthreads();
-        u32 cur = 0xFFFFFFFFu;
-        int ax = 0, ay = 0;
+        u32 rowbase = wfirst[wave];
+        u32 curc = NONE32;
+        int ax = 0, ay = 0, e4 = 0;
         bool any = false;
         i64 s[NMOM];
 #pragma unroll
         for (int q = 0; q < NMOM; ++q) s[q] = 0;
-        // Euler number by bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of
-        // the zero-padded image; window (x, y) = pixels (x..x+1, y..y+1).  holes = components - E, reported so
-        // that a frame whose RETR_EXTERNAL contours could differ from this kernel's is never silent.
-        int e4 = 0;
-        for (int y = (fy0 == 0 ? -1 : fy0); y < fy1; ++y) {
-            u64 a = 0, an = 0, b = 0, bn = 0;
-            if (y >= 0) { a = bits[(int64_t)y * WW + cj]; an = (cj + 1 < WW) ? bits[(int64_t)y * WW + cj + 1] : 0ull; }
-            if (y + 1 < H) { b = bits[(int64_t)(y + 1) * WW + cj]; bn = (cj + 1 < WW) ? bits[(int64_t)(y + 1) * WW + cj + 1] : 0ull; }
-            if (!(a | b | (an & 1ull) | (bn & 1ull))) continue;
-            u64 a1 = (a >> 1) | (an << 63), b1 = (b >> 1) | (bn << 63);
-            u64 x2 = (a ^ a1) ^ (b ^ b1);                                   // odd count: 1 or 3
-            u64 pairs = (a & a1) | (a & b) | (a & b1) | (a1 & b) | (a1 & b1) | (b & b1);   // count >= 2
-            u64 q1 = x2 & ~pairs, q3 = x2 & pairs;
-            u64 qd = (a & b1 & ~a1 & ~b) | (a1 & b & ~a & ~b1);
-            e4 += __popcll(q1) - __popcll(q3) - 2 * __popcll(qd);
-            if (cj == 0) e4 += (int)((a ^ b) & 1ull);                      // window x = -1: only (0,y), (0,y+1)
-        }
-        if (e4) atomicAdd(&euler4, e4);
-        for (int y = fy0; y < fy1; ++y) {
-            const u64* row = bits + (int64_t)y * WW;
-            u64 w = row[cj];
-            if (!w) continue;
-            const int j = cj;
-            const u32* wb = wbase + (int64_t)y * WW;
-            u64 wp = j > 0 ? row[j - 1] : 0ull, wn = (j + 1 < WW) ? row[j + 1] : 0ull;
-            u64 up = 0, upp = 0, upn = 0, dn = 0, dnp = 0, dnn = 0;
-            if (y > 0) {
-                const u64* r2 = row - WW;
-                up = r2[j]; upp = j > 0 ? r2[j - 1] : 0ull; upn = (j + 1 < WW) ? r2[j + 1] : 0ull;
-            }
-            if (y + 1 < H) {
-                const u64* r2 = row + WW;
-                dn = r2[j]; dnp = j > 0 ? r2[j - 1] : 0ull; dnn = (j + 1 < WW) ? r2[j + 1] : 0ull;
-            }
-            u64 E = (w >> 1) | (wn << 63), Wd = (w << 1) | (wp >> 63);
-            u64 NE = (up >> 1) | (upn << 63), NWd = (up << 1) | (upp >> 63);
-            u64 SE = (dn >> 1) | (dnn << 63), SW = (dn << 1) | (dnp >> 63);
-            u64 border = w & ~(up & dn & E & Wd);
-            u64 rest = w;
-            while (rest) {                              // one group (= part of one run) at a time
-                u64 lowbit = rest & (~rest + 1ull);
-                u64 t = rest + lowbit;
-                u64 g = rest & ~t;
-                rest &= t;
-                u64 bg = border & g;
-                if (!bg) continue;
-                int k0 = __ffsll((long long)g) - 1;
-                u32 cid = node_comp[node_of(row, wb, j, k0)];
-                if (cid != cur) {
-                    if (any) {
+        // three-row window in registers: up / w / dn (rows y-1, y, y+1), zero outside the image
+        u64 up = (act && ya > 0) ? bits[(int64_t)(ya - 1) * WW + lane] : 0ull;
+        u64 wv = (act && ya < yb) ? bits[(int64_t)ya * WW + lane] : 0ull;
+        PF_INIT(bits, ya + 1, H)                        // the ring runs one row ahead: it delivers row y+1
+        // Euler number by bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the
+        // zero-padded image; window (x, y) = pixels (x..x+1, y..y+1).  The wave counts the windows whose top row is
+        // y = ya-1 (strip 0 only: the padding row) .. yb-1.  holes = components - E.
+        for (int y = ya; y < yb; ++y) {
+            u64 dn; PF_NEXT(bits, y + 1, H, dn)
+            RowState cur = make_row_state(wv, rowbase);
+            const u64 wn_ = dpp_shl1(wv), wp_ = dpp_shr1(wv), un_ = dpp_shl1(up), up_ = dpp_shr1(up),
+                      dn_ = dpp_shl1(dn), dp_ = dpp_shr1(dn);
+            // quads with top row y (and, once per frame, with top row -1)
 #pragma unroll
-                        for (int q = 0; q < NMOM; ++q)
-                            if (s[q]) atomicAdd(&acc[cur * NMOM + q], (u64)s[q]);
+            for (int q = 0; q < 2; ++q) {
+                if (q == 1 && y != 0) continue;
+                const u64 a = q ? 0ull : wv, an = q ? 0ull : wn_, b = q ? wv : dn, bn = q ? wn_ : dn_;
+                if (a | b | (an & 1ull) | (bn & 1ull)) {
+                    u64 a1 = (a >> 1) | (an << 63), b1 = (b >> 1) | (bn << 63);
+                    u64 x2 = (a ^ a1) ^ (b ^ b1);
+                    u64 pairs = (a & a1) | (a & b) | (a & b1) | (a1 & b) | (a1 & b1) | (b & b1);
+                    u64 qd = (a & b1 & ~a1 & ~b) | (a1 & b & ~a & ~b1);
+                    e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
+                    if (lane == 0) e4 += (int)((a ^ b) & 1ull);           // window x = -1: only (0,y), (0,y+1)
+                }
+            }
+            const u64 w = wv;
+            if (w) {
+                const u64 E = (w >> 1) | (wn_ << 63), Wd = (w << 1) | (wp_ >> 63);
+                const u64 NE = (up >> 1) | (un_ << 63), NWd = (up << 1) | (up_ >> 63);
+                const u64 SE = (dn >> 1) | (dn_ << 63), SW = (dn << 1) | (dp_ >> 63);
+                const u64 border = w & ~(up & dn & E & Wd);
+                u64 rest = w;
+                while (rest) {                          // one group (= part of one run) at a time
+                    u64 lowbit = rest & (~rest + 1ull);
+                    u64 t = rest + lowbit;
+                    u64 g = rest & ~t;
+                    rest &= t;
+                    u64 bg = border & g;
+                    if (!bg) continue;
+                    u32 cid = cid16[node_in_row(cur, __ffsll((long long)g) - 1)];
+                    if (cid != curc) {
+                        if (any) {
 #pragma unroll
-                        for (int q = 0; q < NMOM; ++q) s[q] = 0;
-                        any = false;
+                            for (int q = 0; q < NMOM; ++q)
+                                if (s[q]) atomicAdd(&acc[curc * NMOM + q], (u64)s[q]);
+#pragma unroll
+                            for (int q = 0; q < NMOM; ++q) s[q] = 0;
+                            any = false;
+                        }
+                        curc = cid;
+                        u32 fp = acc_cnt[cid];
+                        ax = fp % W; ay = fp / W;
                     }
-                    cur = cid;
-                    u32 fp = acc_cnt[cid];
-                    ax = fp % W; ay = fp / W;
-                }
-                while (bg) {
-                    int k = __ffsll((long long)bg) - 1;
-                    bg &= bg - 1;
-                    u32 pat = (u32)((E >> k) & 1ull) | ((u32)((NE >> k) & 1ull) << 1) |
-                              ((u32)((up >> k) & 1ull) << 2) | ((u32)((NWd >> k) & 1ull) << 3) |
-                              ((u32)((Wd >> k) & 1ull) << 4) | ((u32)((SW >> k) & 1ull) << 5) |
-                              ((u32)((dn >> k) & 1ull) << 6) | ((u32)((SE >> k) & 1ull) << 7);
-                    i64 mult = lut[pat];
-                    if (!mult) continue;
-                    any = true;
-                    i64 dx = 64 * j + k - ax, dy = y - ay;
-                    i64 x2 = dx * dx, y2 = dy * dy;
-                    s[0] += mult;
-                    s[1] += mult * dx;            s[2] += mult * dy;
-                    s[3] += mult * x2;            s[4] += mult * dx * dy;       s[5] += mult * y2;
-                    s[6] += mult * x2 * dx;       s[7] += mult * x2 * dy;       s[8] += mult * dx * y2;
-                    s[9] += mult * y2 * dy;
-                    s[10] += mult * x2 * x2;      s[11] += mult * x2 * dx * dy; s[12] += mult * x2 * y2;
-                    s[13] += mult * dx * dy * y2; s[14] += mult * y2 * y2;
+                    while (bg) {
+                        int k = __ffsll((long long)bg) - 1;
+                        bg &= bg - 1;
+                        u32 pat = (u32)((E >> k) & 1ull) | ((u32)((NE >> k) & 1ull) << 1) |
+                                  ((u32)((up >> k) & 1ull) << 2) | ((u32)((NWd >> k) & 1ull) << 3) |
+                                  ((u32)((Wd >> k) & 1ull) << 4) | ((u32)((SW >> k) & 1ull) << 5) |
+                                  ((u32)((dn >> k) & 1ull) << 6) | ((u32)((SE >> k) & 1ull) << 7);
+                        i64 mult = lut[pat];
+                        if (!mult) continue;
+                        any = true;
+                        i64 dx = 64 * lane + k - ax, dy = y - ay;
+                        i64 x2 = dx * dx, y2 = dy * dy;
+                        s[0] += mult;
+                        s[1] += mult * dx;            s[2] += mult * dy;
+                        s[3] += mult * x2;            s[4] += mult * dx * dy;       s[5] += mult * y2;
+                        s[6] += mult * x2 * dx;       s[7] += mult * x2 * dy;       s[8] += mult * dx * y2;
+                        s[9] += mult * y2 * dy;
+                        s[10] += mult * x2 * x2;      s[11] += mult * x2 * dx * dy; s[12] += mult * x2 * y2;
+                        s[13] += mult * dx * dy * y2; s[14] += mult * y2 * y2;
+                    }
                 }
             }
+            up = wv;
+            wv = dn;
         }
         if (any) {
 #pragma unroll
             for (int q = 0; q < NMOM; ++q)
-                if (s[q]) atomicAdd(&acc[cur * NMOM + q], (u64)s[q]);
+                if (s[q]) atomicAdd(&acc[curc * NMOM + q], (u64)s[q]);
         }
+        if (e4) atomicAdd(&euler4, e4);
         __syncthreads();
         i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
         for (u32 c = tid; c < ncomp * NMOM; c += nthr) as[(c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
