@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=8)
     ap.add_argument("--cpu-frames-per-worker", type=int, default=3)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) | gloo (rehearsal of N>1 on one GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -107,11 +108,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()       # rehearsal: ranks may share a device
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "gloo":
+            td.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     spec = S.config2()
     H, W, M = spec.height, spec.width, spec.n_markers
@@ -150,7 +156,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
         td.all_reduce(t, op=td.ReduceOp.MAX)
         elapsed = float(t.item())
     table, disp, counts = out

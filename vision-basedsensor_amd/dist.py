@@ -31,6 +31,8 @@ def broadcast_reference(ids, ref_xy, device, src: int = 0):
     rank, ws = world()
     if ws == 1:
         return np.asarray(ids), np.asarray(ref_xy)
+    if td.get_backend() == "gloo":
+        device = torch.device("cpu")
     m = torch.zeros(1, dtype=torch.int64, device=device)
     if rank == src:
         m[0] = len(ids)
@@ -57,8 +59,14 @@ def gather_tables(local: torch.Tensor, n_total: int) -> torch.Tensor:
     if local.shape[0] < nmax:
         pad = torch.zeros((nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
         pad[:local.shape[0]] = local
-    out = torch.empty((ws * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
-    td.all_gather_into_tensor(out, pad.contiguous())
+    if td.get_backend() == "gloo" and local.is_cuda:
+        # rehearsal backend (several ranks on one GPU / CPU tests): gloo gathers host tensors
+        parts = [torch.empty(pad.shape, dtype=pad.dtype) for _ in range(ws)]
+        td.all_gather(parts, pad.cpu().contiguous())
+        out = torch.cat(parts, dim=0).to(local.device)
+    else:
+        out = torch.empty((ws * nmax,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        td.all_gather_into_tensor(out, pad.contiguous())
     if all(b - a == nmax for a, b in per):
         return out
     return torch.cat([out[r * nmax:r * nmax + (b - a)] for r, (a, b) in enumerate(per)], dim=0)
