@@ -74,6 +74,17 @@ int vbs_contour_lut(uint8_t out[256]);
 int vbs_gaussian_taps_q8(int ksize, double sigma, int32_t* out);
 int vbs_ncc_template(int l, double sigma, double* g, double* stats);
 
+/* MarkerTracker._undistort_frame (marker_detection.py:93-109), optional (`calibration_params` in the config):
+ * getOptimalNewCameraMatrix(K, D, (w,h), 0) + initUndistortRectifyMap(CV_16SC2) are evaluated ONCE here (the
+ * reference rebuilds them per frame); afterwards vbs_find_markers / vbs_track_to_3d / vbs_ncc_map first remap every
+ * frame (INTER_LINEAR, fixed point, constant border 0) exactly as `_preprocess_frame` does (:88-89).
+ * K9 row-major float64 camera matrix, dist = up to 5 coefficients k1 k2 p1 p2 k3; newK9 (may be NULL) receives the
+ * new camera matrix.  K9 == NULL switches undistortion off again. */
+int vbs_set_undistort(vbs_handle* h, const double* K9, const double* dist, int ndist, double* newK9, void* stream);
+/* The remap alone: frames [dev] uint8 (same addressing as below) -> out [dev] uint8 [n,h,w,channels] dense. */
+int vbs_undistort_frames(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
+                         int64_t stride_row, uint8_t* out, void* stream);
+
 /* MarkerTracker._find_markers (marker_detection.py:112-135): BGR2GRAY -> 2x GaussianBlur -> uint8
  * difference +15 (mod 256) -> inRange -> area_mask {0,255}; NCC with the Gaussian template
  * (_gkern :138, _normxcorr2 :146) -> mask {0,1} = ncc > 0.1.

@@ -640,7 +640,7 @@ def track_markers(first_frame_markers: Dict[Tuple[int, int], dict], markers: Lis
 
 def process_frames(frames: Sequence[np.ndarray], crop_ratios=(0, 0, 0, 0), num_layers: int = 5,
                    min_dist: float = 20, id_mode: str = "as_written", kmeans: str = "optimal",
-                   ncc: str = "fft"):
+                   ncc: str = "fft", calibration: Optional[dict] = None):
     """`MarkerTracker.process` (`:429-462`) over in-memory frames -> (rows, first_frame_markers)."""
     ref: Dict[Tuple[int, int], dict] = {}
     rows: List[dict] = []
@@ -648,6 +648,9 @@ def process_frames(frames: Sequence[np.ndarray], crop_ratios=(0, 0, 0, 0), num_l
         H, W = frame.shape[:2]
         l, r, t, b = crop_box(W, H, crop_ratios)
         cropped = frame[t:b, l:r]
+        if calibration is not None:                    # `_preprocess_frame` :88-89
+            cropped = undistort_frame(cropped, np.asarray(calibration["camera_matrix"], dtype=np.float64),
+                                      np.asarray(calibration["dist_coeffs"], dtype=np.float64))
         mask, area = find_markers(cropped, ncc=ncc)
         markers = marker_center(mask, area)
         if fc == 0:
@@ -763,3 +766,140 @@ def fit_plane(X, Y, Z) -> Tuple[float, float, float, float]:
     coeff, *_ = np.linalg.lstsq(A, Z, rcond=None)
     a, b, c = coeff
     return float(a), float(b), float(c), float(np.degrees(np.arctan(np.sqrt(a * a + b * b))))
+
+
+# ------------------------------------------------------------------------------------------------
+# a2 / f3  frame undistortion                                      marker_detection.py:93-109 (cv2)
+# ------------------------------------------------------------------------------------------------
+INTER_BITS = 5
+INTER_TAB_SIZE = 1 << INTER_BITS
+INTER_REMAP_COEF_BITS = 15
+INTER_REMAP_COEF_SCALE = 1 << INTER_REMAP_COEF_BITS
+
+
+def _undistort_points_norm(pts: np.ndarray, K: np.ndarray, dist: np.ndarray) -> np.ndarray:
+    """`cvUndistortPoints` to NORMALISED coordinates (no re-projection), 5 iterations."""
+    k = np.zeros(12)
+    d = np.asarray(dist, dtype=np.float64).ravel()
+    k[:d.size] = d
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    x0 = (pts[:, 0] - cx) / fx
+    y0 = (pts[:, 1] - cy) / fy
+    x, y = x0.copy(), y0.copy()
+    for _ in range(5):
+        r2 = x * x + y * y
+        icd = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)
+        dxx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x)
+        dyy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
+        x = (x0 - dxx) * icd
+        y = (y0 - dyy) * icd
+    return np.stack([x, y], axis=1)
+
+
+def get_optimal_new_camera_matrix_alpha0(K, dist, size: Tuple[int, int]) -> np.ndarray:
+    """`cv2.getOptimalNewCameraMatrix(K, D, (w,h), 0, (w,h))[0]` (`:101-103`)  [OpenCV-knowledge].
+    A 9x9 grid over the image is undistorted to normalised coordinates; the INNER rectangle (largest
+    axis-aligned rectangle inside the undistorted border) is scaled to fill the new image."""
+    w, h = size
+    K = np.asarray(K, dtype=np.float64)
+    N = 9
+    pts = np.array([[x * (w - 1) / (N - 1), y * (h - 1) / (N - 1)] for y in range(N) for x in range(N)], dtype=np.float64)
+    # cvUndistortPoints works on float32 (CV_32FC2) points in icvGetRectangles
+    p = _undistort_points_norm(pts.astype(np.float32).astype(np.float64), K, dist).astype(np.float32).astype(np.float64)
+    p = p.reshape(N, N, 2)
+    i_x0 = np.max(p[:, 0, 0]);  i_x1 = np.min(p[:, N - 1, 0])
+    i_y0 = np.max(p[0, :, 1]);  i_y1 = np.min(p[N - 1, :, 1])
+    # alpha = 0: inner rectangle only
+    fx0 = (w - 1) / (i_x1 - i_x0)
+    fy0 = (h - 1) / (i_y1 - i_y0)
+    cx0 = -fx0 * i_x0
+    cy0 = -fy0 * i_y0
+    M = np.eye(3)
+    M[0, 0], M[1, 1], M[0, 2], M[1, 2] = fx0, fy0, cx0, cy0
+    return M
+
+
+def init_undistort_rectify_map_16sc2(K, dist, newK, size: Tuple[int, int]):
+    """`cv2.initUndistortRectifyMap(K, D, None, newK, (w,h), CV_16SC2)` (`:106-108`): for every destination
+    pixel the distorted source position in 1/32 px fixed point -> (map1 int16 [h,w,2], map2 uint16 [h,w])."""
+    w, h = size
+    K = np.asarray(K, dtype=np.float64)
+    newK = np.asarray(newK, dtype=np.float64)
+    k = np.zeros(12)
+    d = np.asarray(dist, dtype=np.float64).ravel()
+    k[:d.size] = d
+    ir = np.linalg.inv(newK)
+    jj, ii = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    X = jj * ir[0, 0] + ii * ir[0, 1] + ir[0, 2]
+    Y = jj * ir[1, 0] + ii * ir[1, 1] + ir[1, 2]
+    Wc = jj * ir[2, 0] + ii * ir[2, 1] + ir[2, 2]
+    x, y = X / Wc, Y / Wc
+    x2, y2 = x * x, y * y
+    r2 = x2 + y2
+    _2xy = 2 * x * y
+    kr = (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2) / (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2)
+    xd = x * kr + k[2] * _2xy + k[3] * (r2 + 2 * x2)
+    yd = y * kr + k[2] * (r2 + 2 * y2) + k[3] * _2xy
+    u = K[0, 0] * xd + K[0, 2]
+    v = K[1, 1] * yd + K[1, 2]
+    iu = np.clip(np.rint(u * INTER_TAB_SIZE), -2**31, 2**31 - 1).astype(np.int64)
+    iv = np.clip(np.rint(v * INTER_TAB_SIZE), -2**31, 2**31 - 1).astype(np.int64)
+    map1 = np.stack([np.clip(iu >> INTER_BITS, -32768, 32767), np.clip(iv >> INTER_BITS, -32768, 32767)],
+                    axis=-1).astype(np.int16)
+    map2 = ((iv & (INTER_TAB_SIZE - 1)) * INTER_TAB_SIZE + (iu & (INTER_TAB_SIZE - 1))).astype(np.uint16)
+    return map1, map2
+
+
+def bilinear_tab_i16() -> np.ndarray:
+    """OpenCV's fixed-point bilinear weights: [1024, 4] int (w00, w01, w10, w11), each row sums to 2^15.
+    Built like `initInterTab2D(INTER_LINEAR, fixpt=true)`: float32 products, saturate_cast<short>(v * 2^15),
+    then the rounding residue is pushed onto the largest (or smallest) weight."""
+    tab1 = np.array([[1.0 - i / INTER_TAB_SIZE, i / INTER_TAB_SIZE] for i in range(INTER_TAB_SIZE)], dtype=np.float32)
+    out = np.zeros((INTER_TAB_SIZE * INTER_TAB_SIZE, 4), dtype=np.int64)
+    for i in range(INTER_TAB_SIZE):            # y fraction
+        for j in range(INTER_TAB_SIZE):        # x fraction
+            wv = np.array([tab1[i, 0] * tab1[j, 0], tab1[i, 0] * tab1[j, 1], tab1[i, 1] * tab1[j, 0],
+                           tab1[i, 1] * tab1[j, 1]], dtype=np.float32)
+            iw = np.rint(wv.astype(np.float64) * INTER_REMAP_COEF_SCALE).astype(np.int64)
+            isum = int(iw.sum())
+            if isum != INTER_REMAP_COEF_SCALE:
+                diff = isum - INTER_REMAP_COEF_SCALE
+                # ksize = 2: the search window is the whole 2x2 block
+                if diff < 0:
+                    iw[int(np.argmax(iw))] -= diff
+                else:
+                    iw[int(np.argmin(iw))] -= diff
+            out[i * INTER_TAB_SIZE + j] = iw
+    return out
+
+
+def remap_linear_16sc2(img: np.ndarray, map1: np.ndarray, map2: np.ndarray) -> np.ndarray:
+    """`cv2.remap(img, map1, map2, INTER_LINEAR)` on uint8 with BORDER_CONSTANT 0 (`:109`):
+    (sum w_i p_i + 2^14) >> 15 with the fixed-point weights above."""
+    tab = bilinear_tab_i16()
+    h, w = map2.shape
+    H, W = img.shape[:2]
+    src = img.astype(np.int64)
+    if src.ndim == 2:
+        src = src[..., None]
+    sx = map1[..., 0].astype(np.int64)
+    sy = map1[..., 1].astype(np.int64)
+    wts = tab[map2.astype(np.int64)]                      # [h, w, 4]
+
+    def tap(yy, xx):
+        ok = (yy >= 0) & (yy < H) & (xx >= 0) & (xx < W)
+        v = src[np.clip(yy, 0, H - 1), np.clip(xx, 0, W - 1)]
+        return np.where(ok[..., None], v, 0)
+
+    acc = (tap(sy, sx) * wts[..., 0:1] + tap(sy, sx + 1) * wts[..., 1:2] + tap(sy + 1, sx) * wts[..., 2:3] +
+           tap(sy + 1, sx + 1) * wts[..., 3:4])
+    out = ((acc + (1 << (INTER_REMAP_COEF_BITS - 1))) >> INTER_REMAP_COEF_BITS).astype(np.uint8)
+    return out[..., 0] if img.ndim == 2 else out
+
+
+def undistort_frame(frame: np.ndarray, K, dist) -> np.ndarray:
+    """`MarkerTracker._undistort_frame` (`:93-109`)."""
+    h, w = frame.shape[:2]
+    newK = get_optimal_new_camera_matrix_alpha0(K, dist, (w, h))
+    m1, m2 = init_undistort_rectify_map_16sc2(K, dist, newK, (w, h))
+    return remap_linear_16sc2(frame, m1, m2)

@@ -99,6 +99,62 @@ def test_bgr_weights_and_dog_wrap():
     eng.close()
 
 
+@pytest.mark.parametrize("channels", [1, 3])
+def test_undistort_frame_parity(channels):
+    """a2 / f3: new camera matrix, fixed-point rectify map + remap, and detection on the undistorted frame."""
+    spec = S.config1()
+    frames = S.make_frames(spec, [0, 2], seed=6, channels=channels)
+    if channels == 3:
+        frames = frames.copy()
+        frames[..., 0] = np.clip(frames[..., 0].astype(int) + 9, 0, 255)         # B != G != R
+        frames[..., 2] = np.clip(frames[..., 2].astype(int) - 6, 0, 255)
+    K = np.array([[600.0, 0, 318.5], [0, 604.0, 241.25], [0, 0, 1]])
+    D = np.array([-0.25, 0.08, 0.001, -0.0005, 0.01])
+    eng = engine(spec.height, spec.width, max_batch=2)
+    newK = eng.set_undistort(K, D)
+    np.testing.assert_allclose(newK, O.get_optimal_new_camera_matrix_alpha0(K, D, (spec.width, spec.height)),
+                               rtol=1e-12, atol=1e-12)
+    ft = torch.from_numpy(frames).cuda()
+    und = eng.undistort_frames(ft).cpu().numpy()
+    mask, area = eng.find_markers(ft)
+    for i in range(2):
+        want = O.undistort_frame(frames[i], K, D)
+        assert np.array_equal(und[i], want)
+        assert np.abs(want.astype(int) - frames[i].astype(int)).max() > 30        # it really moves pixels
+        om, oa = O.find_markers(want)
+        assert np.array_equal(area[i].cpu().numpy(), oa) and np.array_equal(mask[i].cpu().numpy(), om)
+    eng.set_undistort(None)
+    m2, a2 = eng.find_markers(ft)
+    om, oa = O.find_markers(frames[0])
+    assert np.array_equal(a2[0].cpu().numpy(), oa) and np.array_equal(m2[0].cpu().numpy(), om)
+    eng.close()
+
+
+def test_marker_tracker_with_calibration_params(tmp_path):
+    """`MarkerTracker.process` with `calibration_params` (crop -> undistort -> detect) against the oracle."""
+    import pandas as pd
+    from vbs_amd.marker_detection import MarkerTracker
+    spec = S.config1()
+    frames = S.make_frames(spec, range(3), seed=12, channels=3)
+    np.save(tmp_path / "clip.npy", frames)
+    calib = {"camera_matrix": [[520.0, 0, 280.0], [0, 520.0, 225.0], [0, 0, 1]], "dist_coeffs": [-0.12, 0.03, 0.0008, -0.0006, 0.0]}
+    crop = (1 / 16, 1 / 16, 0, 1 / 16)
+    cfg = {"video_path": str(tmp_path / "clip.npy"), "output_dir": str(tmp_path / "o"), "crop_ratios": crop,
+           "id_mode": "full", "calibration_params": calib}
+    trk = MarkerTracker(cfg)
+    trk.process()
+    df = pd.read_csv(trk.output_csv, float_precision="round_trip")
+    rows, ref = O.process_frames(list(frames), crop_ratios=crop, id_mode="full", calibration=calib)
+    assert list(trk.first_frame_markers.keys()) == list(ref.keys()) and len(df) == len(rows) > 100
+    want = pd.DataFrame(rows)
+    assert (df[["frameno", "row", "col"]].to_numpy() == want[["frameno", "row", "col"]].to_numpy()).all()
+    assert np.array_equal(df["Cx"].to_numpy(), want["Cx"].to_numpy()) and np.array_equal(df["Cy"].to_numpy(), want["Cy"].to_numpy())
+    trk.width, trk.height = spec.width, spec.height
+    pre = trk._preprocess_frame(frames[1])
+    l, r, t, b = O.crop_box(spec.width, spec.height, crop)
+    assert np.array_equal(pre, O.undistort_frame(frames[1][t:b, l:r], np.array(calib["camera_matrix"]), np.array(calib["dist_coeffs"])))
+
+
 def test_ncc_map_matches_fft_reference():
     """a7: the float64 NCC map against the oracle's literal FFT evaluation."""
     spec = S.config2()

@@ -11,7 +11,7 @@ FLAG_TRACKED, FLAG_XYZ = 1, 2
 
 # every symbol include/vbs.h declares (tests check the export list against the header)
 SYMBOLS = ("vbs_create", "vbs_destroy", "vbs_last_error", "vbs_version", "vbs_contour_lut",
-           "vbs_gaussian_taps_q8", "vbs_ncc_template", "vbs_find_markers", "vbs_ncc_map", "vbs_normxcorr2",
+           "vbs_gaussian_taps_q8", "vbs_ncc_template", "vbs_set_undistort", "vbs_undistort_frames", "vbs_find_markers", "vbs_ncc_map", "vbs_normxcorr2",
            "vbs_profile", "vbs_profile_read", "vbs_frame_stats", "vbs_undistort_points", "vbs_calculate_3d", "vbs_marker_center",
            "vbs_track", "vbs_solve3d", "vbs_track_to_3d", "vbs_displacement", "vbs_displacement_range", "vbs_displacement_f64",
            "vbs_plane_fit")
@@ -49,6 +49,8 @@ def lib():
         "vbs_contour_lut": (i32, [vp]),
         "vbs_gaussian_taps_q8": (i32, [i32, f64, vp]),
         "vbs_ncc_template": (i32, [i32, f64, vp, vp]),
+        "vbs_set_undistort": (i32, [vp, vp, vp, i32, vp, vp]),
+        "vbs_undistort_frames": (i32, [vp, vp, i32, i32, i64, i64, vp, vp]),
         "vbs_find_markers": (i32, [vp, vp, i32, i32, i64, i64, vp, vp, vp]),
         "vbs_ncc_map": (i32, [vp, vp, i32, i32, i64, i64, vp, vp]),
         "vbs_normxcorr2": (i32, [vp, vp, i32, vp, vp, vp]),

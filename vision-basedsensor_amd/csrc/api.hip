@@ -182,6 +182,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(ell, B * max_markers * 8); ALLOC(det64, B * max_markers * 6);
     ALLOC(cnt, B);
     ALLOC(lut, 256);
+    ALLOC(umap1, (size_t)height * width * 2); ALLOC(umap2, (size_t)height * width); ALLOC(uwtab, 4096);
 #undef ALLOC
     std::vector<double> rx(width), ry(height);
     for (int x = 0; x < width; ++x) {
@@ -199,6 +200,11 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     HIPCHK(h, hipMemcpy(h->ncc_rx, rx.data(), width * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->ncc_ry, ry.data(), height * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> wt(4096);
+        bilinear_weights_i16(wt.data());
+        HIPCHK(h, hipMemcpy(h->uwtab, wt.data(), 4096 * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     HIPCHK(h, hipDeviceSynchronize());
     return VBS_OK;
 }
@@ -212,7 +218,10 @@ static int check_launch(vbs_handle* h) {
 static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
                        int64_t stride_row, u8* mask_u8, u8* area_u8, double* ncc_out, hipStream_t s) {
     HIPCHK(h, hipMemsetAsync(h->fstat, 0, (size_t)nb * 8 * sizeof(u32), s));
-    if (channels == 1) {
+    if (h->undist) {                                    // marker_detection.py:88-89: undistort, then cvtColor
+        launch_remap(h, frames, nb, channels, stride_n, stride_row, h->gray, 1, s);
+        launch_blur(h, h->gray, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
+    } else if (channels == 1) {
         launch_blur(h, frames, stride_n, stride_row, nb, area_u8, s);
     } else {
         launch_gray(h, frames, nb, channels, stride_n, stride_row, s);
@@ -309,6 +318,35 @@ extern "C" int vbs_profile_read(vbs_handle* h, char* buf, int cap) {
     if ((int)out.size() + 1 > cap) { h->err = "vbs_profile_read: buffer too small"; return VBS_EINVAL; }
     memcpy(buf, out.c_str(), out.size() + 1);
     return VBS_OK;
+}
+
+extern "C" int vbs_set_undistort(vbs_handle* h, const double* K9, const double* dist, int ndist, double* newK9,
+                                 void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!K9) { h->undist = false; return VBS_OK; }      // NULL camera matrix switches undistortion off
+    if (ndist < 0 || ndist > 5 || (ndist && !dist) || !(K9[0] > 0) || !(K9[4] > 0)) {
+        h->err = "vbs_set_undistort: bad argument";
+        return VBS_EINVAL;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    int rc = setup_undistort(h, K9, dist, ndist, (hipStream_t)stream);
+    if (rc != VBS_OK) return rc;
+    h->undist = true;
+    if (newK9) for (int i = 0; i < 9; ++i) newK9[i] = h->newK[i];
+    return check_launch(h);
+}
+
+extern "C" int vbs_undistort_frames(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
+                                    int64_t stride_row, uint8_t* out, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!frames || !out || n < 0 || (channels != 1 && channels != 3) || stride_row < (int64_t)h->W * channels) {
+        h->err = "vbs_undistort_frames: bad argument";
+        return VBS_EINVAL;
+    }
+    if (!h->undist) { h->err = "vbs_undistort_frames: call vbs_set_undistort first"; return VBS_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) launch_remap(h, frames, n, channels, stride_n, stride_row, out, 0, (hipStream_t)stream);
+    return check_launch(h);
 }
 
 extern "C" int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n) {

@@ -77,6 +77,11 @@ struct vbs_handle {
     int32_t* cnt;      // [maxb]
     double* tab64;     // [maxb][mref_cap][10]
     u8* lut;           // [256] contour vertex table
+    short* umap1;      // [H][W][2] int16 undistortion source pixel (CV_16SC2)
+    unsigned short* umap2;   // [H][W] fractional index into the bilinear weight table
+    int* uwtab;        // [1024][4] bilinear weights in 1/32768
+    bool undist = false;     // frame undistortion enabled (vbs_set_undistort)
+    double newK[9];
     int mref_cap;
     std::vector<void*> allocs;
 };
@@ -127,3 +132,8 @@ void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, 
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s);
 void launch_displacement64(const double* table, int n, int m_ref, int warmup, double min_size, double max_disp,
                            double* disp, int* fmin_scratch, hipStream_t s);
+int setup_undistort(vbs_handle* h, const double* K9, const double* dist, int ndist, hipStream_t s);
+void launch_remap(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n, int64_t stride_row,
+                  u8* out, int to_gray, hipStream_t s);
+void bilinear_weights_i16(int32_t* out);
+void optimal_new_camera_matrix_alpha0(const double* K, const double* k, int w, int h, double* newK);

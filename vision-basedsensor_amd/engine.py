@@ -80,6 +80,30 @@ class Engine:
             raise ValueError(f"engine was built for {self.H}x{self.W}, got {tuple(frames.shape[1:3])}")
         return frames, frames.shape[0], ch, frames.stride(0), frames.stride(1)
 
+    # ---- a2 / f3 ----------------------------------------------------------------------------
+    def set_undistort(self, K=None, dist=None):
+        """Enable (K, dist given) or disable (K None) frame undistortion; returns the new camera matrix [3,3]."""
+        if K is None:
+            self._check(self.lib.vbs_set_undistort(self._h, None, None, 0, None, self._stream()), "vbs_set_undistort")
+            return None
+        Kd = np.ascontiguousarray(np.asarray(K, dtype=np.float64).reshape(9))
+        dd = np.ascontiguousarray(np.asarray([] if dist is None else dist, dtype=np.float64).ravel()[:5])
+        newK = np.zeros(9, dtype=np.float64)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_set_undistort(self._h, Kd.ctypes.data_as(C.c_void_p),
+                                                   dd.ctypes.data_as(C.c_void_p) if dd.size else None, int(dd.size),
+                                                   newK.ctypes.data_as(C.c_void_p), self._stream()), "vbs_set_undistort")
+        return newK.reshape(3, 3)
+
+    def undistort_frames(self, frames):
+        frames, n, ch, sn, sr = self._frames(frames)
+        shape = (n, self.H, self.W) + ((ch,) if frames.dim() == 4 else ())
+        out = torch.empty(shape, dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_undistort_frames(self._h, _ptr(frames), n, ch, sn, sr, _ptr(out), self._stream()),
+                        "vbs_undistort_frames")
+        return out
+
     # ---- a3-a8 -------------------------------------------------------------------------------
     def find_markers(self, frames):
         frames, n, ch, sn, sr = self._frames(frames)

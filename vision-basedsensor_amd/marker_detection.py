@@ -27,14 +27,22 @@ CSV_COLUMNS = ["frameno", "row", "col", "Ox", "Oy", "Cx", "Cy", "major_axis", "m
 _ENGINES = {}
 
 
-def _engine(height, width, device=None, max_batch=16):
+def _engine(height, width, device=None, max_batch=16, calibration=None):
+    """One cached engine per (frame size, device, undistortion setup)."""
     import torch
     from .engine import Engine
     dev = torch.cuda.current_device() if (device is None and torch.cuda.is_available()) else (device or 0)
-    key = (int(height), int(width), int(dev))
+    ukey = None
+    if calibration is not None:
+        K = np.asarray(calibration["camera_matrix"], dtype=np.float64).reshape(3, 3)
+        D = np.asarray(calibration["dist_coeffs"], dtype=np.float64).ravel()
+        ukey = (K.tobytes(), D.tobytes())
+    key = (int(height), int(width), int(dev), ukey)
     eng = _ENGINES.get(key)
     if eng is None or eng.max_batch < max_batch:
         eng = Engine(height, width, max_markers=1024, max_batch=max_batch, device=int(dev))
+        if calibration is not None:
+            eng.set_undistort(K, D)
         _ENGINES[key] = eng
     return eng
 
@@ -113,13 +121,19 @@ class MarkerTracker:
         self.crop_width, self.crop_height = right - left, bottom - top
 
     def _preprocess_frame(self, frame):
-        """Crop (a view, `:80-85`); frame undistortion (`:93-109`) is not part of this build."""
+        """Crop (a view, `:80-85`) and, when `calibration_params` is configured, undistort (`:88-89`)."""
         left, right, top, bottom = _crop_box(self.width, self.height, self.config["crop_ratios"])
         cropped = frame[top:bottom, left:right]
         if "calibration_params" in self.config:
-            raise NotImplementedError("frame undistortion (marker_detection.py:93-109) is outside the "
-                                      "built hot path (SURVEY.md §8 f3); drop 'calibration_params'")
+            cropped = self._undistort_frame(cropped)
         return cropped
+
+    def _undistort_frame(self, frame):
+        """`:93-109`: getOptimalNewCameraMatrix(alpha=0) + initUndistortRectifyMap(CV_16SC2) + remap(INTER_LINEAR);
+        the maps are built once per (size, K, D), not per frame."""
+        frame = np.asarray(frame)
+        eng = _engine(frame.shape[0], frame.shape[1], self.config.get("device"), calibration=self.config["calibration_params"])
+        return eng.undistort_frames(_to_device(frame[None], eng))[0].cpu().numpy()
 
     # ---- per-stage static methods, NumPy in / NumPy out ------------------------------------------
     @staticmethod
@@ -246,7 +260,8 @@ class MarkerTracker:
     def _process_batch(self, frames):
         import torch
         left, right, top, bottom = _crop_box(self.width, self.height, self.config["crop_ratios"])
-        eng = _engine(bottom - top, right - left, self.config.get("device"), int(self.config.get("batch", 16)))
+        eng = _engine(bottom - top, right - left, self.config.get("device"), int(self.config.get("batch", 16)),
+                      calibration=self.config.get("calibration_params"))    # undistortion, if any, runs inside the engine
         ft = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames))
         ft = ft.to(eng.device)[:, top:bottom, left:right]           # crop = strided view, no copy
         rows = []
