@@ -111,7 +111,8 @@ int vbs_profile_read(vbs_handle* h, char* buf, int cap);
 /* host copy of the per-frame counters of the LAST internal pass: out[i*8 + {0: area_mask popcount,
  * 1: NCC pixels within 1e-9 (relative) of the 0.1 threshold, 2: status, 3: NCC pixels re-evaluated in float64,
  * 4: holes in the opened area mask (components - Euler number; when > 0 the contours of that frame may differ from
- * cv2.findContours(RETR_EXTERNAL), which ignores hole borders)}] (synchronises). */
+ * cv2.findContours(RETR_EXTERNAL), which ignores hole borders), 5 / 6: connected components of the band / opened
+ * mask, 7: runs (union-find nodes) of the mask labelled last}] (synchronises). */
 int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n);
 
 /* MarkerAnalysis._undistort_points (3d_reconstruction.py:185-193) and _calculate_3d_position

@@ -256,6 +256,33 @@ def test_matching_sequential_replay_equals_parallel(monkeypatch):
     assert par == seq and len(par) == spec.n_markers
 
 
+@pytest.mark.parametrize("shape", [(450, 480), (960, 960), (480, 640), (1024, 1280), (1200, 1920), (130, 4096)])
+def test_label_counts_on_line_patterns(shape):
+    """CCL structure cases for every lanes-per-row packing (WW = 8, 15, 10, 20, 30, 64 words per row): runs that
+    cross 64-px word boundaries, a cross spanning all strips and words, a diagonal staircase (one run per row),
+    full-width runs (words that are all ones inside one run).  Band component counts against ndimage.label."""
+    from scipy import ndimage
+    H, W = shape
+    eng = engine(H, W, max_markers=1024, max_batch=1)
+    pats = []
+    m = np.zeros(shape, np.uint8); m[:, 63] = 1; m[:, 64] = 1; pats.append(m)                  # word-crossing runs
+    m = np.zeros(shape, np.uint8); m[10:H - 10, 200] = 1; m[H // 2, 30:W - 30] = 1; pats.append(m)   # cross
+    m = np.zeros(shape, np.uint8)
+    for y in range(0, H - 1, 2):
+        x = (y * 3) % (W - 3)
+        m[y, x:x + 3] = 1; m[y + 1, x + 2:x + 5] = 1
+    pats.append(m)                                                                              # staircases
+    m = np.zeros(shape, np.uint8); m[5, :] = 1; m[5:H - 5, 0] = 1; m[H - 6, :] = 1; m[20, 1:W - 1] = 0; pats.append(m)
+    for m in pats:
+        mt = torch.from_numpy(m).cuda()
+        _, counts = eng.marker_center(mt, mt)
+        st = eng.frame_stats(1)[0]
+        assert int(counts[0]) >= 0
+        want = ndimage.label(O.band_mask(m))[1]
+        assert int(st[5]) == want, (shape, int(st[5]), want)
+    eng.close()
+
+
 def test_holes_are_reported_not_silent():
     """Euler-number check: a ring-shaped area blob (one hole) is flagged, hole-free frames report 0."""
     import warnings

@@ -331,20 +331,23 @@ __device__ __forceinline__ u32 wave_scan_incl(u32 x) {   // inclusive prefix sum
 __device__ __forceinline__ u32 wave_last(u32 x) { return (u32)__builtin_amdgcn_readlane((int)x, 63); }
 
 
-// Per-lane view of one image row: lane j holds word j (64 px), the run-start bits in it, the node index of
-// the first run that starts in it, and the node of the run that enters it from the left (NONE32 if none).
+// Per-lane view of G = 64 / WW consecutive image rows ("a step"): lane = g * WW + j holds word j (64 px) of row
+// y0 + g, the run-start bits in it, the node index of the first run that starts in it, and the node of the run that
+// enters it from the left (NONE32 if none).  Lanes are in raster order, so one wave-wide prefix sum numbers the runs.
 struct RowState {
     u64 w, st;
     u32 base, cin;
 };
 
-// Build the RowState of a row from its words (lane j < WW holds word j, other lanes 0).  `rowbase` is the node
-// index of the row's first run (wave-uniform) and is advanced past the row.
-__device__ __forceinline__ RowState make_row_state(u64 w, u32& rowbase) {
-    const int lane = threadIdx.x & 63;
+// Build the state of a step from its words (lanes outside the step hold 0).  `j` = word column of the lane,
+// `rowbase` = node index of the step's first run (wave-uniform), advanced past the step.
+__device__ __forceinline__ RowState make_row_state(u64 w, int j, u32& rowbase) {
     RowState s;
     s.w = w;
-    const u64 msb = (u64)(dpp_shr1((u32)(w >> 32)) >> 31);                 // bit 63 of word j-1 (0 for lane 0)
+    // (cross-lane moves run with all lanes enabled and are selected afterwards: a DPP read from an exec-masked
+    //  lane returns 0, so they must never sit inside a conditional)
+    const u64 msb_all = (u64)(dpp_shr1((u32)(w >> 32)) >> 31);
+    const u64 msb = j ? msb_all : 0ull;                   // bit 63 of the word to the left in the row
     s.st = w & ~((w << 1) | msb);
     const u32 c = __popcll(s.st);
     const u32 inc = wave_scan_incl(c);
@@ -359,8 +362,7 @@ __device__ __forceinline__ RowState make_row_state(u64 w, u32& rowbase) {
     s.cin = NONE32;
     for (int it = 0; it < 64; ++it) {
         u32 upn = dpp_shr1(lastnode);
-        if (lane == 0) upn = NONE32;
-        u32 ncin = cont ? upn : NONE32;
+        u32 ncin = cont ? upn : NONE32;                  // cont implies j > 0
         u32 nlast = c ? last_here : (full ? ncin : NONE32);
         bool changed = (ncin != s.cin) || (nlast != lastnode);
         s.cin = ncin;
@@ -370,17 +372,24 @@ __device__ __forceinline__ RowState make_row_state(u64 w, u32& rowbase) {
     return s;
 }
 
-__device__ __forceinline__ RowState shfl_state_up(const RowState& s) {       // state of lane j-1 (zeros for lane 0)
+__device__ __forceinline__ RowState zero_state() { RowState z = {0ull, 0ull, 0u, NONE32}; return z; }
+
+// state of the word to the left / right in the same row (zeros at the row ends)
+__device__ __forceinline__ RowState state_left(const RowState& s, int j) {
     RowState r;
     r.w = dpp_shr1(s.w); r.st = dpp_shr1(s.st); r.base = dpp_shr1(s.base); r.cin = dpp_shr1(s.cin);
-    if ((threadIdx.x & 63) == 0) r.cin = NONE32;
-    return r;
+    return j ? r : zero_state();
 }
-
-__device__ __forceinline__ RowState shfl_state_down(const RowState& s) {     // state of lane j+1 (zeros for lane 63)
+__device__ __forceinline__ RowState state_right(const RowState& s, int j, int WW) {
     RowState r;
     r.w = dpp_shl1(s.w); r.st = dpp_shl1(s.st); r.base = dpp_shl1(s.base); r.cin = dpp_shl1(s.cin);
-    if ((threadIdx.x & 63) == 63) r.cin = NONE32;
+    return (j + 1 < WW) ? r : zero_state();
+}
+
+// state held by another lane (ds_bpermute; executed by every lane)
+__device__ __forceinline__ RowState state_from(const RowState& s, int src) {
+    RowState r;
+    r.w = __shfl(s.w, src); r.st = __shfl(s.st, src); r.base = __shfl(s.base, src); r.cin = __shfl(s.cin, src);
     return r;
 }
 
@@ -396,9 +405,10 @@ __device__ __forceinline__ u32 node_in_row(const RowState& s, int k) {
     return s.base;
 }
 
-// unions of the runs of row `cur` with the runs of the row above (`prev`): 4-connectivity (m = 0) or 8 (m = 1)
-__device__ __forceinline__ void link_rows(u32* parent, const RowState& cur, const RowState& prev, int m) {
-    const RowState pl = shfl_state_up(prev), pr = shfl_state_down(prev);       // every lane takes part in the shuffles
+// unions of the runs of this lane's word (`cur`) with the runs of the row above (`prev` = same column, one row up):
+// 4-connectivity (m = 0) or 8 (m = 1).  Cross-lane moves first, by every lane; the loops after them may diverge.
+__device__ __forceinline__ void link_rows(u32* parent, const RowState& cur, const RowState& prev, int j, int WW, int m) {
+    const RowState pl = state_left(prev, j), pr = state_right(prev, j, WW);
     const u64 B = cur.w, A = prev.w;
     u64 adj = A;
     if (m == 1) adj |= (A << 1) | (A >> 1) | (pl.w >> 63) | (pr.w << 63);
@@ -427,23 +437,25 @@ __device__ __forceinline__ void link_rows(u32* parent, const RowState& cur, cons
     }
 }
 
-// 4-deep register ring of row words: PF_INIT issues the loads of rows y0..y0+3, PF_NEXT hands out row y and
-// issues row y+4, so a row-step never waits for a load it has just issued.  (lane j < WW holds word j.)
-#define PF_INIT(ptr, y0, ylim)                                                                      \
-    u64 pf0 = (act && (y0) + 0 < (ylim)) ? (ptr)[(int64_t)((y0) + 0) * WW + lane] : 0ull;          \
-    u64 pf1 = (act && (y0) + 1 < (ylim)) ? (ptr)[(int64_t)((y0) + 1) * WW + lane] : 0ull;          \
-    u64 pf2 = (act && (y0) + 2 < (ylim)) ? (ptr)[(int64_t)((y0) + 2) * WW + lane] : 0ull;          \
-    u64 pf3 = (act && (y0) + 3 < (ylim)) ? (ptr)[(int64_t)((y0) + 3) * WW + lane] : 0ull;
-#define PF_NEXT(ptr, y, ylim, out)                                                                  \
-    out = pf0; pf0 = pf1; pf1 = pf2; pf2 = pf3;                                                     \
-    pf3 = (act && (y) + 4 < (ylim)) ? (ptr)[(int64_t)((y) + 4) * WW + lane] : 0ull;
+// 4-deep register ring of step words: PF_INIT issues the loads of steps y0, y0+G, .., PF_NEXT hands out the step at
+// y and issues the one at y + 4 G, so a step never waits for a load it has just issued.  Lane (g, j) holds word j of
+// row y + g; rows >= ylim read as 0.
+#define PF_LOAD(ptr, yy, ylim) ((act && (yy) < (ylim)) ? (ptr)[(int64_t)(yy) * WW + j] : 0ull)
+#define PF_INIT(ptr, y0, ylim)                               \
+    u64 pf0 = PF_LOAD(ptr, (y0) + g, ylim);                  \
+    u64 pf1 = PF_LOAD(ptr, (y0) + G + g, ylim);              \
+    u64 pf2 = PF_LOAD(ptr, (y0) + 2 * G + g, ylim);          \
+    u64 pf3 = PF_LOAD(ptr, (y0) + 3 * G + g, ylim);
+#define PF_NEXT(ptr, y, ylim, out)                           \
+    out = pf0; pf0 = pf1; pf1 = pf2; pf2 = pf3;              \
+    pf3 = PF_LOAD(ptr, (y) + 4 * G + g, ylim);
 
-// One workgroup (16 waves) per (frame, mask).  Wave w owns the strip of rows [w R, (w+1) R), R = ceil(H / 16),
-// and walks it top-down with lane j holding word j of the row: run starts, node indices and the links to the row
-// above come from registers and wave shuffles, the union-find table lives in LDS.  Because a row is linked only
-// after the rows above it, the trees stay shallow (path halving keeps them flat); the 15 strip boundaries are
-// linked at the end.  Node indices follow raster order, so the root (minimum) of a component is its first run and
-// component ids come out in ndimage.label order.
+// One workgroup (16 waves) per (frame, mask).  Wave w owns the strip of rows [w R, (w+1) R), R = ceil(H / 16), and
+// walks it top-down G = 64 / WW rows at a time (3 at W = 1280), lane = g * WW + j holding word j of row y0 + g:
+// run starts, node indices (one wave prefix sum, raster order), the run entering from the left and the links to the
+// row above come from registers, DPP moves and a few ds_bpermute; the union-find table lives in LDS (path halving,
+// atomicMin hooking).  The 15 strip boundaries are linked at the end.  Node indices follow raster order, so the
+// root (minimum) of a component is its first run and component ids come out in ndimage.label order.
 __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bits,
                                                 const u64* __restrict__ open_bits,
                                                 u32* __restrict__ wbase_all, u32* __restrict__ node_pos_all,
@@ -474,15 +486,21 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     for (int i = tid; i < 1024; i += nthr) { acc_cnt[i] = 0; acc_sx[i] = 0; acc_sy[i] = 0; }
     const int R = (H + 15) / 16;
     const int ya = min(H, wave * R), yb = min(H, ya + R);                  // this wave's rows
-    const bool act = lane < WW;
+    const int G = 64 / WW;                                                 // rows per step (WW <= 64)
+    const int g = lane / WW, j = lane - g * WW;
+    const bool act = g < G;
+    const int up_src = g ? lane - WW : lane + (G - 1) * WW;                // lane holding the word one row up
+    bnd_w[wave][lane] = 0; bnd_base[wave][lane] = 0; bnd_cin[wave][lane] = NONE32;
 
     // ---- 1: runs per strip -> first node index of every strip ---------------------------------------
     {
         u32 c = 0;
         PF_INIT(bits, ya, yb)
-        for (int y = ya; y < yb; ++y) {
+        for (int y = ya; y < yb; y += G) {
             u64 w; PF_NEXT(bits, y, yb, w)
-            c += __popcll(w & ~((w << 1) | (u64)(dpp_shr1((u32)(w >> 32)) >> 31)));
+            const u64 msb_all = (u64)(dpp_shr1((u32)(w >> 32)) >> 31);
+            const u64 msb = j ? msb_all : 0ull;
+            c += __popcll(w & ~((w << 1) | msb));
         }
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) c += __shfl_xor(c, off);
@@ -497,40 +515,50 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         return;
     }
 
-    // ---- 2: label the strip, row by row ---------------------------------------------------------------
-    RowState first_row = {0, 0, 0, NONE32};
+    // ---- 2: label the strip, G rows per step ------------------------------------------------------------
+    RowState first_row = zero_state();
     {
         u32 rowbase = mybase;
-        RowState prev = {0, 0, 0, NONE32};
+        RowState last = zero_state();                   // previous step
         PF_INIT(bits, ya, yb)
-        for (int y = ya; y < yb; ++y) {
+        for (int y = ya; y < yb; y += G) {
             u64 w; PF_NEXT(bits, y, yb, w)
-            RowState cur = make_row_state(w, rowbase);
-            if (act) wbase[(int64_t)y * WW + lane] = cur.base;
+            const int yr = y + g;                       // this lane's row
+            RowState cur = make_row_state(w, j, rowbase);
+            if (act && yr < yb) wbase[(int64_t)yr * WW + j] = cur.base;
             u64 st = cur.st;
             u32 nd = cur.base;
             while (st) {
                 int k = __ffsll((long long)st) - 1;
                 st &= st - 1;
                 parent[nd] = nd;
-                node_pos[nd] = (u32)(y * W + 64 * lane + k);
+                node_pos[nd] = (u32)(yr * W + 64 * j + k);
                 ++nd;
             }
-            if (y == ya) first_row = cur;
-            else if (!(stop & 32)) link_rows(parent, cur, prev, m);
-            prev = cur;
+            // the row above: same step (g > 0) or the last row of the previous step (g == 0)
+            const RowState a = state_from(cur, up_src), b = state_from(last, up_src);
+            RowState prev = g ? a : b;
+            if (!act) prev = zero_state();
+            if (y == ya && g == 0) { first_row = cur; prev = zero_state(); }    // strip boundary: linked in pass 3
+            __builtin_amdgcn_wave_barrier();            // the new nodes' parents are initialised before any union
+            if (!(stop & 32)) link_rows(parent, cur, prev, j, WW, m);
+            last = cur;
+            if (y + G >= yb) {                          // last step: keep the strip's last row for the wave below
+                const int gl = (yb - 1 - y);
+                if (act && g == gl) { bnd_w[wave][j] = cur.w; bnd_base[wave][j] = cur.base; bnd_cin[wave][j] = cur.cin; }
+            }
         }
-        bnd_w[wave][lane] = prev.w; bnd_base[wave][lane] = prev.base; bnd_cin[wave][lane] = prev.cin;
     }
     __syncthreads();
     // ---- 3: link every strip's first row with the last row of the strip above --------------------------
     if (wave > 0 && ya < yb && !(stop & 32)) {
-        RowState prev;
-        prev.w = bnd_w[wave - 1][lane];
-        prev.base = bnd_base[wave - 1][lane];
-        prev.cin = bnd_cin[wave - 1][lane];
-        prev.st = prev.w & ~((prev.w << 1) | (u64)(dpp_shr1((u32)(prev.w >> 32)) >> 31));
-        link_rows(parent, first_row, prev, m);
+        RowState cur = (act && g == 0) ? first_row : zero_state();
+        RowState prev = zero_state();
+        if (act && g == 0) { prev.w = bnd_w[wave - 1][j]; prev.base = bnd_base[wave - 1][j]; prev.cin = bnd_cin[wave - 1][j]; }
+        const u64 msb_all = (u64)(dpp_shr1((u32)(prev.w >> 32)) >> 31);
+        const u64 msb = j ? msb_all : 0ull;
+        prev.st = prev.w & ~((prev.w << 1) | msb);
+        link_rows(parent, cur, prev, j, WW, m);
     }
     __syncthreads();
     if ((stop & 15) == 2) return;
@@ -579,7 +607,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         }
         cids[k] = (unsigned short)cid;
     }
-    if (tid == 0) ncomp_all[n * 2 + m] = ncomp;
+    if (tid == 0) { ncomp_all[n * 2 + m] = ncomp; fstat[n * 8 + 5 + m] = ncomp; fstat[n * 8 + 7] = nruns; }
     __syncthreads();
     unsigned short* cid16 = reinterpret_cast<unsigned short*>(parent);
 #pragma unroll
@@ -592,33 +620,34 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     __syncthreads();
     if ((stop & 15) == 4) return;
 
-    // ---- F: per-component sums, same walk: wave = strip, lane = word column, sums kept in registers and
-    //         flushed with LDS atomics when the component under the lane changes -------------------------------
+    // ---- F: per-component sums, same walk; sums stay in registers and are flushed with LDS atomics when the
+    //         component under the lane changes (a lane sees rows y0 + g, y0 + g + G, ... of one word column) --------
     if (m == 0) {
         u32 rowbase = wfirst[wave];
         u32 curc = NONE32, c_cnt = 0;
         u64 c_sx = 0, c_sy = 0;
         PF_INIT(bits, ya, yb)
-        for (int y = ya; y < yb; ++y) {
+        for (int y = ya; y < yb; y += G) {
             u64 wv; PF_NEXT(bits, y, yb, wv)
-            RowState cur = make_row_state(wv, rowbase);
+            const int yr = y + g;
+            RowState cur = make_row_state(wv, j, rowbase);
             u64 w = wv;
             while (w) {
                 u64 lowbit = w & (~w + 1ull);
                 u64 t = w + lowbit;
-                u64 g = w & ~t;
+                u64 gg = w & ~t;
                 w &= t;
-                int k0 = __ffsll((long long)g) - 1;
-                u32 len = __popcll(g);
+                int k0 = __ffsll((long long)gg) - 1;
+                u32 len = __popcll(gg);
                 u32 cid = cid16[node_in_row(cur, k0)];
                 if (cid != curc) {
                     if (c_cnt) { atomicAdd(&acc_cnt[curc], c_cnt); atomicAdd(&acc_sx[curc], c_sx); atomicAdd(&acc_sy[curc], c_sy); }
                     curc = cid; c_cnt = 0; c_sx = 0; c_sy = 0;
                 }
-                u64 x0 = 64 * lane + k0;
+                u64 x0 = 64 * j + k0;
                 c_cnt += len;
                 c_sx += (u64)len * x0 + (u64)len * (len - 1) / 2;
-                c_sy += (u64)len * (u64)y;
+                c_sy += (u64)len * (u64)yr;
             }
         }
         if (c_cnt) { atomicAdd(&acc_cnt[curc], c_cnt); atomicAdd(&acc_sx[curc], c_sx); atomicAdd(&acc_sy[curc], c_sy); }
@@ -637,30 +666,42 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         i64 s[NMOM];
 #pragma unroll
         for (int q = 0; q < NMOM; ++q) s[q] = 0;
-        // three-row window in registers: up / w / dn (rows y-1, y, y+1), zero outside the image
-        u64 up = (act && ya > 0) ? bits[(int64_t)(ya - 1) * WW + lane] : 0ull;
-        u64 wv = (act && ya < yb) ? bits[(int64_t)ya * WW + lane] : 0ull;
-        PF_INIT(bits, ya + 1, H)                        // the ring runs one row ahead: it delivers row y+1
-        // Euler number by bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the
-        // zero-padded image; window (x, y) = pixels (x..x+1, y..y+1).  The wave counts the windows whose top row is
-        // y = ya-1 (strip 0 only: the padding row) .. yb-1.  holes = components - E.
-        for (int y = ya; y < yb; ++y) {
-            u64 dn; PF_NEXT(bits, y + 1, H, dn)
-            RowState cur = make_row_state(wv, rowbase);
-            const u64 wn_ = dpp_shl1(wv), wp_ = dpp_shr1(wv), un_ = dpp_shl1(up), up_ = dpp_shr1(up),
-                      dn_ = dpp_shl1(dn), dp_ = dpp_shr1(dn);
-            // quads with top row y (and, once per frame, with top row -1)
+        const int dn_src = (g + 1 < G) ? lane + WW : lane - (G - 1) * WW;   // lane holding the word one row down
+        // raw words of the previous step (for "up" of g == 0): before the first step, row ya-1 sits in group G-1
+        u64 wlast = (act && g == G - 1 && ya > 0) ? bits[(int64_t)(ya - 1) * WW + j] : 0ull;
+        PF_INIT(bits, ya, H)                            // raw rows, also beyond yb: they are some row's "down" row
+        for (int y = ya; y < yb; y += G) {
+            u64 wraw; PF_NEXT(bits, y, H, wraw)
+            const int yr = y + g;
+            const bool mine = act && yr < yb;           // rows >= yb belong to the next strip
+            const u64 wv = mine ? wraw : 0ull;
+            RowState cur = make_row_state(wv, j, rowbase);
+            const u64 ua = __shfl(wraw, up_src), ub = __shfl(wlast, up_src);
+            const u64 da = __shfl(wraw, dn_src), db = __shfl(pf0, dn_src);   // pf0 = the next step's raw words
+            const u64 up = g ? ua : ub;
+            const u64 dn = (g + 1 < G) ? da : db;
+            wlast = wraw;
+            const u64 wn_t = dpp_shl1(wv), wp_t = dpp_shr1(wv);
+            const u64 wn_ = (j + 1 < WW) ? wn_t : 0ull, wp_ = j ? wp_t : 0ull;
+            const u64 un_t = dpp_shl1(up), up_t = dpp_shr1(up), dn_t = dpp_shl1(dn), dp_t = dpp_shr1(dn);
+            const u64 un_ = (j + 1 < WW) ? un_t : 0ull, up_ = j ? up_t : 0ull, dn_ = (j + 1 < WW) ? dn_t : 0ull,
+                      dp_ = j ? dp_t : 0ull;
+            // Euler number by bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the
+            // zero-padded image; window (x, y) = pixels (x..x+1, y..y+1).  A lane counts the windows whose top row is its
+            // own row (and, for row 0, the padding row above it).  holes = components - E.
+            if (mine) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (q == 1 && y != 0) continue;
-                const u64 a = q ? 0ull : wv, an = q ? 0ull : wn_, b = q ? wv : dn, bn = q ? wn_ : dn_;
-                if (a | b | (an & 1ull) | (bn & 1ull)) {
-                    u64 a1 = (a >> 1) | (an << 63), b1 = (b >> 1) | (bn << 63);
-                    u64 x2 = (a ^ a1) ^ (b ^ b1);
-                    u64 pairs = (a & a1) | (a & b) | (a & b1) | (a1 & b) | (a1 & b1) | (b & b1);
-                    u64 qd = (a & b1 & ~a1 & ~b) | (a1 & b & ~a & ~b1);
-                    e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
-                    if (lane == 0) e4 += (int)((a ^ b) & 1ull);           // window x = -1: only (0,y), (0,y+1)
+                for (int q = 0; q < 2; ++q) {
+                    if (q == 1 && yr != 0) continue;
+                    const u64 a = q ? 0ull : wv, an = q ? 0ull : wn_, b = q ? wv : dn, bn = q ? wn_ : dn_;
+                    if (a | b | (an & 1ull) | (bn & 1ull)) {
+                        u64 a1 = (a >> 1) | (an << 63), b1 = (b >> 1) | (bn << 63);
+                        u64 x2 = (a ^ a1) ^ (b ^ b1);
+                        u64 pairs = (a & a1) | (a & b) | (a & b1) | (a1 & b) | (a1 & b1) | (b & b1);
+                        u64 qd = (a & b1 & ~a1 & ~b) | (a1 & b & ~a & ~b1);
+                        e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
+                        if (j == 0) e4 += (int)((a ^ b) & 1ull);             // window x = -1: only (0,y), (0,y+1)
+                    }
                 }
             }
             const u64 w = wv;
@@ -673,11 +714,11 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                 while (rest) {                          // one group (= part of one run) at a time
                     u64 lowbit = rest & (~rest + 1ull);
                     u64 t = rest + lowbit;
-                    u64 g = rest & ~t;
+                    u64 gg = rest & ~t;
                     rest &= t;
-                    u64 bg = border & g;
+                    u64 bg = border & gg;
                     if (!bg) continue;
-                    u32 cid = cid16[node_in_row(cur, __ffsll((long long)g) - 1)];
+                    u32 cid = cid16[node_in_row(cur, __ffsll((long long)gg) - 1)];
                     if (cid != curc) {
                         if (any) {
 #pragma unroll
@@ -701,7 +742,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                         i64 mult = lut[pat];
                         if (!mult) continue;
                         any = true;
-                        i64 dx = 64 * lane + k - ax, dy = y - ay;
+                        i64 dx = 64 * j + k - ax, dy = yr - ay;
                         i64 x2 = dx * dx, y2 = dy * dy;
                         s[0] += mult;
                         s[1] += mult * dx;            s[2] += mult * dy;
@@ -713,8 +754,6 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                     }
                 }
             }
-            up = wv;
-            wv = dn;
         }
         if (any) {
 #pragma unroll
