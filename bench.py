@@ -85,8 +85,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
-    ap.add_argument("--batch", type=int, default=256, help="frames per internal pass (workspace size)")
-    ap.add_argument("--roofline-frames", type=int, default=512)
+    ap.add_argument("--batch", type=int, default=512, help="frames per internal pass (workspace size)")
+    ap.add_argument("--roofline-frames", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-workers", type=int, default=8)
     ap.add_argument("--cpu-frames-per-worker", type=int, default=3)
