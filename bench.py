@@ -13,6 +13,8 @@ RCCL (N > 1), then the last-seen displacement pass on the gathered table.  value
 ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
+  (dtype "u8+f64": uint8 / int32 integer work in the blur and labelling kernels, float64 decisions in the NCC
+   (behind a float32 filter), the ellipse fit and the 3-D solve; tables are stored as float32)
   roofline      threshold+CCL stage (`vbs_marker_center` on uint8 mask + area_mask: k_threshold,
                 k_morph x2, k_label, k_finalize), timed live with HIP events on the launch stream
                 inside libvbs.  achieved = algorithmic bytes / stage time, algorithmic bytes per
@@ -172,7 +174,7 @@ def main():
             "metric": "frames/sec (track->3D) at 1280x1024, 169 markers", "value": round(fps, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u8/i32 (blur, CCL) + f64 (NCC, ellipse, 3D)", "data": "synthetic",
+            "vs_baseline": None, "dtype": "u8+f64", "data": "synthetic",
             "config": {"workload": f"BASELINE config 3/4: {args.frames} synthetic 1280x1024 gray uint8 frames per GPU "
                                    f"(13x13 dots, seeded jitter+noise), resident in HBM; fused track->3D table + "
                                    f"{'RCCL all-gather + ' if world > 1 else ''}last-seen displacement",

@@ -7,6 +7,6 @@ TAG=${1:-r1}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline > $OUT/prof_$TAG.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $GRAFT_REPO_ROOT/tests/gpu_stage_run.py 512 > $OUT/pmc_fetch_$TAG.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3 $GRAFT_REPO_ROOT/tests/gpu_stage_run.py 512 > $OUT/pmc_write_$TAG.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch_$TAG -- python3 $GRAFT_REPO_ROOT/tools/gpu_stage_run.py 512 > $OUT/pmc_fetch_$TAG.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write_$TAG -- python3 $GRAFT_REPO_ROOT/tools/gpu_stage_run.py 512 > $OUT/pmc_write_$TAG.log 2>&1
 echo collected $TAG

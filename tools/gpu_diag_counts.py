@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vbs_amd.engine import Engine
 from oracle import stages as O
 from scipy import ndimage
-G = np.load(os.path.join(os.path.dirname(__file__), "golden", "stages.npz"))
+G = np.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "stages.npz"))
 def rle_decode(runs, shape):
     vals = np.zeros(len(runs), dtype=np.uint8); vals[1::2] = 1
     return np.repeat(vals, runs).reshape(shape)

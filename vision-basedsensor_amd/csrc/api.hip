@@ -171,7 +171,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(gray, B * HP);
     ALLOC(planes, B * 4 * (size_t)h->QE * h->P);
     ALLOC(area_bits, B * HW); ALLOC(mask_bits, B * HW); ALLOC(band_bits, B * HW);
-    ALLOC(er_bits, B * HW); ALLOC(open_bits, B * HW);
+    ALLOC(open_bits, B * HW);
     ALLOC(ncc_rx, (size_t)width); ALLOC(ncc_ry, (size_t)height);
     ALLOC(fstat, B * 8 + 8);                           // + one spare word (displacement's first-frame cell)
     ALLOC(wbase, B * 2 * HW);

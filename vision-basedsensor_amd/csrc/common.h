@@ -59,7 +59,6 @@ struct vbs_handle {
     u64* area_bits;    // [maxb][H][WW]
     u64* mask_bits;    // [maxb][H][WW]
     u64* band_bits;    // [maxb][H][WW]
-    u64* er_bits;      // [maxb][H][WW]
     u64* open_bits;    // [maxb][H][WW]
     double* ncc_rx;    // [W]  sum of g over the in-image part of the window (columns)
     double* ncc_ry;    // [H]
