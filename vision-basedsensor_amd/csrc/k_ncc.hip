@@ -121,6 +121,8 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
         const int r0 = wave * (RT / 4) + oct * 8;        // first LDS row of this lane's 8 output rows
         const int y0 = yb + r0;
         if (y0 >= H) break;                              // wave-uniform
+        const bool interior = (y0 + LO >= 0) && (y0 + 7 + HI <= H - 1) && (x0 + LO >= 0) && (x0 + 63 + HI <= W - 1);
+        const double full_t = ry[min(max(-LO, 0), H - 1)] * rx[min(max(-LO, 0), W - 1)];   // rows / columns with a full window
         float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         float vw[8];
 #pragma unroll
@@ -159,10 +161,15 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
             const int y = y0 + s;
             bool pred = false;
             if (y < H && x < W) {
-                int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
-                int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
-                double nn = (double)(ny * nx);
-                double sum_t = ry[y] * rx[x];
+                double nn, sum_t;
+                if (interior) {                          // wave-uniform: every window of these 8 rows x 64 columns is
+                    nn = nc.l2; sum_t = full_t;          // inside the image, so n = l*l and sum_W t is the full sum
+                } else {
+                    int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
+                    int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
+                    nn = (double)(ny * nx);
+                    sum_t = ry[y] * rx[x];
+                }
                 double sum_I = 255.0 * (double)(cs0 - pre[s] + post[s]);
                 double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);       // num = 255 G + rest
                 double s1 = sum_I - nn * mu;
