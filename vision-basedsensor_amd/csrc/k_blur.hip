@@ -67,26 +67,40 @@ __global__ __launch_bounds__(64) void k_blur_h(const u8* __restrict__ gray, int6
         }
     }
     __syncthreads();
-    u32 hiA[4] = {0, 0, 0, 0}, loA[4] = {0, 0, 0, 0}, hiB[4] = {0, 0, 0, 0}, loB[4] = {0, 0, 0, 0};
+    // tap word outermost: its 4 phase variants are fetched once (SGPRs) and serve all 4 rows
+    u32 oa[4][4], ob[4][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        u32 pw[NWB];
+    for (int r = 0; r < 4; ++r)
 #pragma unroll
-        for (int q = 0; q < NWB; ++q) pw[q] = rowbuf[r][lane + q];
+        for (int s = 0; s < 4; ++s) oa[r][s] = ob[r][s] = 0;
+#pragma unroll
+    for (int q = 0; q < NWB; ++q) {
+        u32 pw[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[r] = rowbuf[r][lane + q];
+        constexpr int QA0 = (C4B - C4A) / 4;
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            u32 oa = 0, ob = 0;
+            const u32 tb = taps.b[s][q];
 #pragma unroll
-            for (int q = 0; q < NWA; ++q)
-                oa = __builtin_amdgcn_udot4(pw[q + (C4B - C4A) / 4], taps.a[s][q], oa, false);
+            for (int r = 0; r < 4; ++r) ob[r][s] = __builtin_amdgcn_udot4(pw[r], tb, ob[r][s], false);
+            if (q >= QA0 && q < QA0 + NWA) {
+                const u32 ta = taps.a[s][q - QA0];
 #pragma unroll
-            for (int q = 0; q < NWB; ++q) ob = __builtin_amdgcn_udot4(pw[q], taps.b[s][q], ob, false);
-            hiA[s] |= (oa >> 8) << (8 * r);
-            loA[s] |= (oa & 255u) << (8 * r);
-            hiB[s] |= (ob >> 8) << (8 * r);
-            loB[s] |= (ob & 255u) << (8 * r);
+                for (int r = 0; r < 4; ++r) oa[r][s] = __builtin_amdgcn_udot4(pw[r], ta, oa[r][s], false);
+            }
         }
     }
+    u32 hiA[4] = {0, 0, 0, 0}, loA[4] = {0, 0, 0, 0}, hiB[4] = {0, 0, 0, 0}, loB[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            hiA[s] |= (oa[r][s] >> 8) << (8 * r);
+            loA[s] |= (oa[r][s] & 255u) << (8 * r);
+            hiB[s] |= (ob[r][s] >> 8) << (8 * r);
+            loB[s] |= (ob[r][s] & 255u) << (8 * r);
+        }
     const int x0 = tile_x0 + 4 * lane;
     if (x0 < P) {
         int64_t plane_sz = (int64_t)QE * P;

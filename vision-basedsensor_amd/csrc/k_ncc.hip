@@ -45,6 +45,21 @@ __device__ __forceinline__ double ncc_row_exact(const u64* __restrict__ row, int
     return h;
 }
 
+// Exact float64 G(y, x) = sum_i g[i] H(y + LO + i, x), products added in ascending i.  Rare path (pixels the float32
+// filter cannot decide, or the diagnostic map): kept out of line so that its loops are not replicated 8x.
+template <int L, int LO>
+__device__ __attribute__((noinline)) double ncc_exact_G(const u64* fbits, int H, int WW, int y, int x, const double* cg,
+                                                        const double* gsh) {
+    u32 dummy = 0;
+    double Ge = 0.0;
+    for (int i = 0; i < L; ++i) {
+        int yy = y + LO + i;
+        double hrow = (yy >= 0 && yy < H) ? ncc_row_exact<L, LO>(fbits + (int64_t)yy * WW, WW, x, cg, &dummy) : 0.0;
+        Ge = __builtin_fma(gsh[i], hrow, Ge);
+    }
+    return Ge;
+}
+
 // One workgroup = 64 columns x 64 output rows.
 // Phase 1 fills LDS with the horizontal pass of the 64+L-1 rows the tile needs, 8 px per work item from one
 // shared bit window, computed in float64 from runs (2 table lookups per run instead of L multiply-adds) and
@@ -182,14 +197,7 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
                     bool plo = (nlo > 0.0) && (nlo * nlo > rhs), phi = (nhi > 0.0) && (nhi * nhi > rhs);
                     pred = plo;
                     if (plo != phi || ncc_out) {          // undecided by float32 (or a map was asked for): exact
-                        u32 dummy = 0;
-                        double Ge = 0.0;
-                        for (int i = 0; i < L; ++i) {
-                            int yy = y + LO + i;
-                            double hrow = (yy >= 0 && yy < H)
-                                              ? ncc_row_exact<L, LO>(fbits + (int64_t)yy * WW, WW, x, cg, &dummy) : 0.0;
-                            Ge = __builtin_fma(gsh[i], hrow, Ge);
-                        }
+                        const double Ge = ncc_exact_G<L, LO>(fbits, H, WW, y, x, cg, gsh);
                         double num = 255.0 * Ge + rest;
                         pred = (num > 0.0) && (num * num > rhs);
                         if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
