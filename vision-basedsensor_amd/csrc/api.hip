@@ -163,7 +163,6 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     pack_taps_t<VBS_MAX_TAPS_WORDS>(gaussian_taps_q8(bp.taps_b, sb), bp.c4b, bp.nwb, h->taps.b);
     ncc_consts(bp.ncc_l, ts, &h->ncc);
     h->QE = (height + 3) / 4 + bp.nwb - 1;
-    h->mref_cap = 0;
 
     const size_t B = (size_t)max_batch, HW = (size_t)height * h->WW, HP = (size_t)height * h->P;
     int rc;

@@ -74,14 +74,12 @@ struct vbs_handle {
     double* ell;       // [maxb][maxm][8]   cx, cy, w, h, angle, nvert, ok, spare
     double* det64;     // [maxb][maxm][6]
     int32_t* cnt;      // [maxb]
-    double* tab64;     // [maxb][mref_cap][10]
     u8* lut;           // [256] contour vertex table
     short* umap1;      // [H][W][2] int16 undistortion source pixel (CV_16SC2)
     unsigned short* umap2;   // [H][W] fractional index into the bilinear weight table
     int* uwtab;        // [1024][4] bilinear weights in 1/32768
     bool undist = false;     // frame undistortion enabled (vbs_set_undistort)
     double newK[9];
-    int mref_cap;
     std::vector<void*> allocs;
 };
 
