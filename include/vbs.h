@@ -110,9 +110,9 @@ int vbs_profile(vbs_handle* h, int enable);
 int vbs_profile_read(vbs_handle* h, char* buf, int cap);
 /* host copy of the per-frame counters of the LAST internal pass: out[i*8 + {0: area_mask popcount,
  * 1: NCC pixels within 1e-9 (relative) of the 0.1 threshold, 2: status, 3: NCC pixels re-evaluated in float64,
- * 4: holes in the opened area mask (components - Euler number; when > 0 the contours of that frame may differ from
- * cv2.findContours(RETR_EXTERNAL), which ignores hole borders), 5 / 6: connected components of the band / opened
- * mask, 7: runs (union-find nodes) of the mask labelled last}] (synchronises). */
+ * 4: holes LEFT in the opened area mask (components - Euler number; holes are filled before contouring, like
+ * cv2.findContours(RETR_EXTERNAL) ignores them, so this is 0 unless the fill pass ran out of capacity), 5 / 6: connected
+ * components of the band / opened mask, 7: holes that were filled}] (synchronises). */
 int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n);
 
 /* MarkerAnalysis._undistort_points (3d_reconstruction.py:185-193) and _calculate_3d_position

@@ -283,32 +283,43 @@ def test_label_counts_on_line_patterns(shape):
     eng.close()
 
 
-def test_holes_are_reported_not_silent():
-    """Euler-number check: a ring-shaped area blob (one hole) is flagged, hole-free frames report 0."""
+def test_holes_are_filled_like_retr_external():
+    """cv2.findContours(RETR_EXTERNAL) ignores hole borders and anything nested inside a hole.  The HIP path gets the
+    same result by filling the holes of the opened mask (background components that do not touch the border) before
+    contouring; the Euler-number check decides per frame whether that pass runs."""
     import warnings
     from vbs_amd.marker_detection import MarkerTracker
-    yy, xx = np.mgrid[0:256, 0:320]
+    yy, xx = np.mgrid[0:300, 0:400]
+    area = np.zeros((300, 400), np.uint8)
+    mask = np.zeros((300, 400), np.uint8)
     r2 = (yy - 120) ** 2 + (xx - 150) ** 2
-    area = ((r2 <= 40 ** 2) & (r2 >= 15 ** 2)).astype(np.uint8) * 255
-    area[200:230, 20:60] = 255                           # a second, hole-free blob
-    mask = (r2 <= 30 ** 2).astype(np.uint8)
-    with warnings.catch_warnings(record=True) as w:
-        warnings.simplefilter("always")
-        MarkerTracker._marker_center(mask, area)
-    assert any("1 hole(s)" in str(x.message) for x in w)
-    eng = engine(256, 320, max_batch=1)
+    area[(r2 <= 45 ** 2) & (r2 >= 18 ** 2)] = 255                    # ring: one hole ...
+    area[(yy - 120) ** 2 + (xx - 150) ** 2 <= 7 ** 2] = 255          # ... with a blob nested inside the hole
+    mask[r2 <= 30 ** 2] = 1
+    r3 = (yy - 230) ** 2 + (xx - 60) ** 2
+    area[(r3 <= 30 ** 2) & (r3 >= 9 ** 2)] = 255                     # second ring
+    mask[r3 <= 20 ** 2] = 1
+    r4 = (yy - 240) ** 2 + (xx - 330) ** 2
+    area[r4 <= 28 ** 2] = 255                                         # plain disc
+    mask[r4 <= 18 ** 2] = 1
+    r5 = (yy - 20) ** 2 + (xx - 378) ** 2
+    area[(r5 <= 26 ** 2) & (r5 >= 8 ** 2)] = 255                      # holed disc cut by the image corner
+    mask[r5 <= 14 ** 2] = 1
+    want = O.marker_center(mask, area)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        got = MarkerTracker._marker_center(mask, area)
+    compare_markers(got, want)
+    assert len(want) >= 3
+    eng = engine(300, 400, max_batch=1)
     eng.marker_center(torch.from_numpy(mask).cuda(), torch.from_numpy(area).cuda())
-    assert eng.frame_stats(1)[0, 4] == 1
-    filled = (r2 <= 40 ** 2).astype(np.uint8) * 255
-    filled[0:20, 0:30] = 255                             # touches the image corner: zero padding matters
-    filled[236:256, 300:320] = 255
-    eng.marker_center(torch.from_numpy(mask).cuda(), torch.from_numpy(filled).cuda())
-    assert eng.frame_stats(1)[0, 4] == 0
+    st = eng.frame_stats(1)[0]
+    assert st[7] == 3 and st[4] == 0                                  # three holes filled, none left
     spec = S.config2()
     om, oa = O.find_markers(S.make_frames(spec, [1], seed=4)[0])
     e2 = engine(spec.height, spec.width, max_batch=1)
     e2.marker_center(torch.from_numpy(om).cuda(), torch.from_numpy(oa).cuda())
-    assert e2.frame_stats(1)[0, 4] == 0
+    assert e2.frame_stats(1)[0, 4] == 0 and e2.frame_stats(1)[0, 7] == 0
     eng.close(); e2.close()
 
 

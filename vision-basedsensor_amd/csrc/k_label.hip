@@ -440,7 +440,7 @@ __device__ __forceinline__ void link_rows(u32* parent, const RowState& cur, cons
 // 4-deep register ring of step words: PF_INIT issues the loads of steps y0, y0+G, .., PF_NEXT hands out the step at
 // y and issues the one at y + 4 G, so a step never waits for a load it has just issued.  Lane (g, j) holds word j of
 // row y + g; rows >= ylim read as 0.
-#define PF_LOAD(ptr, yy, ylim) ((act && (yy) < (ylim)) ? (ptr)[(int64_t)(yy) * WW + j] : 0ull)
+#define PF_LOAD(ptr, yy, ylim) ((act && (yy) < (ylim)) ? (inv ? (~(ptr)[(int64_t)(yy) * WW + j] & vmask) : (ptr)[(int64_t)(yy) * WW + j]) : 0ull)
 #define PF_INIT(ptr, y0, ylim)                               \
     u64 pf0 = PF_LOAD(ptr, (y0) + g, ylim);                  \
     u64 pf1 = PF_LOAD(ptr, (y0) + G + g, ylim);              \
@@ -456,14 +456,20 @@ __device__ __forceinline__ void link_rows(u32* parent, const RowState& cur, cons
 // row above come from registers, DPP moves and a few ds_bpermute; the union-find table lives in LDS (path halving,
 // atomicMin hooking).  The 15 strip boundaries are linked at the end.  Node indices follow raster order, so the
 // root (minimum) of a component is its first run and component ids come out in ndimage.label order.
+// mode 0: label the band mask (blockIdx.y = 0, 4-conn) and the opened mask (1, 8-conn).
+// mode 1: only for frames whose opened mask has holes (Euler check of mode 0): label its COMPLEMENT (4-conn), find the
+//         background components that do not touch the image border (= holes) and fill them in open_bits: outer
+//         contours, "inside the contour" and RETR_EXTERNAL's nesting rule are invariant under hole filling, and after
+//         it every border is an outer border, which is what the per-pixel vertex table assumes.
+// mode 2: relabel the (now hole-free) opened mask of those frames.
 __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bits,
-                                                const u64* __restrict__ open_bits,
+                                                u64* __restrict__ open_bits,
                                                 u32* __restrict__ wbase_all, u32* __restrict__ node_pos_all,
                                                 u32* __restrict__ node_comp_all, u32* __restrict__ ncomp_all,
                                                 u32* __restrict__ band_first, u64* __restrict__ band_sums,
                                                 u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                 u32* __restrict__ fstat, const u8* __restrict__ lut_g,
-                                                int H, int W, int WW, int maxm, int stop) {
+                                                int H, int W, int WW, int maxm, int stop, int mode) {
     __shared__ u32 parent[VBS_RUN_CAP];                // union-find parents; later [m=1] the moment accumulators
     __shared__ u64 bnd_w[16][64];                      // last row of every strip: words,
     __shared__ u32 bnd_base[16][64], bnd_cin[16][64];  //   first-node indices, entering nodes
@@ -473,13 +479,18 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     __shared__ u32 tmp[32];
     __shared__ u8 lut[256];
     __shared__ int euler4;                             // 4 x Euler number of the opened mask (bit quads)
-    const int n = blockIdx.x, m = blockIdx.y;          // m = 0 band (4-conn), 1 open (8-conn)
+    const int n = blockIdx.x;
+    const int m = mode == 0 ? (int)blockIdx.y : (mode == 1 ? 2 : 1);   // 0 band (4-conn), 1 open (8-conn), 2 background of open
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int NW = H * WW;
+    if (mode == 1 && fstat[n * 8 + 4] == 0) return;    // no holes in this frame
+    if (mode == 2 && fstat[n * 8 + 7] == 0) return;    // nothing was filled
+    const bool inv = (m == 2);                          // walk the complement of the opened mask
+    const int mslot = (m == 2) ? 0 : m;                 // the background pass borrows the band pass's scratch tables
     const u64* bits = (m == 0 ? band_bits : open_bits) + (int64_t)n * NW;
-    u32* wbase = wbase_all + ((int64_t)n * 2 + m) * NW;
-    u32* node_pos = node_pos_all + ((int64_t)n * 2 + m) * VBS_RUN_CAP;
-    u32* node_comp = node_comp_all + ((int64_t)n * 2 + m) * VBS_RUN_CAP;
+    u32* wbase = wbase_all + ((int64_t)n * 2 + mslot) * NW;
+    u32* node_pos = node_pos_all + ((int64_t)n * 2 + mslot) * VBS_RUN_CAP;
+    u32* node_comp = node_comp_all + ((int64_t)n * 2 + mslot) * VBS_RUN_CAP;
     if (stop == 9) return;
     if (tid < 256) lut[tid] = lut_g[tid];
     if (tid == 0) euler4 = 0;
@@ -489,6 +500,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     const int G = 64 / WW;                                                 // rows per step (WW <= 64)
     const int g = lane / WW, j = lane - g * WW;
     const bool act = g < G;
+    const u64 vmask = valid_mask(j, W);
     const int up_src = g ? lane - WW : lane + (G - 1) * WW;                // lane holding the word one row up
     bnd_w[wave][lane] = 0; bnd_base[wave][lane] = 0; bnd_cin[wave][lane] = NONE32;
 
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     for (int w = 0; w < 16; ++w) { if (w == wave) mybase = nruns; nruns += wtot[w]; }
     if (lane == 0) wfirst[wave] = mybase;
     if (nruns > VBS_RUN_CAP) {                          // block-uniform
-        if (tid == 0) { ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
+        if (tid == 0) { if (m != 2) ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
         return;
     }
 
@@ -541,7 +553,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
             if (!act) prev = zero_state();
             if (y == ya && g == 0) { first_row = cur; prev = zero_state(); }    // strip boundary: linked in pass 3
             __builtin_amdgcn_wave_barrier();            // the new nodes' parents are initialised before any union
-            if (!(stop & 32)) link_rows(parent, cur, prev, j, WW, m);
+            if (!(stop & 32)) link_rows(parent, cur, prev, j, WW, m == 1 ? 1 : 0);
             last = cur;
             if (y + G >= yb) {                          // last step: keep the strip's last row for the wave below
                 const int gl = (yb - 1 - y);
@@ -558,7 +570,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         const u64 msb_all = (u64)(dpp_shr1((u32)(prev.w >> 32)) >> 31);
         const u64 msb = j ? msb_all : 0ull;
         prev.st = prev.w & ~((prev.w << 1) | msb);
-        link_rows(parent, cur, prev, j, WW, m);
+        link_rows(parent, cur, prev, j, WW, m == 1 ? 1 : 0);
     }
     __syncthreads();
     if ((stop & 15) == 2) return;
@@ -577,15 +589,15 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     for (u32 i = r0; i < r1; ++i) nroot += (parent[i] == i);
     u32 ncomp;
     u32 cbase = block_exclusive_scan(nroot, tmp, &ncomp);
-    if (ncomp > (u32)maxm || (m == 1 && ncomp * NMOM * 8u > sizeof(parent) / 2)) {
-        if (tid == 0) { ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
+    if ((m != 2 && ncomp > (u32)maxm) || ncomp > 1024u || (m == 1 && ncomp * NMOM * 8u > sizeof(parent) / 2)) {
+        if (tid == 0) { if (m != 2) ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
         return;
     }
     u32* first = (m == 0 ? band_first : area_first) + (int64_t)n * maxm;
     for (u32 i = r0; i < r1; ++i) {
         if (parent[i] == i) {
             const u32 pos = node_pos[i];                // first pixel of the component = start of its root run
-            first[cbase] = pos;
+            if (m != 2) first[cbase] = pos;
             if (m == 1) acc_cnt[cbase] = pos;          // LDS copy of the anchor for phase F
             parent[i] = i | ((cbase + 1) << 16);       // root: id in the high half
             ++cbase;
@@ -607,7 +619,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         }
         cids[k] = (unsigned short)cid;
     }
-    if (tid == 0) { ncomp_all[n * 2 + m] = ncomp; fstat[n * 8 + 5 + m] = ncomp; fstat[n * 8 + 7] = nruns; }
+    if (tid == 0 && m != 2) { ncomp_all[n * 2 + m] = ncomp; fstat[n * 8 + 5 + m] = ncomp; }
     __syncthreads();
     unsigned short* cid16 = reinterpret_cast<unsigned short*>(parent);
 #pragma unroll
@@ -622,6 +634,41 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
 
     // ---- F: per-component sums, same walk; sums stay in registers and are flushed with LDS atomics when the
     //         component under the lane changes (a lane sees rows y0 + g, y0 + g + G, ... of one word column) --------
+    if (m == 2) {
+        // background components that touch the image border are the outside; the others are holes: fill them
+        for (int pass = 0; pass < 2; ++pass) {
+            u32 rowbase = wfirst[wave];
+            PF_INIT(bits, ya, yb)
+            for (int y = ya; y < yb; y += G) {
+                u64 wv; PF_NEXT(bits, y, yb, wv)
+                const int yr = y + g;
+                RowState cur = make_row_state(wv, j, rowbase);
+                u64 w = wv, fill = 0;
+                while (w) {
+                    u64 lowbit = w & (~w + 1ull);
+                    u64 t = w + lowbit;
+                    u64 gg = w & ~t;
+                    w &= t;
+                    const u32 cid = cid16[node_in_row(cur, __ffsll((long long)gg) - 1)];
+                    if (pass == 0) {
+                        const int xl = W - 1 - 64 * j;                   // bit of the last image column, if in this word
+                        const bool edge = (yr == 0) || (yr == H - 1) || (j == 0 && (gg & 1ull)) ||
+                                          (xl >= 0 && xl < 64 && ((gg >> xl) & 1ull));
+                        if (edge && acc_cnt[cid] == 0) acc_cnt[cid] = 1;
+                    } else if (acc_cnt[cid] == 0) {
+                        fill |= gg;
+                    }
+                }
+                if (pass == 1 && fill)
+                    open_bits[(int64_t)n * NW + (int64_t)yr * WW + j] = (~wv & vmask) | fill;
+            }
+            __syncthreads();
+        }
+        u32 nholes = 0;
+        for (u32 c = tid; c < ncomp; c += nthr) nholes += (acc_cnt[c] == 0);
+        if (nholes) atomicAdd(&fstat[n * 8 + 7], nholes);
+        return;
+    }
     if (m == 0) {
         u32 rowbase = wfirst[wave];
         u32 curc = NONE32, c_cnt = 0;
@@ -769,10 +816,12 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
 }
 
 void launch_label(vbs_handle* h, int nb, hipStream_t s) {
-    VBS_LAUNCH(h, s, "k_label", k_label, dim3(nb, 2), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
-                       h->node_pos, h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first,
-                       h->area_sums, h->fstat, h->lut, h->H, h->W, h->WW, h->maxm,
-                       getenv("VBS_LABEL_STOP") ? atoi(getenv("VBS_LABEL_STOP")) : 0);
+    const int stop = getenv("VBS_LABEL_STOP") ? atoi(getenv("VBS_LABEL_STOP")) : 0;     // debug: phase timing
+    for (int mode = 0; mode < 3; ++mode)       // label; fill holes (frames that have any); relabel those frames
+        VBS_LAUNCH(h, s, mode == 0 ? "k_label" : (mode == 1 ? "k_label_fill" : "k_label_redo"), k_label,
+                   dim3(nb, mode == 0 ? 2 : 1), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase, h->node_pos,
+                   h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first, h->area_sums, h->fstat, h->lut,
+                   h->H, h->W, h->WW, h->maxm, stop, mode);
 }
 
 // ------------------------------------------------------------------------------------------------

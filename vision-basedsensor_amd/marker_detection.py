@@ -189,8 +189,8 @@ class MarkerTracker:
         holes = int(eng.frame_stats(1)[0, 4])
         if holes:
             import warnings
-            warnings.warn(f"{holes} hole(s) in the opened area mask: contour vertices include hole borders, "
-                          "cv2.findContours(RETR_EXTERNAL) would ignore them (DESIGN.md section 7)", RuntimeWarning)
+            warnings.warn(f"{holes} hole(s) of the opened area mask could not be filled (capacity): contour vertices "
+                          "include their borders, cv2.findContours(RETR_EXTERNAL) would ignore them", RuntimeWarning)
         return _det_to_markers(det[0].cpu().numpy(), n)
 
     # ---- identities and tracking -----------------------------------------------------------------
