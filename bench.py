@@ -93,6 +93,9 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=8)
     ap.add_argument("--cpu-frames-per-worker", type=int, default=3)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+                    help="c3 = BASELINE config 3/4 (1280x1024, 13x13; the headline metric); c5 = config 5 (1920x1200, 21x21, "
+                         "adds the plane-fit pose per frame; the JSON line then names that workload)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) | gloo (rehearsal of N>1 on one GPU)")
     args = ap.parse_args()
 
@@ -121,12 +124,12 @@ def main():
         else:
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    spec = S.config2()
+    spec = S.config2() if args.workload == "c3" else S.config5()
     H, W, M = spec.height, spec.width, spec.n_markers
     n_local, n_total = args.frames, args.frames * world
     K, dist, R, T = S.default_camera(spec)
     cam = L.make_camera(K, dist, R, T, 2.0)
-    eng = Engine(H, W, max_markers=512, max_batch=args.batch, device=local_rank)
+    eng = Engine(H, W, max_markers=512 if args.workload == "c3" else 1024, max_batch=args.batch, device=local_rank)
 
     # synthetic frames of this rank's contiguous block, rendered on the device (same bytes as NumPy)
     a, b = D.shard_bounds(n_total, world, rank)
@@ -142,6 +145,8 @@ def main():
         table, _, counts = eng.track_to_3d(frames, xy, 20.0, cam, 5.0)
         table = D.gather_tables(table, n_total)
         disp = eng.displacement(table, 0, 5.0, 50.0, frame_range=(a, b))    # this rank's frames of the gathered table
+        if args.workload == "c5":
+            eng.plane_fit(table[a:b])
         return table, disp, counts
 
     def barrier():
@@ -171,12 +176,15 @@ def main():
     if rank == 0:
         fps = n_total * args.steps / elapsed
         result = {
-            "metric": "frames/sec (track->3D) at 1280x1024, 169 markers", "value": round(fps, 2),
+            "metric": f"frames/sec (track->3D) at {W}x{H}, {M} markers", "value": round(fps, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8+f64", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 3/4: {args.frames} synthetic 1280x1024 gray uint8 frames per GPU "
-                                   f"(13x13 dots, seeded jitter+noise), resident in HBM; fused track->3D table + "
+            "config": {"workload": (f"BASELINE config 3/4: {args.frames} synthetic 1280x1024 gray uint8 frames per GPU "
+                                    f"(13x13 dots, seeded jitter+noise)" if args.workload == "c3" else
+                                    f"BASELINE config 5: {args.frames} synthetic 1920x1200 gray uint8 frames per GPU "
+                                    f"(21x21 dots), plus plane-fit pose") +
+                                   f", resident in HBM; fused track->3D table + "
                                    f"{'RCCL all-gather + ' if world > 1 else ''}last-seen displacement",
                        "frames_per_gpu": args.frames, "internal_batch": args.batch, "markers": M,
                        "tracked_observations": tracked, "xyz_solved": solved,

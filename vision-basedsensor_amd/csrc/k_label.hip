@@ -989,7 +989,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
     __shared__ double bx[1024], by[1024];
     __shared__ u8 unmatched[1024];
     __shared__ int best_of[1024], claim[1024], wsum[4];
-    __shared__ int dup_s, nout_s;
+    __shared__ int dup_s;
     const int n = blockIdx.x, tid = threadIdx.x;
     int status = (int)fstat[n * 8 + 2];
     if (status != 0) {
@@ -1025,7 +1025,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
     // these choices (a contour loses its first choice only to an earlier contour with the same choice).
     // Otherwise (never seen on marker frames) one wave replays the reference's sequential loop.
     for (int i = tid; i < nb_; i += blockDim.x) claim[i] = 0;
-    if (tid == 0) { dup_s = force_seq; nout_s = 0; }
+    if (tid == 0) dup_s = force_seq;
     __syncthreads();
     for (int ci = tid; ci < na; ci += blockDim.x) {
         const double* e = ell + ci * 8;
