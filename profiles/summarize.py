@@ -37,7 +37,8 @@ stage = ("k_threshold", "k_morph", "k_label", "k_finalize")
 per_kernel = {}
 total = 0.0
 for k in stage:
-    n_launch = {"k_morph": 2}.get(k, 1)              # launches per stage call
+    n_launch = max(1, len(fetch[k]) // max(1, len(fetch["k_threshold"])))   # launches per stage call (k_morph 2,
+                                                     # k_label 3 since the hole-fill / relabel modes were added)
     # steady-state launches only (the script runs the stage 4x after one find_markers pass): take the last ones
     fk = sum(fetch[k][-n_launch:]) * 1024.0          # FETCH_SIZE / WRITE_SIZE are in KiB
     wk = sum(write[k][-n_launch:]) * 1024.0

@@ -1,4 +1,5 @@
 // C-ABI of include/vbs.h: workspace management, host-side constant tables, kernel sequencing.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <new>
@@ -162,6 +163,15 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     pack_taps_t<12>(gaussian_taps_q8(bp.taps_a, sa), bp.c4a, bp.nwa, h->taps.a);
     pack_taps_t<VBS_MAX_TAPS_WORDS>(gaussian_taps_q8(bp.taps_b, sb), bp.c4b, bp.nwb, h->taps.b);
     ncc_consts(bp.ncc_l, ts, &h->ncc);
+    std::vector<u32> frags;
+    {   // the int8 matrix-core blur needs taps < 128 that sum to 256 (true for every sigma >= 1)
+        std::vector<int> ka = gaussian_taps_q8(bp.taps_a, sa), kb = gaussian_taps_q8(bp.taps_b, sb);
+        int suma = 0, sumb = 0, mx = 0;
+        for (int v : ka) { suma += v; mx = std::max(mx, v); }
+        for (int v : kb) { sumb += v; mx = std::max(mx, v); }
+        if (suma != 256 || sumb != 256 || mx > 127) { h->err = "internal: blur taps do not fit int8"; return VBS_EINVAL; }
+        frags = bp.small ? blur_mfma_fragments(ka, kb, 3, 0, 3) : blur_mfma_fragments(ka, kb, 5, 1, 3);
+    }
     h->QE = (height + 3) / 4 + bp.nwb - 1;
 
     const size_t B = (size_t)max_batch, HW = (size_t)height * h->WW, HP = (size_t)height * h->P;
@@ -181,6 +191,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(ell, B * max_markers * 8); ALLOC(det64, B * max_markers * 6);
     ALLOC(cnt, B);
     ALLOC(lut, 256);
+    ALLOC(blur_frags, frags.size() / 4);
     ALLOC(umap1, (size_t)height * width * 2); ALLOC(umap2, (size_t)height * width); ALLOC(uwtab, 4096);
 #undef ALLOC
     std::vector<double> rx(width), ry(height);
@@ -199,6 +210,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     HIPCHK(h, hipMemcpy(h->ncc_rx, rx.data(), width * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->ncc_ry, ry.data(), height * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->blur_frags, frags.data(), frags.size() * sizeof(u32), hipMemcpyHostToDevice));
     {
         std::vector<int32_t> wt(4096);
         bilinear_weights_i16(wt.data());

@@ -55,6 +55,7 @@ struct vbs_handle {
     std::string err;
     // ---- device workspace (per internal pass of maxb frames) ----
     u8* gray;          // [maxb][H][P]
+    uint4* blur_frags; // Toeplitz operand fragments of k_blur_mfma (blur_mfma_fragments)
     u32* planes;       // [maxb][4][QE][P]   hi/lo byte planes of both horizontal blurs, row-quad packed
     u64* area_bits;    // [maxb][H][WW]
     u64* mask_bits;    // [maxb][H][WW]
@@ -124,6 +125,8 @@ void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, in
 void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane,
                       hipStream_t s);
 void make_contour_lut(u8 out[256]);
+std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::vector<int>& taps_b, int nk,
+                                     int sa0, int nka);
 void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s);
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s);

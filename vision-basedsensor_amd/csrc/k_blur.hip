@@ -9,6 +9,9 @@
 // with v_dot4_u32_u8 against phase-shifted tap words held in SGPRs.  The 16-bit row sums are split
 // into hi / lo byte planes packed four ROWS to a dword, so the vertical pass can use the same dot4
 // trick down the columns (k_blur_v), finishing with a wave ballot that emits 64 mask bits per row.
+#include <algorithm>
+#include <cstdlib>
+
 #include "common.h"
 
 __device__ __forceinline__ int reflect101(int i, int n) {
@@ -187,6 +190,232 @@ __global__ __launch_bounds__(256) void k_blur_v(const u32* __restrict__ planes, 
     if (lane == 0 && total) atomicAdd(&fstat[n * 8 + 0], total);
 }
 
+// ---- MFMA path -------------------------------------------------------------------------------------
+// A 101-tap separable blur is 140 MACs per pixel per pass: compute-bound on the vector ALU (v_dot4 at half
+// rate), but a banded-Toeplitz matrix product for the matrix cores, and exact there: taps < 128 and
+// p - 128 are int8, v_mfma_i32_32x32x32_i8 accumulates in int32.
+//
+//   horizontal  Hs[y][x]  = sum_k (p[y][xw+k] - 128) * tap[k - x - (LEFT - R)]        (A = image rows from LDS,
+//                                                                                       B = Toeplitz, constant)
+//               H = Hs + 128 * 256                                                      (taps sum to 256)
+//   vertical    V[x][y]   = sum_k Hs_hi[k][x] * tap[..] * 256 + sum_k (Hs_lo[k][x] - 128) * tap[..] + const
+//
+// One wave owns a 32-column strip and slides down it 32 rows per step.  The horizontal result tile (column
+// on the lane, 16 rows in the accumulator registers) is split into its signed high byte and its low byte
+// (offset by 128), packed four rows to a dword and used directly as the A operand of the vertical product
+// (X^T * T^T sums over the accumulator's row index, so no lane movement and no LDS).  The last NK tiles are
+// kept in a register ring, so every horizontal tile is computed once.  The vertical result has the output
+// row on the lane and 16 columns in registers: each lane assembles its row's 16 mask bits from sign bits
+// and the two lane halves are OR-ed into the 32-bit half word of the bit image.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ void pack_tile(const v16i& acc, v4i& hi, v4i& lo) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        u32 t01 = __builtin_amdgcn_perm((u32)acc[4 * q + 1], (u32)acc[4 * q + 0], 0x05010400u);
+        u32 t23 = __builtin_amdgcn_perm((u32)acc[4 * q + 3], (u32)acc[4 * q + 2], 0x05010400u);
+        lo[q] = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+        hi[q] = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
+    }
+}
+
+template <int NK, int SA0, int NKA>
+__global__ __launch_bounds__(256) void k_blur_mfma(const u8* __restrict__ gray, int64_t gstride_n,
+                                                   int64_t gstride_row, const uint4* __restrict__ frags,
+                                                   u64* __restrict__ bits, u8* __restrict__ area_u8,
+                                                   u32* __restrict__ fstat, int H, int W, int WW,
+                                                   int tiles_per_seg, int thresh, int hi_thr) {
+    constexpr int LEFT = 32 * ((NK - 1) / 2);
+    constexpr int ROWB = 128 + 32 * (NK - 1);          // bytes staged per image row
+    constexpr int CH = ROWB / 16;
+    constexpr int STRIDE = ROWB + 16;                  // 68 (52) dwords: 16 consecutive rows hit all banks
+    constexpr int NIT = (32 * CH + 255) / 256;
+    __shared__ __align__(16) u8 tile[2][32 * STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int hh = lane >> 5, m = lane & 31;
+    const int X0 = blockIdx.x * 128, n = blockIdx.z;
+    const int tilesY = (H + 31) / 32;
+    const int tile0 = blockIdx.y * tiles_per_seg;
+    const int ntiles = min(tiles_per_seg, tilesY - tile0);
+    if (ntiles <= 0) return;
+    const int Y0 = tile0 * 32, nsteps = ntiles + NK - 1;
+    const u8* g = gray + (int64_t)n * gstride_n;
+    const bool aligned = ((gstride_row & 3) == 0) && ((gstride_n & 3) == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
+
+    v4i bh[NK], bha[NKA], tv[NK], tva[NKA];
+#pragma unroll
+    for (int s = 0; s < NK; ++s) {
+        uint4 a = frags[(0 * NK + s) * 64 + lane], b = frags[(1 * NK + s) * 64 + lane];
+        bh[s] = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+        tv[s] = v4i{(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+    }
+#pragma unroll
+    for (int s = 0; s < NKA; ++s) {
+        uint4 a = frags[(2 * NK + s) * 64 + lane], b = frags[(2 * NK + NKA + s) * 64 + lane];
+        bha[s] = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+        tva[s] = v4i{(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+    }
+
+    uint4 stage[NIT];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = tid + 256 * it;
+            if (c < 32 * CH) {
+                int row = c / CH, ch = c - row * CH;
+                int yy = reflect101(Y0 - LEFT + 32 * t + row, H);
+                int px = X0 - LEFT + 16 * ch;
+                const u8* src = g + (int64_t)yy * gstride_row;
+                if (aligned && px >= 0 && px + 16 <= W) {
+                    const u32* s32 = reinterpret_cast<const u32*>(src + px);
+                    stage[it] = make_uint4(s32[0], s32[1], s32[2], s32[3]);
+                } else {
+                    u32 w[4];
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        u32 v = 0;
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) v |= (u32)src[reflect101(px + 4 * d + b, W)] << (8 * b);
+                        w[d] = v;
+                    }
+                    stage[it] = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+        }
+    };
+    auto commit = [&](int buf) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int c = tid + 256 * it;
+            if (c < 32 * CH) {
+                int row = c / CH, ch = c - row * CH;
+                uint4 v = stage[it];
+                v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+                *reinterpret_cast<uint4*>(&tile[buf][row * STRIDE + 16 * ch]) = v;
+            }
+        }
+    };
+
+    v4i rLh[NK], rLl[NK], rSh[NK], rSl[NK];            // ring of horizontal tiles: large / small kernel, hi / lo bytes
+#pragma unroll
+    for (int s = 0; s < NK; ++s) rLh[s] = rLl[s] = rSh[s] = rSl[s] = v4i{0, 0, 0, 0};
+    const int xw = X0 + 32 * wave;                     // first column of this wave's strip
+    const u32 colmask = xw + 32 <= W ? 0xFFFFFFFFu : (xw >= W ? 0u : ((1u << (W - xw)) - 1u));
+    const int vconst = 256 * (128 + 32768) + 32768;    // offsets of both passes and the rounding term
+    const u32 span = (u32)(hi_thr - thresh);
+    u32 total = 0;
+
+    fetch(0);
+    commit(0);
+    __syncthreads();
+    for (int t0 = 0; t0 < nsteps; t0 += NK) {
+#pragma unroll
+        for (int u = 0; u < NK; ++u) {
+            const int t = t0 + u;
+            if (t >= nsteps) break;                    // uniform
+            const bool more = t + 1 < nsteps;
+            if (more) fetch(t + 1);
+            const u8* tb = &tile[t & 1][m * STRIDE + 32 * wave + 16 * hh];
+            v4i a[NK];
+#pragma unroll
+            for (int s = 0; s < NK; ++s) a[s] = *reinterpret_cast<const v4i*>(tb + 32 * s);
+            {
+                v16i acc = {};
+#pragma unroll
+                for (int s = 0; s < NK; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], bh[s], acc, 0, 0, 0);
+                pack_tile(acc, rLh[u], rLl[u]);
+            }
+            {
+                v16i acc = {};
+#pragma unroll
+                for (int s = 0; s < NKA; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[SA0 + s], bha[s], acc, 0, 0, 0);
+                pack_tile(acc, rSh[u], rSl[u]);
+            }
+            if (t >= NK - 1) {
+                v16i dh = {}, dl;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dl[i] = vconst;
+#pragma unroll
+                for (int o = 0; o < NK; ++o) {
+                    dh = __builtin_amdgcn_mfma_i32_32x32x32_i8(rLh[(u + 1 + o) % NK], tv[o], dh, 0, 0, 0);
+                    dl = __builtin_amdgcn_mfma_i32_32x32x32_i8(rLl[(u + 1 + o) % NK], tv[o], dl, 0, 0, 0);
+                }
+                v16i eh = {}, el;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) el[i] = vconst;
+#pragma unroll
+                for (int o = 0; o < NKA; ++o) {
+                    eh = __builtin_amdgcn_mfma_i32_32x32x32_i8(rSh[(u + 1 + SA0 + o) % NK], tva[o], eh, 0, 0, 0);
+                    el = __builtin_amdgcn_mfma_i32_32x32x32_i8(rSl[(u + 1 + SA0 + o) % NK], tva[o], el, 0, 0, 0);
+                }
+                u32 sgn = 0;                           // bit i = 1 when register i is OUT of range
+#pragma unroll
+                for (int i = 15; i >= 0; --i) {
+                    u32 b8 = (u32)((dh[i] << 8) + dl[i]) >> 16;          // im_blur_8 (large kernel)
+                    u32 b3 = (u32)((eh[i] << 8) + el[i]) >> 16;          // im_blur_3 (small kernel)
+                    u32 dg = (b8 - b3 + 15u - (u32)thresh) & 255u;       // uint8 arithmetic wraps (:128)
+                    sgn = __builtin_amdgcn_alignbit(sgn, span - dg, 31);
+                }
+                u32 w16 = ~sgn & 0xFFFFu;              // register i = column (i&3) + 8(i>>2) + 4*half
+                u32 w32 = ((w16 & 0xFu) | ((w16 & 0xF0u) << 4) | ((w16 & 0xF00u) << 8) | ((w16 & 0xF000u) << 12)) << (4 * hh);
+                const int y = Y0 + 32 * (t - (NK - 1)) + m;
+                w32 = (y < H) ? (w32 & colmask) : 0u;
+                u32 full = w32 | (u32)__shfl_xor((int)w32, 32);
+                if (hh == 0 && y < H && (xw >> 6) < WW) {
+                    reinterpret_cast<u32*>(bits)[(((int64_t)n * H + y) * WW + (xw >> 6)) * 2 + ((xw >> 5) & 1)] = full;
+                    total += __popc(full);
+                }
+                if (area_u8 && y < H) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        int x = xw + 8 * q + 4 * hh;
+                        u32 nib = (w32 >> (8 * q + 4 * hh)) & 15u;
+                        u8* dst = area_u8 + ((int64_t)n * H + y) * W + x;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            if (x + r < W) dst[r] = ((nib >> r) & 1u) ? 255 : 0;
+                    }
+                }
+            }
+            if (more) commit((t + 1) & 1);
+            __syncthreads();
+        }
+    }
+#pragma unroll
+    for (int off = 32; off; off >>= 1) total += __shfl_xor((int)total, off);
+    if (lane == 0 && total) atomicAdd(&fstat[n * 8 + 0], total);
+}
+
+// Toeplitz operand fragments in the lane layout of v_mfma_i32_32x32x32_i8 (lane = 32*half + column; a
+// lane's 16 bytes pair with the other operand's 16 bytes of the same half, so only the pairing matters):
+//   horizontal (B operand, k = pixel of the staged window): byte e of half h is window pixel 32s + 16h + e
+//   vertical   (B operand, k = row of ring tile o):         byte 4q + r of half h is tile row 8q + 4h + r
+std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::vector<int>& taps_b, int nk,
+                                     int sa0, int nka) {
+    const int left = 32 * ((nk - 1) / 2);
+    std::vector<u32> out((size_t)(2 * nk + 2 * nka) * 64 * 4, 0);
+    auto fill = [&](int frag, const std::vector<int>& taps, int kbase, bool vertical) {
+        const int R = (int)taps.size() / 2;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int h = lane >> 5, col = lane & 31;
+            for (int e = 0; e < 16; ++e) {
+                int k = kbase + (vertical ? 8 * (e >> 2) + 4 * h + (e & 3) : 16 * h + e);
+                int idx = k - col - (left - R);
+                u32 v = (idx >= 0 && idx <= 2 * R) ? (u32)taps[idx] : 0u;
+                out[((size_t)frag * 64 + lane) * 4 + (e >> 2)] |= v << (8 * (e & 3));
+            }
+        }
+    };
+    for (int s = 0; s < nk; ++s) { fill(0 * nk + s, taps_b, 32 * s, false); fill(1 * nk + s, taps_b, 32 * s, true); }
+    for (int s = 0; s < nka; ++s) {
+        fill(2 * nk + s, taps_a, 32 * (sa0 + s), false);
+        fill(2 * nk + nka + s, taps_a, 32 * (sa0 + s), true);
+    }
+    return out;
+}
+
+
 void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
                  int64_t stride_row, hipStream_t s) {
     dim3 grid((h->P / 4 + 255) / 256, h->H, nb);
@@ -196,6 +425,20 @@ void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t 
 
 void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,
                  u8* area_u8, hipStream_t s) {
+    if (!getenv("VBS_BLUR_DOT4")) {
+        const int gx = (h->P + 127) / 128, tilesY = (h->H + 31) / 32;
+        int nseg = std::min(tilesY, std::max(1, (1024 + gx * nb - 1) / (gx * nb)));     // few frames: split columns
+        const int tps = (tilesY + nseg - 1) / nseg;
+        nseg = (tilesY + tps - 1) / tps;
+        dim3 grid(gx, nseg, nb);
+        if (!h->bp.small)
+            VBS_LAUNCH(h, s, "k_blur_mfma", (k_blur_mfma<5, 1, 3>), grid, dim3(256), 0, s, gray, gstride_n, gstride_row,
+                       h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, h->bp.thresh, h->bp.hi);
+        else
+            VBS_LAUNCH(h, s, "k_blur_mfma", (k_blur_mfma<3, 0, 3>), grid, dim3(256), 0, s, gray, gstride_n, gstride_row,
+                       h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, h->bp.thresh, h->bp.hi);
+        return;
+    }
     dim3 gh((h->P + 255) / 256, h->QE, nb);
     dim3 gv(h->WW, (h->H + 31) / 32, nb);
     if (!h->bp.small) {
