@@ -220,12 +220,25 @@ __device__ __forceinline__ void pack_tile(const v16i& acc, v4i& hi, v4i& lo) {
     }
 }
 
-template <int NK, int SA0, int NKA>
-__global__ __launch_bounds__(256) void k_blur_mfma(const u8* __restrict__ gray, int64_t gstride_n,
-                                                   int64_t gstride_row, const uint4* __restrict__ frags,
-                                                   u64* __restrict__ bits, u8* __restrict__ area_u8,
-                                                   u32* __restrict__ fstat, int H, int W, int WW,
-                                                   int tiles_per_seg, int thresh, int hi_thr) {
+// reflect-101 bytes of one 16-byte chunk that touches the image border or is not dword aligned
+__device__ __forceinline__ uint4 fetch_chunk_slow(const u8* src, int px, int W) {
+    u32 w[4];
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        u32 v = 0;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) v |= (u32)src[reflect101(px + 4 * d + b, W)] << (8 * b);
+        w[d] = v;
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <int NK, int SA0, int NKA, bool U8OUT>
+__global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gray, int64_t gstride_n,
+                                                      int64_t gstride_row, const uint4* __restrict__ frags,
+                                                      u64* __restrict__ bits, u8* __restrict__ area_u8,
+                                                      u32* __restrict__ fstat, int H, int W, int WW,
+                                                      int tiles_per_seg, int thresh, int hi_thr) {
     constexpr int LEFT = 32 * ((NK - 1) / 2);
     constexpr int ROWB = 128 + 32 * (NK - 1);          // bytes staged per image row
     constexpr int CH = ROWB / 16;
@@ -257,42 +270,43 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const u8* __restrict__ gray, 
         tva[s] = v4i{(int)b.x, (int)b.y, (int)b.z, (int)b.w};
     }
 
+    // this thread's chunks of the staged tile: row, pixel offset, LDS offset; fast = plain 16-byte load
+    int c_row[NIT], c_px[NIT], c_lds[NIT];
+    bool c_on[NIT], c_fast[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        int c = tid + 256 * it;
+        c_on[it] = c < 32 * CH;
+        c_row[it] = c / CH;
+        int ch = c - c_row[it] * CH;
+        c_px[it] = X0 - LEFT + 16 * ch;
+        c_lds[it] = c_row[it] * STRIDE + 16 * ch;
+        c_fast[it] = aligned && c_px[it] >= 0 && c_px[it] + 16 <= W;
+    }
+    // plain chunks are loaded a step ahead into registers and written to LDS at the end of the step; border chunks
+    // (few, only in the first / last workgroup of a row) are gathered byte by byte at commit time
     uint4 stage[NIT];
+    auto row_of = [&](int t, int it) { return g + (int64_t)reflect101(Y0 - LEFT + 32 * t + c_row[it], H) * gstride_row; };
     auto fetch = [&](int t) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            int c = tid + 256 * it;
-            if (c < 32 * CH) {
-                int row = c / CH, ch = c - row * CH;
-                int yy = reflect101(Y0 - LEFT + 32 * t + row, H);
-                int px = X0 - LEFT + 16 * ch;
-                const u8* src = g + (int64_t)yy * gstride_row;
-                if (aligned && px >= 0 && px + 16 <= W) {
-                    const u32* s32 = reinterpret_cast<const u32*>(src + px);
-                    stage[it] = make_uint4(s32[0], s32[1], s32[2], s32[3]);
-                } else {
-                    u32 w[4];
-#pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        u32 v = 0;
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) v |= (u32)src[reflect101(px + 4 * d + b, W)] << (8 * b);
-                        w[d] = v;
-                    }
-                    stage[it] = make_uint4(w[0], w[1], w[2], w[3]);
-                }
+        for (int it = 0; it < NIT; ++it)
+            if (c_on[it] && c_fast[it]) {
+                const u32* s32 = reinterpret_cast<const u32*>(row_of(t, it) + c_px[it]);
+                stage[it] = make_uint4(s32[0], s32[1], s32[2], s32[3]);
             }
-        }
     };
-    auto commit = [&](int buf) {
+    auto commit = [&](int t, int buf) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            int c = tid + 256 * it;
-            if (c < 32 * CH) {
-                int row = c / CH, ch = c - row * CH;
+            if (!c_on[it]) continue;
+            if (c_fast[it]) {
                 uint4 v = stage[it];
                 v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-                *reinterpret_cast<uint4*>(&tile[buf][row * STRIDE + 16 * ch]) = v;
+                *reinterpret_cast<uint4*>(&tile[buf][c_lds[it]]) = v;
+            } else {
+                uint4 v = fetch_chunk_slow(row_of(t, it), c_px[it], W);
+                v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
+                *reinterpret_cast<uint4*>(&tile[buf][c_lds[it]]) = v;
             }
         }
     };
@@ -302,12 +316,18 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const u8* __restrict__ gray, 
     for (int s = 0; s < NK; ++s) rLh[s] = rLl[s] = rSh[s] = rSl[s] = v4i{0, 0, 0, 0};
     const int xw = X0 + 32 * wave;                     // first column of this wave's strip
     const u32 colmask = xw + 32 <= W ? 0xFFFFFFFFu : (xw >= W ? 0u : ((1u << (W - xw)) - 1u));
-    const int vconst = 256 * (128 + 32768) + 32768;    // offsets of both passes and the rounding term
+    // sum tap*H = 256*Dhi + Dlo + 256*(128 + 32768); + 2^15 to round; the large kernel also carries
+    // (15 - thresh) << 16 so that its high word is im_blur_8 + 15 - thresh (mod 2^16)
+    const int k3 = 256 * (128 + 32768) + 32768;
+    const int k8 = __builtin_amdgcn_readfirstlane(k3 + (15 - thresh) * 65536);
     const u32 span = (u32)(hi_thr - thresh);
     u32 total = 0;
 
     fetch(0);
-    commit(0);
+    commit(0, 0);
+    // every load issued so far (the operand fragments above all) has landed: without this the loop's first uses
+    // keep a vmcnt wait that, in steady state, stalls on the prefetch of the next tile instead
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
     __syncthreads();
     for (int t0 = 0; t0 < nsteps; t0 += NK) {
 #pragma unroll
@@ -333,28 +353,23 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const u8* __restrict__ gray, 
                 pack_tile(acc, rSh[u], rSl[u]);
             }
             if (t >= NK - 1) {
-                v16i dh = {}, dl;
+                v16i d8 = {}, d3 = {};
 #pragma unroll
-                for (int i = 0; i < 16; ++i) dl[i] = vconst;
+                for (int o = 0; o < NK; ++o) d8 = __builtin_amdgcn_mfma_i32_32x32x32_i8(rLh[(u + 1 + o) % NK], tv[o], d8, 0, 0, 0);
 #pragma unroll
-                for (int o = 0; o < NK; ++o) {
-                    dh = __builtin_amdgcn_mfma_i32_32x32x32_i8(rLh[(u + 1 + o) % NK], tv[o], dh, 0, 0, 0);
-                    dl = __builtin_amdgcn_mfma_i32_32x32x32_i8(rLl[(u + 1 + o) % NK], tv[o], dl, 0, 0, 0);
-                }
-                v16i eh = {}, el;
+                for (int o = 0; o < NKA; ++o) d3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(rSh[(u + 1 + SA0 + o) % NK], tva[o], d3, 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) el[i] = vconst;
+                for (int i = 0; i < 16; ++i) d8[i] = (d8[i] << 8) + k8;
 #pragma unroll
-                for (int o = 0; o < NKA; ++o) {
-                    eh = __builtin_amdgcn_mfma_i32_32x32x32_i8(rSh[(u + 1 + SA0 + o) % NK], tva[o], eh, 0, 0, 0);
-                    el = __builtin_amdgcn_mfma_i32_32x32x32_i8(rSl[(u + 1 + SA0 + o) % NK], tva[o], el, 0, 0, 0);
-                }
+                for (int o = 0; o < NK; ++o) d8 = __builtin_amdgcn_mfma_i32_32x32x32_i8(rLl[(u + 1 + o) % NK], tv[o], d8, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) d3[i] = (d3[i] << 8) + k3;
+#pragma unroll
+                for (int o = 0; o < NKA; ++o) d3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(rSl[(u + 1 + SA0 + o) % NK], tva[o], d3, 0, 0, 0);
                 u32 sgn = 0;                           // bit i = 1 when register i is OUT of range
 #pragma unroll
                 for (int i = 15; i >= 0; --i) {
-                    u32 b8 = (u32)((dh[i] << 8) + dl[i]) >> 16;          // im_blur_8 (large kernel)
-                    u32 b3 = (u32)((eh[i] << 8) + el[i]) >> 16;          // im_blur_3 (small kernel)
-                    u32 dg = (b8 - b3 + 15u - (u32)thresh) & 255u;       // uint8 arithmetic wraps (:128)
+                    u32 dg = (((u32)d8[i] >> 16) - ((u32)d3[i] >> 16)) & 255u;   // (blur_8 - blur_3 + 15 - thresh) mod 256 (:128)
                     sgn = __builtin_amdgcn_alignbit(sgn, span - dg, 31);
                 }
                 u32 w16 = ~sgn & 0xFFFFu;              // register i = column (i&3) + 8(i>>2) + 4*half
@@ -366,19 +381,18 @@ __global__ __launch_bounds__(256) void k_blur_mfma(const u8* __restrict__ gray, 
                     reinterpret_cast<u32*>(bits)[(((int64_t)n * H + y) * WW + (xw >> 6)) * 2 + ((xw >> 5) & 1)] = full;
                     total += __popc(full);
                 }
-                if (area_u8 && y < H) {
-#pragma unroll
+                if (U8OUT && y < H) {
+#pragma unroll 1
                     for (int q = 0; q < 4; ++q) {
                         int x = xw + 8 * q + 4 * hh;
                         u32 nib = (w32 >> (8 * q + 4 * hh)) & 15u;
                         u8* dst = area_u8 + ((int64_t)n * H + y) * W + x;
-#pragma unroll
                         for (int r = 0; r < 4; ++r)
                             if (x + r < W) dst[r] = ((nib >> r) & 1u) ? 255 : 0;
                     }
                 }
             }
-            if (more) commit((t + 1) & 1);
+            if (more) commit(t + 1, (t + 1) & 1);
             __syncthreads();
         }
     }
@@ -431,12 +445,13 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
         const int tps = (tilesY + nseg - 1) / nseg;
         nseg = (tilesY + tps - 1) / tps;
         dim3 grid(gx, nseg, nb);
-        if (!h->bp.small)
-            VBS_LAUNCH(h, s, "k_blur_mfma", (k_blur_mfma<5, 1, 3>), grid, dim3(256), 0, s, gray, gstride_n, gstride_row,
-                       h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, h->bp.thresh, h->bp.hi);
-        else
-            VBS_LAUNCH(h, s, "k_blur_mfma", (k_blur_mfma<3, 0, 3>), grid, dim3(256), 0, s, gray, gstride_n, gstride_row,
-                       h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, h->bp.thresh, h->bp.hi);
+#define BLUR_GO(NK, SA0, NKA, U8)                                                                            \
+        VBS_LAUNCH(h, s, "k_blur_mfma", (k_blur_mfma<NK, SA0, NKA, U8>), grid, dim3(256), 0, s, gray, gstride_n, \
+                   gstride_row, h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps,          \
+                   h->bp.thresh, h->bp.hi)
+        if (!h->bp.small) { if (area_u8) BLUR_GO(5, 1, 3, true); else BLUR_GO(5, 1, 3, false); }
+        else { if (area_u8) BLUR_GO(3, 0, 3, true); else BLUR_GO(3, 0, 3, false); }
+#undef BLUR_GO
         return;
     }
     dim3 gh((h->P + 255) / 256, h->QE, nb);
