@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
                                                       int64_t gstride_row, const uint4* __restrict__ frags,
                                                       u64* __restrict__ bits, u8* __restrict__ area_u8,
                                                       u32* __restrict__ fstat, int H, int W, int WW,
-                                                      int tiles_per_seg, int thresh, int hi_thr) {
+                                                      int tiles_per_seg, int k3, int k8, int span_i) {
     constexpr int LEFT = 32 * ((NK - 1) / 2);
     constexpr int ROWB = 128 + 32 * (NK - 1);          // bytes staged per image row
     constexpr int CH = ROWB / 16;
@@ -318,9 +318,8 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
     const u32 colmask = xw + 32 <= W ? 0xFFFFFFFFu : (xw >= W ? 0u : ((1u << (W - xw)) - 1u));
     // sum tap*H = 256*Dhi + Dlo + 256*(128 + 32768); + 2^15 to round; the large kernel also carries
     // (15 - thresh) << 16 so that its high word is im_blur_8 + 15 - thresh (mod 2^16)
-    const int k3 = 256 * (128 + 32768) + 32768;
-    const int k8 = __builtin_amdgcn_readfirstlane(k3 + (15 - thresh) * 65536);
-    const u32 span = (u32)(hi_thr - thresh);
+    // (host computes k3 = 256*(128+32768) + 2^15, k8 = k3 + (15 - thresh) << 16, span = hi - thresh)
+    const u32 span = (u32)span_i;
     u32 total = 0;
 
     fetch(0);
@@ -445,10 +444,11 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
         const int tps = (tilesY + nseg - 1) / nseg;
         nseg = (tilesY + tps - 1) / tps;
         dim3 grid(gx, nseg, nb);
+        const int k3 = 256 * (128 + 32768) + 32768, k8 = k3 + (15 - h->bp.thresh) * 65536;
 #define BLUR_GO(NK, SA0, NKA, U8)                                                                            \
         VBS_LAUNCH(h, s, "k_blur_mfma", (k_blur_mfma<NK, SA0, NKA, U8>), grid, dim3(256), 0, s, gray, gstride_n, \
-                   gstride_row, h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps,          \
-                   h->bp.thresh, h->bp.hi)
+                   gstride_row, h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8,  \
+                   h->bp.hi - h->bp.thresh)
         if (!h->bp.small) { if (area_u8) BLUR_GO(5, 1, 3, true); else BLUR_GO(5, 1, 3, false); }
         else { if (area_u8) BLUR_GO(3, 0, 3, true); else BLUR_GO(3, 0, 3, false); }
 #undef BLUR_GO
