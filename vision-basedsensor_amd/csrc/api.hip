@@ -192,6 +192,9 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(cnt, B);
     ALLOC(lut, 256);
     ALLOC(blur_frags, frags.size() / 4);
+    std::vector<u32> nfrags = ncc_mfma_fragments(h->ncc, bp.ncc_l);
+    ALLOC(ncc_frags, nfrags.size() / 4);
+    ALLOC(ncc_theta, B * ((size_t)bp.ncc_l * bp.ncc_l + 1));
     ALLOC(umap1, (size_t)height * width * 2); ALLOC(umap2, (size_t)height * width); ALLOC(uwtab, 4096);
 #undef ALLOC
     std::vector<double> rx(width), ry(height);
@@ -211,6 +214,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     HIPCHK(h, hipMemcpy(h->ncc_ry, ry.data(), height * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->blur_frags, frags.data(), frags.size() * sizeof(u32), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->ncc_frags, nfrags.data(), nfrags.size() * sizeof(u32), hipMemcpyHostToDevice));
     {
         std::vector<int32_t> wt(4096);
         bilinear_weights_i16(wt.data());

@@ -63,6 +63,8 @@ struct vbs_handle {
     u64* open_bits;    // [maxb][H][WW]
     double* ncc_rx;    // [W]  sum of g over the in-image part of the window (columns)
     double* ncc_ry;    // [H]
+    float* ncc_theta;  // [maxb][l*l + 1]  decision threshold on 2^20 G by window count (k_ncc_theta)
+    uint4* ncc_frags;  // Toeplitz operand fragments of k_ncc_mfma (ncc_mfma_fragments)
     u32* fstat;        // [maxb][8]  0: area popcount, 1: ambiguous ncc pixels, 2: status
     u32* wbase;        // [maxb][2][H*WW]   first node index of each word
     u32* node_pos;     // [maxb][2][RUN_CAP]  y*W + x0 of each run
@@ -125,6 +127,7 @@ void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, in
 void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane,
                       hipStream_t s);
 void make_contour_lut(u8 out[256]);
+std::vector<u32> ncc_mfma_fragments(const NccConst& nc, int l);
 std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::vector<int>& taps_b, int nk,
                                      int sa0, int nka);
 void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,

@@ -10,7 +10,9 @@
 //     var = 255^2 c - 2 mu 255 c + n mu^2 - (255 c - n mu)^2 / l^2
 //     mask = num / sqrt(var * T2) > 0.1   <=>   var > 0, num > 0, num^2 > 0.01 var T2
 // k_ncc: both passes in one kernel, the horizontal one from bit runs into LDS (no float64 image in HBM).
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "common.h"
 
@@ -223,6 +225,236 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
     if (nexact) atomicAdd(&fstat[n * 8 + 3], nexact);
 }
 
+// ---- matrix-core path ------------------------------------------------------------------------------
+// G and the window count c are banded-Toeplitz products, like the blurs (k_blur.hip), here in float16 operands
+// with float32 accumulation on v_mfma_f32_16x16x32_f16:
+//   horizontal  h[y][x]  = sum_k b[y][xw+k] * w[k - x]          A = image bits expanded to 0.0 / 1.0 (exact),
+//               ch[y][x] = sum_k b[y][xw+k] * 1[k - x]          B = Toeplitz of w = 1024 g, split w = whi + wlo
+//   vertical    G[y][x]  = sum_k w[k - y] * h[yw+k][x]           A = the same Toeplitz fragments, B = h split into
+//               c[y][x]  = sum_k 1[k - y] * ch[yw+k][x]          float16 hi + lo (products hi*hi, hi*lo, lo*hi)
+// One wave owns a 16-column strip and slides down it 16 rows per step; horizontal tiles go through a per-wave
+// LDS ring stored column-major, so a vertical B operand is one 16-byte read.  The result is a FILTER exactly as
+// before: relative error of G is below 2^-16 (dropped lo*lo, float16 lo roundings, float32 accumulation of <= 300
+// positive terms), the decision is taken against theta(c) (1 +- 2e-5) and the undecided pixels recompute G in
+// float64 from the bits.  For windows inside the image the decision only depends on (c, G): num > sqrt(rhs) <=>
+// G > theta(c), a per-frame table of l*l + 1 entries built by k_ncc_theta; border tiles evaluate theta per pixel.
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+#define NCC_WSCALE 1024.0                               // weights are scaled so that every wlo is a normal float16
+#define NCC_REL 2e-5f
+#define NCC_ABS 1e-3f                                   // in units of G * 2^20: far below any theta with c >= 1
+
+// theta(c) for full windows: the smallest 2^20 G that makes num > 0 and num^2 > rhs (+inf where var <= 0)
+__device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, double mu, const NccConst& nc) {
+    double sum_I = 255.0 * c;
+    double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
+    double s1 = sum_I - nn * mu;
+    double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
+    double var = s2 - s1 * s1 * nc.inv_l2;
+    double rhs = nc.thr2 * var * nc.T2;
+    if (!(var > 0.0)) return (double)INFINITY;
+    // an empty window has G = 0 exactly on both paths (var is then 0 up to rounding): decide it here, once
+    if (c == 0.0) return (rest > 0.0 && rest * rest > rhs) ? -(double)INFINITY : (double)INFINITY;
+    return (sqrt(rhs) - rest) * (NCC_WSCALE * NCC_WSCALE / 255.0);
+}
+
+__global__ __launch_bounds__(256) void k_ncc_theta(const u32* __restrict__ fstat, const double* __restrict__ rx,
+                                                   const double* __restrict__ ry, float* __restrict__ theta,
+                                                   int H, int W, int l2, int lo, NccConst nc) {
+    const int n = blockIdx.x;
+    const double mu = (double)(255ull * (u64)fstat[n * 8 + 0]) / (double)((int64_t)H * W);
+    const double full_t = ry[min(max(-lo, 0), H - 1)] * rx[min(max(-lo, 0), W - 1)];
+    for (int c = threadIdx.x; c <= l2; c += 256)
+        theta[(int64_t)n * (l2 + 1) + c] = (float)ncc_theta((double)c, nc.l2, full_t, mu, nc);
+}
+
+template <int L, int LO>
+__global__ __launch_bounds__(256, 2) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
+                                                     const double* __restrict__ ry, const float* __restrict__ theta,
+                                                     const uint4* __restrict__ wfrag, u64* __restrict__ mbits,
+                                                     u8* __restrict__ mask_u8, u32* __restrict__ fstat, int H, int W,
+                                                     int WW, int tiles_per_seg, NccConst nc) {
+    constexpr int HI = L - 1 + LO;
+    constexpr int NT = (16 + L - 1 + 15) / 16;          // horizontal tiles under one output tile
+    constexpr int NKS = (16 * NT + 31) / 32;            // k-steps of 32
+    constexpr int RING = 16 * NT;
+    constexpr int RSTR = RING + 8;                      // halves per ring column (+16 B: conflict-free 16-byte reads)
+    constexpr int L2 = L * L;
+    __shared__ __align__(16) uint4 lut[256];
+    __shared__ float th_s[L2 + 1];
+    __shared__ __align__(16) _Float16 ring[4][3][16 * RSTR];
+    __shared__ double cg[L + 1];
+    __shared__ double gsh[L];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int g = lane >> 4, q = lane & 15;
+    const int n = blockIdx.z;
+    const int tilesY = (H + 15) / 16;
+    const int tile0 = blockIdx.y * tiles_per_seg;
+    const int ntiles = min(tiles_per_seg, tilesY - tile0);
+    if (ntiles <= 0) return;
+    const int Y0 = tile0 * 16, nsteps = ntiles + NT - 1;
+    const int xw = blockIdx.x * 64 + 16 * wave;         // first column of this wave's strip
+    const u64* fbits = bits + (int64_t)n * H * WW;
+    {
+        u32 w[4];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) w[d] = (((u32)tid >> (2 * d)) & 1u ? 0x3C00u : 0u) | (((u32)tid >> (2 * d + 1)) & 1u ? 0x3C000000u : 0u);
+        lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    for (int i = tid; i <= L2; i += 256) th_s[i] = theta[(int64_t)n * (L2 + 1) + i];
+    for (int i = tid; i <= L; i += 256) cg[i] = nc.cg[i];
+    for (int i = tid; i < L; i += 256) gsh[i] = nc.g[i];
+    for (int i = lane; i < 3 * 16 * RSTR / 8; i += 64) reinterpret_cast<uint4*>(&ring[wave][0][0])[i] = make_uint4(0, 0, 0, 0);
+    h8 whi[NKS], wlo[NKS], one[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) {
+        uint4 a = wfrag[(0 * NKS + s) * 64 + lane], b = wfrag[(1 * NKS + s) * 64 + lane], c = wfrag[(2 * NKS + s) * 64 + lane];
+        whi[s] = __builtin_bit_cast(h8, a);
+        wlo[s] = __builtin_bit_cast(h8, b);
+        one[s] = __builtin_bit_cast(h8, c);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                 // operand fragments landed (see k_blur_mfma)
+    __syncthreads();
+
+    const double mu = (double)(255ull * (u64)fstat[n * 8 + 0]) / (double)((int64_t)H * W);
+    _Float16* rhi = &ring[wave][0][q * RSTR];
+    _Float16* rlo = &ring[wave][1][q * RSTR];
+    _Float16* rct = &ring[wave][2][q * RSTR];
+    u32 amb = 0, nexact = 0;
+    // row bits of the next horizontal tile: lane (g, q) holds row q's window [xw + LO, xw + LO + 32 NKS)
+    auto load_rows = [&](int t, u64& w0, u64& w1) {
+        const int y = Y0 + LO + 16 * t + q;
+        w0 = w1 = 0;
+        if (y >= 0 && y < H) {
+            const u64* row = fbits + (int64_t)y * WW;
+            w0 = load_bits(row, WW, xw + LO);
+            if (NKS > 2) w1 = load_bits(row, WW, xw + LO + 64);
+        }
+    };
+    u64 nw0, nw1;
+    load_rows(0, nw0, nw1);
+    for (int t = 0; t < nsteps; ++t) {
+        const u64 w0 = nw0, w1 = nw1;
+        if (t + 1 < nsteps) load_rows(t + 1, nw0, nw1);
+        // ---- horizontal tile t ----
+        f4 ah = {0, 0, 0, 0}, ac = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            const u32 byte = (u32)((s < 2 ? w0 >> (32 * s + 8 * g) : w1 >> (32 * (s - 2) + 8 * g)) & 255ull);
+            const h8 a = __builtin_bit_cast(h8, lut[byte]);
+            ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, whi[s], ah, 0, 0, 0);
+            ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wlo[s], ah, 0, 0, 0);
+            ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, one[s], ac, 0, 0, 0);
+        }
+        {
+            h4 vh, vl, vc;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                vh[r] = (_Float16)ah[r];
+                vl[r] = (_Float16)(ah[r] - (float)vh[r]);
+                vc[r] = (_Float16)ac[r];
+            }
+            const int ro = 16 * (t % NT) + 4 * g;
+            *reinterpret_cast<h4*>(rhi + ro) = vh;
+            *reinterpret_cast<h4*>(rlo + ro) = vl;
+            *reinterpret_cast<h4*>(rct + ro) = vc;
+        }
+        if (t < NT - 1) continue;
+        // ---- vertical: output tile rows yo .. yo + 15 from ring tiles t-NT+1 .. t ----
+        const int yo = Y0 + 16 * (t - (NT - 1));
+        const int base = 16 * ((t - (NT - 1)) % NT);
+        f4 G = {0, 0, 0, 0}, C = {0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) {
+            int ro = base + 32 * s + 8 * g;
+            ro = ro >= RING ? ro - RING : ro;
+            ro = ro >= RING ? ro - RING : ro;
+            const h8 bh = *reinterpret_cast<const h8*>(rhi + ro);
+            const h8 bl = *reinterpret_cast<const h8*>(rlo + ro);
+            const h8 bc = *reinterpret_cast<const h8*>(rct + ro);
+            G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bh, G, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bl, G, 0, 0, 0);
+            G = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[s], bh, G, 0, 0, 0);
+            C = __builtin_amdgcn_mfma_f32_16x16x32_f16(one[s], bc, C, 0, 0, 0);
+        }
+        // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
+        const int x = xw + q;
+        const bool interior = (yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
+        u64 words[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int y = yo + 4 * g + r;
+            const bool valid = (y < H) && (x < W);
+            const int ci = (int)C[r];
+            float th;
+            if (interior) {
+                th = th_s[min(ci, L2)];
+            } else {
+                int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
+                int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
+                th = valid ? (float)ncc_theta((double)ci, (double)(ny * nx), ry[min(y, H - 1)] * rx[min(x, W - 1)], mu, nc) : INFINITY;
+            }
+            bool pred = valid && (G[r] > __builtin_fmaf(th, 1.0f + NCC_REL, NCC_ABS));
+            const bool undecided = valid && !pred && !(G[r] < __builtin_fmaf(th, 1.0f - NCC_REL, -NCC_ABS));
+            if (undecided) {                             // rare: exact float64 G straight from the bits
+                int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
+                int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
+                double nn = (double)(ny * nx), sum_t = ry[y] * rx[x];
+                double sum_I = 255.0 * (double)ci;
+                double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
+                double s1 = sum_I - nn * mu;
+                double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
+                double var = s2 - s1 * s1 * nc.inv_l2;
+                double rhs = nc.thr2 * var * nc.T2;
+                if (var > 0.0) {
+                    const double Ge = ncc_exact_G<L, LO>(fbits, H, WW, y, x, cg, gsh);
+                    double num = 255.0 * Ge + rest;
+                    pred = (num > 0.0) && (num * num > rhs);
+                    if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
+                    nexact++;
+                }
+            }
+            words[r] = __ballot(pred);
+            if (mask_u8 && valid) mask_u8[((int64_t)n * H + y) * W + x] = pred ? 1 : 0;
+        }
+        if (lane < 16) {                                 // lane = row of the tile: 16 mask bits of this strip
+            const int y = yo + lane;
+            u64 wsel = (lane & 3) == 0 ? words[0] : (lane & 3) == 1 ? words[1] : (lane & 3) == 2 ? words[2] : words[3];
+            if (y < H)
+                reinterpret_cast<unsigned short*>(mbits)[(((int64_t)n * H + y) * WW + blockIdx.x) * 4 + wave] =
+                    (unsigned short)(wsel >> (16 * (lane >> 2)));
+        }
+    }
+    if (amb) atomicAdd(&fstat[n * 8 + 1], amb);
+    if (nexact) atomicAdd(&fstat[n * 8 + 3], nexact);
+}
+
+// Toeplitz fragments of k_ncc_mfma in the lane layout of v_mfma_f32_16x16x32_f16 (lane = 16 g + column, element j
+// pairs with the other operand's element j of the same g): weight index (32 s + 8 g + j) - column.  The same
+// fragments serve as B operand of the horizontal and as A operand of the vertical product.
+std::vector<u32> ncc_mfma_fragments(const NccConst& nc, int l) {
+    const int nt = (16 + l - 1 + 15) / 16, nks = (16 * nt + 31) / 32;
+    std::vector<u32> out((size_t)3 * nks * 64 * 4, 0);
+    auto bits16 = [](double v) { _Float16 hv = (_Float16)v; unsigned short b; memcpy(&b, &hv, 2); return (u32)b; };
+    for (int kind = 0; kind < 3; ++kind)
+        for (int s = 0; s < nks; ++s)
+            for (int lane = 0; lane < 64; ++lane) {
+                const int g = lane >> 4, col = lane & 15;
+                for (int j = 0; j < 8; ++j) {
+                    const int idx = 32 * s + 8 * g + j - col;
+                    u32 v = 0;
+                    if (idx >= 0 && idx < l) {
+                        const double w = nc.g[idx] * NCC_WSCALE;
+                        const _Float16 hi = (_Float16)w;
+                        v = kind == 0 ? bits16((double)hi) : kind == 1 ? bits16(w - (double)hi) : bits16(1.0);
+                    }
+                    out[((size_t)(kind * nks + s) * 64 + lane) * 4 + (j >> 1)] |= v << (16 * (j & 1));
+                }
+            }
+    return out;
+}
+
 // area popcount per frame (feeds the global mean of _normxcorr2 :153) when the bits did not come from k_blur_v
 __global__ __launch_bounds__(256) void k_popcount(const u64* __restrict__ bits, u32* __restrict__ fstat, int NW) {
     __shared__ u32 part[4];
@@ -240,6 +472,24 @@ void launch_popcount(vbs_handle* h, int nb, hipStream_t s) {
 }
 
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s) {
+    if (!ncc_out && !getenv("VBS_NCC_VALU")) {
+        const int l = h->bp.ncc_l, tilesY = (h->H + 15) / 16;
+        VBS_LAUNCH(h, s, "k_ncc_theta", k_ncc_theta, dim3(nb), dim3(256), 0, s, h->fstat, h->ncc_rx, h->ncc_ry,
+                   h->ncc_theta, h->H, h->W, l * l, h->bp.ncc_lo, h->ncc);
+        int nseg = std::min(tilesY, std::max(1, (2048 + h->WW * nb - 1) / (h->WW * nb)));   // few frames: split columns
+        const int tps = (tilesY + nseg - 1) / nseg;
+        nseg = (tilesY + tps - 1) / tps;
+        dim3 grid(h->WW, nseg, nb);
+        if (!h->bp.small)
+            VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
+                       h->ncc_ry, h->ncc_theta, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
+                       h->ncc);
+        else
+            VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
+                       h->ncc_ry, h->ncc_theta, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
+                       h->ncc);
+        return;
+    }
     dim3 grid(h->WW, (h->H + 63) / 64, nb);
     const int stop = getenv("VBS_NCC_STOP") ? atoi(getenv("VBS_NCC_STOP")) : 0;   // debug: phase timing
     if (!h->bp.small) {
