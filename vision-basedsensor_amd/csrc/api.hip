@@ -194,7 +194,6 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(blur_frags, frags.size() / 4);
     std::vector<u32> nfrags = ncc_mfma_fragments(h->ncc, bp.ncc_l);
     ALLOC(ncc_frags, nfrags.size() / 4);
-    ALLOC(ncc_theta, B * ((size_t)bp.ncc_l * bp.ncc_l + 1));
     ALLOC(umap1, (size_t)height * width * 2); ALLOC(umap2, (size_t)height * width); ALLOC(uwtab, 4096);
 #undef ALLOC
     std::vector<double> rx(width), ry(height);

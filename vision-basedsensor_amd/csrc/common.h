@@ -63,7 +63,6 @@ struct vbs_handle {
     u64* open_bits;    // [maxb][H][WW]
     double* ncc_rx;    // [W]  sum of g over the in-image part of the window (columns)
     double* ncc_ry;    // [H]
-    float* ncc_theta;  // [maxb][l*l + 1]  decision threshold on 2^20 G by window count (k_ncc_theta)
     uint4* ncc_frags;  // Toeplitz operand fragments of k_ncc_mfma (ncc_mfma_fragments)
     u32* fstat;        // [maxb][8]  0: area popcount, 1: ambiguous ncc pixels, 2: status
     u32* wbase;        // [maxb][2][H*WW]   first node index of each word

@@ -234,10 +234,14 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
 //               c[y][x]  = sum_k 1[k - y] * ch[yw+k][x]          float16 hi + lo (products hi*hi, hi*lo, lo*hi)
 // One wave owns a 16-column strip and slides down it 16 rows per step; horizontal tiles go through a per-wave
 // LDS ring stored column-major, so a vertical B operand is one 16-byte read.  The result is a FILTER exactly as
-// before: relative error of G is below 2^-16 (dropped lo*lo, float16 lo roundings, float32 accumulation of <= 300
-// positive terms), the decision is taken against theta(c) (1 +- 2e-5) and the undecided pixels recompute G in
-// float64 from the bits.  For windows inside the image the decision only depends on (c, G): num > sqrt(rhs) <=>
-// G > theta(c), a per-frame table of l*l + 1 entries built by k_ncc_theta; border tiles evaluate theta per pixel.
+// before: the relative error of G stays below 2^-16 (dropped lo*lo, float16 lo roundings, float32 accumulation of
+// <= 300 positive terms), the decision is taken against theta (1 +- 2e-5) and the undecided pixels recompute G in
+// float64 from the bits, so every decision equals the float64 one.
+// For a window inside the image the mean terms cancel: var = 255^2 c (1 - c / l^2), hence
+//   num > 0 and num^2 > rhs  <=>  G > theta(c) = sqrt(thr2 T2 c (l^2 - c)) / l + tbar c + mu (sum_t - l^2 tbar) / 255,
+// three float32 operations per pixel (c (l^2 - c) < 2^24 is exact).  An empty window has G = 0 exactly on both
+// paths and var = 0 up to rounding: its decision is taken once per wave with the float64 formula.  Border tiles
+// (windows that leave the image) evaluate theta per pixel in float64.
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
@@ -245,7 +249,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 #define NCC_REL 2e-5f
 #define NCC_ABS 1e-3f                                   // in units of G * 2^20: far below any theta with c >= 1
 
-// theta(c) for full windows: the smallest 2^20 G that makes num > 0 and num^2 > rhs (+inf where var <= 0)
+// theta on 2^20 G for a window with c foreground and nn in-image samples (+inf where var <= 0)
 __device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, double mu, const NccConst& nc) {
     double sum_I = 255.0 * c;
     double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
@@ -254,27 +258,17 @@ __device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, d
     double var = s2 - s1 * s1 * nc.inv_l2;
     double rhs = nc.thr2 * var * nc.T2;
     if (!(var > 0.0)) return (double)INFINITY;
-    // an empty window has G = 0 exactly on both paths (var is then 0 up to rounding): decide it here, once
+    // an empty window has G = 0 exactly on both paths: decide it here
     if (c == 0.0) return (rest > 0.0 && rest * rest > rhs) ? -(double)INFINITY : (double)INFINITY;
     return (sqrt(rhs) - rest) * (NCC_WSCALE * NCC_WSCALE / 255.0);
 }
 
-__global__ __launch_bounds__(256) void k_ncc_theta(const u32* __restrict__ fstat, const double* __restrict__ rx,
-                                                   const double* __restrict__ ry, float* __restrict__ theta,
-                                                   int H, int W, int l2, int lo, NccConst nc) {
-    const int n = blockIdx.x;
-    const double mu = (double)(255ull * (u64)fstat[n * 8 + 0]) / (double)((int64_t)H * W);
-    const double full_t = ry[min(max(-lo, 0), H - 1)] * rx[min(max(-lo, 0), W - 1)];
-    for (int c = threadIdx.x; c <= l2; c += 256)
-        theta[(int64_t)n * (l2 + 1) + c] = (float)ncc_theta((double)c, nc.l2, full_t, mu, nc);
-}
-
 template <int L, int LO>
-__global__ __launch_bounds__(256, 2) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
-                                                     const double* __restrict__ ry, const float* __restrict__ theta,
-                                                     const uint4* __restrict__ wfrag, u64* __restrict__ mbits,
-                                                     u8* __restrict__ mask_u8, u32* __restrict__ fstat, int H, int W,
-                                                     int WW, int tiles_per_seg, NccConst nc) {
+__global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
+                                                     const double* __restrict__ ry, const uint4* __restrict__ wfrag,
+                                                     u64* __restrict__ mbits, u8* __restrict__ mask_u8,
+                                                     u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
+                                                     NccConst nc) {
     constexpr int HI = L - 1 + LO;
     constexpr int NT = (16 + L - 1 + 15) / 16;          // horizontal tiles under one output tile
     constexpr int NKS = (16 * NT + 31) / 32;            // k-steps of 32
@@ -282,7 +276,6 @@ __global__ __launch_bounds__(256, 2) void k_ncc_mfma(const u64* __restrict__ bit
     constexpr int RSTR = RING + 8;                      // halves per ring column (+16 B: conflict-free 16-byte reads)
     constexpr int L2 = L * L;
     __shared__ __align__(16) uint4 lut[256];
-    __shared__ float th_s[L2 + 1];
     __shared__ __align__(16) _Float16 ring[4][3][16 * RSTR];
     __shared__ double cg[L + 1];
     __shared__ double gsh[L];
@@ -302,7 +295,6 @@ __global__ __launch_bounds__(256, 2) void k_ncc_mfma(const u64* __restrict__ bit
         for (int d = 0; d < 4; ++d) w[d] = (((u32)tid >> (2 * d)) & 1u ? 0x3C00u : 0u) | (((u32)tid >> (2 * d + 1)) & 1u ? 0x3C000000u : 0u);
         lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    for (int i = tid; i <= L2; i += 256) th_s[i] = theta[(int64_t)n * (L2 + 1) + i];
     for (int i = tid; i <= L; i += 256) cg[i] = nc.cg[i];
     for (int i = tid; i < L; i += 256) gsh[i] = nc.g[i];
     for (int i = lane; i < 3 * 16 * RSTR / 8; i += 64) reinterpret_cast<uint4*>(&ring[wave][0][0])[i] = make_uint4(0, 0, 0, 0);
@@ -318,25 +310,40 @@ __global__ __launch_bounds__(256, 2) void k_ncc_mfma(const u64* __restrict__ bit
     __syncthreads();
 
     const double mu = (double)(255ull * (u64)fstat[n * 8 + 0]) / (double)((int64_t)H * W);
+    const double full_t = ry[min(max(-LO, 0), H - 1)] * rx[min(max(-LO, 0), W - 1)];
+    // theta(c) = ks sqrt(c (l^2 - c)) + kc c + k0 on 2^20 G; th0 decides the empty window
+    const float ks = (float)(sqrt(nc.thr2 * nc.T2) / (double)L * (NCC_WSCALE * NCC_WSCALE));
+    const float kc = (float)(nc.tbar * (NCC_WSCALE * NCC_WSCALE));
+    const float k0 = (float)(mu * (full_t - nc.l2 * nc.tbar) / 255.0 * (NCC_WSCALE * NCC_WSCALE));
+    const float th0 = (float)ncc_theta(0.0, nc.l2, full_t, mu, nc);
     _Float16* rhi = &ring[wave][0][q * RSTR];
     _Float16* rlo = &ring[wave][1][q * RSTR];
     _Float16* rct = &ring[wave][2][q * RSTR];
     u32 amb = 0, nexact = 0;
-    // row bits of the next horizontal tile: lane (g, q) holds row q's window [xw + LO, xw + LO + 32 NKS)
-    auto load_rows = [&](int t, u64& w0, u64& w1) {
+    // Row bits of a horizontal tile: lane (g, q) takes row q's window [xw + LO, xw + LO + 32 NKS) out of three words.
+    // The loads are branch-free (clamped addresses, masked afterwards) so that the next tile's stay in flight.
+    const int wstart = xw + LO, wi0 = wstart >> 6, sh = wstart & 63;        // wave-uniform
+    const bool in0 = wi0 >= 0 && wi0 < WW, in1 = wi0 + 1 >= 0 && wi0 + 1 < WW, in2 = wi0 + 2 >= 0 && wi0 + 2 < WW;
+    const int c0 = min(max(wi0, 0), WW - 1), c1 = min(max(wi0 + 1, 0), WW - 1), c2 = min(max(wi0 + 2, 0), WW - 1);
+    u64 na, nb_, ncw;
+    auto load_rows = [&](int t) {
         const int y = Y0 + LO + 16 * t + q;
-        w0 = w1 = 0;
-        if (y >= 0 && y < H) {
-            const u64* row = fbits + (int64_t)y * WW;
-            w0 = load_bits(row, WW, xw + LO);
-            if (NKS > 2) w1 = load_bits(row, WW, xw + LO + 64);
-        }
+        const u64* row = fbits + (int64_t)min(max(y, 0), H - 1) * WW;
+        na = row[c0]; nb_ = row[c1]; ncw = row[c2];
     };
-    u64 nw0, nw1;
-    load_rows(0, nw0, nw1);
+    load_rows(0);
     for (int t = 0; t < nsteps; ++t) {
-        const u64 w0 = nw0, w1 = nw1;
-        if (t + 1 < nsteps) load_rows(t + 1, nw0, nw1);
+        u64 wa = na, wb = nb_, wc = ncw;
+        {
+            const int y = Y0 + LO + 16 * t + q;
+            const bool rowin = y >= 0 && y < H;
+            wa = (rowin && in0) ? wa : 0ull;
+            wb = (rowin && in1) ? wb : 0ull;
+            wc = (rowin && in2) ? wc : 0ull;
+        }
+        if (t + 1 < nsteps) load_rows(t + 1);
+        const u64 w0 = sh ? ((wa >> sh) | (wb << (64 - sh))) : wa;
+        const u64 w1 = sh ? ((wb >> sh) | (wc << (64 - sh))) : wb;
         // ---- horizontal tile t ----
         f4 ah = {0, 0, 0, 0}, ac = {0, 0, 0, 0};
 #pragma unroll
@@ -381,42 +388,74 @@ __global__ __launch_bounds__(256, 2) void k_ncc_mfma(const u64* __restrict__ bit
         // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
         const int x = xw + q;
         const bool interior = (yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
-        u64 words[4];
+        float th[4];
+        if (interior) {                                  // wave-uniform
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float cf = C[r];                   // exact integer
+                const float t1 = __builtin_fmaf(ks, __builtin_sqrtf(cf * ((float)L2 - cf)), __builtin_fmaf(kc, cf, k0));
+                th[r] = cf == 0.0f ? th0 : t1;
+            }
+        } else {
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
+                const int y = yo + 4 * g + r;
+                int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
+                int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
+                float v = (y < H && x < W) ? (float)ncc_theta((double)C[r], (double)(ny * nx), ry[min(y, H - 1)] * rx[min(x, W - 1)], mu, nc)
+                                           : INFINITY;
+                th[0] = r == 0 ? v : th[0]; th[1] = r == 1 ? v : th[1]; th[2] = r == 2 ? v : th[2]; th[3] = r == 3 ? v : th[3];
+            }
+        }
+        bool pred[4];
+        bool any_undecided = false;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int y = yo + 4 * g + r;
             const bool valid = (y < H) && (x < W);
-            const int ci = (int)C[r];
-            float th;
-            if (interior) {
-                th = th_s[min(ci, L2)];
-            } else {
-                int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
-                int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
-                th = valid ? (float)ncc_theta((double)ci, (double)(ny * nx), ry[min(y, H - 1)] * rx[min(x, W - 1)], mu, nc) : INFINITY;
-            }
-            bool pred = valid && (G[r] > __builtin_fmaf(th, 1.0f + NCC_REL, NCC_ABS));
-            const bool undecided = valid && !pred && !(G[r] < __builtin_fmaf(th, 1.0f - NCC_REL, -NCC_ABS));
-            if (undecided) {                             // rare: exact float64 G straight from the bits
-                int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
-                int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
-                double nn = (double)(ny * nx), sum_t = ry[y] * rx[x];
-                double sum_I = 255.0 * (double)ci;
-                double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
-                double s1 = sum_I - nn * mu;
-                double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
-                double var = s2 - s1 * s1 * nc.inv_l2;
-                double rhs = nc.thr2 * var * nc.T2;
-                if (var > 0.0) {
-                    const double Ge = ncc_exact_G<L, LO>(fbits, H, WW, y, x, cg, gsh);
-                    double num = 255.0 * Ge + rest;
-                    pred = (num > 0.0) && (num * num > rhs);
-                    if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
-                    nexact++;
+            pred[r] = valid && (G[r] > __builtin_fmaf(th[r], 1.0f + NCC_REL, NCC_ABS));
+            any_undecided |= valid && !pred[r] && !(G[r] < __builtin_fmaf(th[r], 1.0f - NCC_REL, -NCC_ABS));
+        }
+        if (__ballot(any_undecided)) {                   // rare: exact float64 G straight from the bits
+#pragma unroll 1
+            for (int r = 0; r < 4; ++r) {
+                const int y = yo + 4 * g + r;
+                const bool valid = (y < H) && (x < W);
+                const float gr = r == 0 ? G[0] : r == 1 ? G[1] : r == 2 ? G[2] : G[3];
+                const float tr = r == 0 ? th[0] : r == 1 ? th[1] : r == 2 ? th[2] : th[3];
+                const float cr = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
+                const bool pr = gr > __builtin_fmaf(tr, 1.0f + NCC_REL, NCC_ABS);
+                if (valid && !pr && !(gr < __builtin_fmaf(tr, 1.0f - NCC_REL, -NCC_ABS))) {
+                    int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
+                    int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
+                    double nn = (double)(ny * nx), sum_t = ry[y] * rx[x];
+                    double sum_I = 255.0 * (double)cr;
+                    double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
+                    double s1 = sum_I - nn * mu;
+                    double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
+                    double var = s2 - s1 * s1 * nc.inv_l2;
+                    double rhs = nc.thr2 * var * nc.T2;
+                    bool pe = false;
+                    if (var > 0.0) {
+                        const double Ge = ncc_exact_G<L, LO>(fbits, H, WW, y, x, cg, gsh);
+                        double num = 255.0 * Ge + rest;
+                        pe = (num > 0.0) && (num * num > rhs);
+                        if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
+                        nexact++;
+                    }
+                    pred[0] = r == 0 ? pe : pred[0]; pred[1] = r == 1 ? pe : pred[1];
+                    pred[2] = r == 2 ? pe : pred[2]; pred[3] = r == 3 ? pe : pred[3];
                 }
             }
-            words[r] = __ballot(pred);
-            if (mask_u8 && valid) mask_u8[((int64_t)n * H + y) * W + x] = pred ? 1 : 0;
+        }
+        u64 words[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            words[r] = __ballot(pred[r]);
+            if (mask_u8) {
+                const int y = yo + 4 * g + r;
+                if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = pred[r] ? 1 : 0;
+            }
         }
         if (lane < 16) {                                 // lane = row of the tile: 16 mask bits of this strip
             const int y = yo + lane;
@@ -473,20 +512,18 @@ void launch_popcount(vbs_handle* h, int nb, hipStream_t s) {
 
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s) {
     if (!ncc_out && !getenv("VBS_NCC_VALU")) {
-        const int l = h->bp.ncc_l, tilesY = (h->H + 15) / 16;
-        VBS_LAUNCH(h, s, "k_ncc_theta", k_ncc_theta, dim3(nb), dim3(256), 0, s, h->fstat, h->ncc_rx, h->ncc_ry,
-                   h->ncc_theta, h->H, h->W, l * l, h->bp.ncc_lo, h->ncc);
+        const int tilesY = (h->H + 15) / 16;
         int nseg = std::min(tilesY, std::max(1, (2048 + h->WW * nb - 1) / (h->WW * nb)));   // few frames: split columns
         const int tps = (tilesY + nseg - 1) / nseg;
         nseg = (tilesY + tps - 1) / tps;
         dim3 grid(h->WW, nseg, nb);
         if (!h->bp.small)
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
-                       h->ncc_ry, h->ncc_theta, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
+                       h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
                        h->ncc);
         else
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
-                       h->ncc_ry, h->ncc_theta, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
+                       h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
                        h->ncc);
         return;
     }
