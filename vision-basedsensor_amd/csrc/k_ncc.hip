@@ -247,6 +247,7 @@ typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
 #define NCC_WSCALE 1024.0                               // weights are scaled so that every wlo is a normal float16
 #define NCC_REL 2e-5f
+#define NCC_NEVER 3e38                                  // "no G reaches this" (finite, so G - theta stays ordered)
 #define NCC_ABS 1e-3f                                   // in units of G * 2^20: far below any theta with c >= 1
 
 // theta on 2^20 G for a window with c foreground and nn in-image samples (+inf where var <= 0)
@@ -257,9 +258,9 @@ __device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, d
     double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
     double var = s2 - s1 * s1 * nc.inv_l2;
     double rhs = nc.thr2 * var * nc.T2;
-    if (!(var > 0.0)) return (double)INFINITY;
+    if (!(var > 0.0)) return NCC_NEVER;
     // an empty window has G = 0 exactly on both paths: decide it here
-    if (c == 0.0) return (rest > 0.0 && rest * rest > rhs) ? -(double)INFINITY : (double)INFINITY;
+    if (c == 0.0) return (rest > 0.0 && rest * rest > rhs) ? -NCC_NEVER : NCC_NEVER;
     return (sqrt(rhs) - rest) * (NCC_WSCALE * NCC_WSCALE / 255.0);
 }
 
@@ -320,35 +321,46 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
     _Float16* rlo = &ring[wave][1][q * RSTR];
     _Float16* rct = &ring[wave][2][q * RSTR];
     u32 amb = 0, nexact = 0;
-    // Row bits of a horizontal tile: lane (g, q) takes row q's window [xw + LO, xw + LO + 32 NKS) out of three words.
-    // The loads are branch-free (clamped addresses, masked afterwards) so that the next tile's stay in flight.
-    const int wstart = xw + LO, wi0 = wstart >> 6, sh = wstart & 63;        // wave-uniform
-    const bool in0 = wi0 >= 0 && wi0 < WW, in1 = wi0 + 1 >= 0 && wi0 + 1 < WW, in2 = wi0 + 2 >= 0 && wi0 + 2 < WW;
-    const int c0 = min(max(wi0, 0), WW - 1), c1 = min(max(wi0 + 1, 0), WW - 1), c2 = min(max(wi0 + 2, 0), WW - 1);
-    u64 na, nb_, ncw;
+    // Row bits of a horizontal tile: lane (g, q) takes row q's window [xw + LO, xw + LO + 32 NKS) as dwords.  Strips
+    // whose window lies inside the row load them with one branch-free 16-byte load (issued a step ahead); the
+    // first / last strips of a row go through clamped 64-bit loads.
+    const int wstart = xw + LO;                          // wave-uniform
+    const int d0 = wstart >> 5, dsh = wstart & 31;
+    const bool wide = (d0 >= 0) && (d0 + 4 <= 2 * WW);
+    uint4 nraw = make_uint4(0, 0, 0, 0);
     auto load_rows = [&](int t) {
         const int y = Y0 + LO + 16 * t + q;
         const u64* row = fbits + (int64_t)min(max(y, 0), H - 1) * WW;
-        na = row[c0]; nb_ = row[c1]; ncw = row[c2];
+        if (wide) {
+            const u32* r32 = reinterpret_cast<const u32*>(row) + d0;
+            nraw = make_uint4(r32[0], r32[1], r32[2], r32[3]);
+        } else {
+            u64 w0 = load_bits(row, WW, wstart), w1 = load_bits(row, WW, wstart + 64);
+            nraw = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, 0u);
+        }
     };
     load_rows(0);
     for (int t = 0; t < nsteps; ++t) {
-        u64 wa = na, wb = nb_, wc = ncw;
-        {
-            const int y = Y0 + LO + 16 * t + q;
-            const bool rowin = y >= 0 && y < H;
-            wa = (rowin && in0) ? wa : 0ull;
-            wb = (rowin && in1) ? wb : 0ull;
-            wc = (rowin && in2) ? wc : 0ull;
-        }
+        const uint4 raw = nraw;
+        const int ytile = Y0 + LO + 16 * t;
         if (t + 1 < nsteps) load_rows(t + 1);
-        const u64 w0 = sh ? ((wa >> sh) | (wb << (64 - sh))) : wa;
-        const u64 w1 = sh ? ((wb >> sh) | (wc << (64 - sh))) : wb;
+        u32 dw[3];
+        if (wide) {
+            dw[0] = __builtin_amdgcn_alignbit(raw.y, raw.x, dsh);
+            dw[1] = __builtin_amdgcn_alignbit(raw.z, raw.y, dsh);
+            dw[2] = __builtin_amdgcn_alignbit(raw.w, raw.z, dsh);
+        } else {
+            dw[0] = raw.x; dw[1] = raw.y; dw[2] = raw.z;
+        }
+        if (ytile < 0 || ytile + 15 >= H) {              // uniform: rows outside the image are empty
+            const bool rowin = (ytile + q >= 0) && (ytile + q < H);
+            dw[0] = rowin ? dw[0] : 0u; dw[1] = rowin ? dw[1] : 0u; dw[2] = rowin ? dw[2] : 0u;
+        }
         // ---- horizontal tile t ----
         f4 ah = {0, 0, 0, 0}, ac = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
-            const u32 byte = (u32)((s < 2 ? w0 >> (32 * s + 8 * g) : w1 >> (32 * (s - 2) + 8 * g)) & 255ull);
+            const u32 byte = (dw[s] >> (8 * g)) & 255u;
             const h8 a = __builtin_bit_cast(h8, lut[byte]);
             ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, whi[s], ah, 0, 0, 0);
             ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wlo[s], ah, 0, 0, 0);
@@ -374,9 +386,11 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
         f4 G = {0, 0, 0, 0}, C = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
-            int ro = base + 32 * s + 8 * g;
-            ro = ro >= RING ? ro - RING : ro;
-            ro = ro >= RING ? ro - RING : ro;
+            int ub = base + 32 * s;                      // uniform part of the ring offset, wraps at RING
+            ub = ub >= RING ? ub - RING : ub;
+            ub = ub >= RING ? ub - RING : ub;
+            int ro = ub + 8 * g;
+            ro = min((u32)ro, (u32)(ro - RING));         // ro >= RING ? ro - RING : ro
             const h8 bh = *reinterpret_cast<const h8*>(rhi + ro);
             const h8 bl = *reinterpret_cast<const h8*>(rlo + ro);
             const h8 bc = *reinterpret_cast<const h8*>(rct + ro);
@@ -389,43 +403,43 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
         const int x = xw + q;
         const bool interior = (yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
         float th[4];
-        if (interior) {                                  // wave-uniform
+        if (interior && th0 > 0.0f) {                    // wave-uniform; th0 > 0: an empty window is background
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float cf = C[r];                   // exact integer
-                const float t1 = __builtin_fmaf(ks, __builtin_sqrtf(cf * ((float)L2 - cf)), __builtin_fmaf(kc, cf, k0));
-                th[r] = cf == 0.0f ? th0 : t1;
+                const float cf = C[r];                   // exact integer; c = 0 <=> G = 0 < 0.01
+                th[r] = fmaxf(__builtin_fmaf(ks, __builtin_amdgcn_sqrtf(cf * ((float)L2 - cf)), __builtin_fmaf(kc, cf, k0)), 0.01f);
             }
         } else {
 #pragma unroll 1
             for (int r = 0; r < 4; ++r) {
                 const int y = yo + 4 * g + r;
+                const float cr = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
                 int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
                 int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
-                float v = (y < H && x < W) ? (float)ncc_theta((double)C[r], (double)(ny * nx), ry[min(y, H - 1)] * rx[min(x, W - 1)], mu, nc)
-                                           : INFINITY;
+                float v = (y < H && x < W) ? (float)ncc_theta((double)cr, (double)(ny * nx), ry[min(y, H - 1)] * rx[min(x, W - 1)], mu, nc)
+                                           : (float)NCC_NEVER;
                 th[0] = r == 0 ? v : th[0]; th[1] = r == 1 ? v : th[1]; th[2] = r == 2 ? v : th[2]; th[3] = r == 3 ? v : th[3];
             }
         }
-        bool pred[4];
-        bool any_undecided = false;
+        const bool allvalid = (yo + 15 < H) && (xw + 15 < W);   // uniform
+        u64 pw[4], uw[4], any = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const int y = yo + 4 * g + r;
-            const bool valid = (y < H) && (x < W);
-            pred[r] = valid && (G[r] > __builtin_fmaf(th[r], 1.0f + NCC_REL, NCC_ABS));
-            any_undecided |= valid && !pred[r] && !(G[r] < __builtin_fmaf(th[r], 1.0f - NCC_REL, -NCC_ABS));
+            const float m = __builtin_fmaf(th[r], NCC_REL, NCC_ABS), d = G[r] - th[r];
+            const u64 pb = __ballot(d > m), fb = __ballot(d < -m);
+            const u64 vm = allvalid ? ~0ull : __ballot((yo + 4 * g + r < H) && (x < W));
+            pw[r] = pb & vm;
+            uw[r] = ~pb & ~fb & vm;                      // neither above theta (1 + e) nor below theta (1 - e)
+            any |= uw[r];
         }
-        if (__ballot(any_undecided)) {                   // rare: exact float64 G straight from the bits
+        if (any) {                                       // rare: exact float64 G straight from the bits
 #pragma unroll 1
             for (int r = 0; r < 4; ++r) {
-                const int y = yo + 4 * g + r;
-                const bool valid = (y < H) && (x < W);
-                const float gr = r == 0 ? G[0] : r == 1 ? G[1] : r == 2 ? G[2] : G[3];
-                const float tr = r == 0 ? th[0] : r == 1 ? th[1] : r == 2 ? th[2] : th[3];
-                const float cr = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
-                const bool pr = gr > __builtin_fmaf(tr, 1.0f + NCC_REL, NCC_ABS);
-                if (valid && !pr && !(gr < __builtin_fmaf(tr, 1.0f - NCC_REL, -NCC_ABS))) {
+                const u64 ur = r == 0 ? uw[0] : r == 1 ? uw[1] : r == 2 ? uw[2] : uw[3];
+                bool pe = false;
+                if ((ur >> lane) & 1ull) {
+                    const int y = yo + 4 * g + r;
+                    const float cr = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
                     int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
                     int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
                     double nn = (double)(ny * nx), sum_t = ry[y] * rx[x];
@@ -435,7 +449,6 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
                     double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
                     double var = s2 - s1 * s1 * nc.inv_l2;
                     double rhs = nc.thr2 * var * nc.T2;
-                    bool pe = false;
                     if (var > 0.0) {
                         const double Ge = ncc_exact_G<L, LO>(fbits, H, WW, y, x, cg, gsh);
                         double num = 255.0 * Ge + rest;
@@ -443,23 +456,21 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
                         if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
                         nexact++;
                     }
-                    pred[0] = r == 0 ? pe : pred[0]; pred[1] = r == 1 ? pe : pred[1];
-                    pred[2] = r == 2 ? pe : pred[2]; pred[3] = r == 3 ? pe : pred[3];
                 }
+                const u64 pb = __ballot(pe);
+                pw[0] |= r == 0 ? pb : 0ull; pw[1] |= r == 1 ? pb : 0ull; pw[2] |= r == 2 ? pb : 0ull; pw[3] |= r == 3 ? pb : 0ull;
             }
         }
-        u64 words[4];
+        if (mask_u8) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            words[r] = __ballot(pred[r]);
-            if (mask_u8) {
+            for (int r = 0; r < 4; ++r) {
                 const int y = yo + 4 * g + r;
-                if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = pred[r] ? 1 : 0;
+                if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)((pw[r] >> lane) & 1ull);
             }
         }
         if (lane < 16) {                                 // lane = row of the tile: 16 mask bits of this strip
             const int y = yo + lane;
-            u64 wsel = (lane & 3) == 0 ? words[0] : (lane & 3) == 1 ? words[1] : (lane & 3) == 2 ? words[2] : words[3];
+            u64 wsel = (lane & 3) == 0 ? pw[0] : (lane & 3) == 1 ? pw[1] : (lane & 3) == 2 ? pw[2] : pw[3];
             if (y < H)
                 reinterpret_cast<unsigned short*>(mbits)[(((int64_t)n * H + y) * WW + blockIdx.x) * 4 + wave] =
                     (unsigned short)(wsel >> (16 * (lane >> 2)));
