@@ -264,12 +264,34 @@ __device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, d
     return (sqrt(rhs) - rest) * (NCC_WSCALE * NCC_WSCALE / 255.0);
 }
 
+// The empty window (c = 0, so G = 0 exactly on both paths), reference operation order: +-NCC_NEVER
+__device__ __forceinline__ double ncc_theta_empty(double nn, double sum_t, double mu, const NccConst& nc) {
+    double rest = -mu * (sum_t - nn * nc.tbar);
+    double s1 = -nn * mu, s2 = nn * mu * mu;
+    double var = s2 - s1 * s1 * nc.inv_l2;
+    double rhs = nc.thr2 * var * nc.T2;
+    return (var > 0.0 && rest > 0.0 && rest * rest > rhs) ? -NCC_NEVER : NCC_NEVER;
+}
+
+// theta for a window that leaves the image, c >= 1, with the mean terms collected (a = 1 - nn / l^2):
+//   var = 255^2 c (1 - c / l^2) + a mu (nn mu - 510 c);  sqrt by one Newton step on the float32 rsqrt
+__device__ __forceinline__ double ncc_theta_border(double c, double nn, double sum_t, double mu, const NccConst& nc) {
+    double rest = -nc.tbar * 255.0 * c - mu * (sum_t - nn * nc.tbar);
+    double var = 65025.0 * c * (1.0 - c * nc.inv_l2) + (1.0 - nn * nc.inv_l2) * mu * (nn * mu - 510.0 * c);
+    double rhs = nc.thr2 * nc.T2 * var;
+    if (!(rhs > 1e-30)) return NCC_NEVER;
+    double r0 = (double)__builtin_amdgcn_rsqf((float)rhs);
+    double sq = rhs * r0;
+    sq = __builtin_fma(0.5 * r0, __builtin_fma(-sq, sq, rhs), sq);
+    return (sq - rest) * (NCC_WSCALE * NCC_WSCALE / 255.0);
+}
+
 template <int L, int LO>
 __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
                                                      u64* __restrict__ mbits, u8* __restrict__ mask_u8,
                                                      u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
-                                                     NccConst nc) {
+                                                     int dbg, NccConst nc) {
     constexpr int HI = L - 1 + LO;
     constexpr int NT = (16 + L - 1 + 15) / 16;          // horizontal tiles under one output tile
     constexpr int NKS = (16 * NT + 31) / 32;            // k-steps of 32
@@ -280,6 +302,7 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
     __shared__ __align__(16) _Float16 ring[4][3][16 * RSTR];
     __shared__ double cg[L + 1];
     __shared__ double gsh[L];
+    __shared__ double hrow_s[4][L];                     // exact path: one window's row sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int g = lane >> 4, q = lane & 15;
     const int n = blockIdx.z;
@@ -401,7 +424,7 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
         }
         // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
         const int x = xw + q;
-        const bool interior = (yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
+        const bool interior = (dbg & 1) || ((yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1));
         float th[4];
         if (interior && th0 > 0.0f) {                    // wave-uniform; th0 > 0: an empty window is background
 #pragma unroll
@@ -416,8 +439,11 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
                 const float cr = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
                 int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
                 int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
-                float v = (y < H && x < W) ? (float)ncc_theta((double)cr, (double)(ny * nx), ry[min(y, H - 1)] * rx[min(x, W - 1)], mu, nc)
-                                           : (float)NCC_NEVER;
+                float v = (float)NCC_NEVER;
+                if (y < H && x < W) {
+                    const double nn = (double)(ny * nx), sum_t = ry[y] * rx[x];
+                    v = (float)(cr == 0.0f ? ncc_theta_empty(nn, sum_t, mu, nc) : ncc_theta_border((double)cr, nn, sum_t, mu, nc));
+                }
                 th[0] = r == 0 ? v : th[0]; th[1] = r == 1 ? v : th[1]; th[2] = r == 2 ? v : th[2]; th[3] = r == 3 ? v : th[3];
             }
         }
@@ -432,33 +458,48 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
             uw[r] = ~pb & ~fb & vm;                      // neither above theta (1 + e) nor below theta (1 - e)
             any |= uw[r];
         }
-        if (any) {                                       // rare: exact float64 G straight from the bits
+        if (any && !(dbg & 2)) {
+            // Rare (a handful of pixels per frame): exact float64 G straight from the bits, one pixel at a time by the
+            // whole wave: lane i sums rows i and i + 64 of the window from their runs, then the L products are added
+            // in ascending row order exactly as ncc_exact_G does.
 #pragma unroll 1
             for (int r = 0; r < 4; ++r) {
-                const u64 ur = r == 0 ? uw[0] : r == 1 ? uw[1] : r == 2 ? uw[2] : uw[3];
-                bool pe = false;
-                if ((ur >> lane) & 1ull) {
-                    const int y = yo + 4 * g + r;
-                    const float cr = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
+                u64 ur = r == 0 ? uw[0] : r == 1 ? uw[1] : r == 2 ? uw[2] : uw[3];
+                const float crl = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
+                u64 add = 0;
+                while (ur) {
+                    const int l = __ffsll((long long)ur) - 1;
+                    ur &= ur - 1ull;
+                    const int y = yo + 4 * (l >> 4) + r, xe = xw + (l & 15);
+                    const float cr = __shfl(crl, l);
+#pragma unroll
+                    for (int k = 0; k < (L + 63) / 64; ++k) {
+                        const int i = lane + 64 * k, yy = y + LO + i;
+                        u32 dummy = 0;
+                        if (i < L) hrow_s[wave][i] = (yy >= 0 && yy < H) ? ncc_row_exact<L, LO>(fbits + (int64_t)yy * WW, WW, xe, cg, &dummy) : 0.0;
+                    }
+                    double Ge = 0.0;
+#pragma unroll 8
+                    for (int i = 0; i < L; ++i) Ge = __builtin_fma(gsh[i], hrow_s[wave][i], Ge);
                     int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
-                    int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
-                    double nn = (double)(ny * nx), sum_t = ry[y] * rx[x];
+                    int nx = min(xe + HI, W - 1) - max(xe + LO, 0) + 1;
+                    double nn = (double)(ny * nx), sum_t = ry[y] * rx[xe];
                     double sum_I = 255.0 * (double)cr;
                     double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
                     double s1 = sum_I - nn * mu;
                     double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
                     double var = s2 - s1 * s1 * nc.inv_l2;
                     double rhs = nc.thr2 * var * nc.T2;
-                    if (var > 0.0) {
-                        const double Ge = ncc_exact_G<L, LO>(fbits, H, WW, y, x, cg, gsh);
+                    if (var > 0.0) {                     // wave-uniform
                         double num = 255.0 * Ge + rest;
-                        pe = (num > 0.0) && (num * num > rhs);
-                        if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
-                        nexact++;
+                        if ((num > 0.0) && (num * num > rhs)) add |= 1ull << l;
+                        if (lane == 0) {
+                            if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
+                            nexact++;
+                        }
                     }
                 }
-                const u64 pb = __ballot(pe);
-                pw[0] |= r == 0 ? pb : 0ull; pw[1] |= r == 1 ? pb : 0ull; pw[2] |= r == 2 ? pb : 0ull; pw[3] |= r == 3 ? pb : 0ull;
+                pw[0] |= r == 0 ? add : 0ull; pw[1] |= r == 1 ? add : 0ull; pw[2] |= r == 2 ? add : 0ull; pw[3] |= r == 3 ? add : 0ull;
             }
         }
         if (mask_u8) {
@@ -528,14 +569,15 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         const int tps = (tilesY + nseg - 1) / nseg;
         nseg = (tilesY + tps - 1) / tps;
         dim3 grid(h->WW, nseg, nb);
+        const int dbg = getenv("VBS_NCC_DBG") ? atoi(getenv("VBS_NCC_DBG")) : 0;
         if (!h->bp.small)
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
                        h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
-                       h->ncc);
+                       dbg, h->ncc);
         else
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
                        h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
-                       h->ncc);
+                       dbg, h->ncc);
         return;
     }
     dim3 grid(h->WW, (h->H + 63) / 64, nb);
