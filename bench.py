@@ -13,12 +13,15 @@ RCCL (N > 1), then the last-seen displacement pass on the gathered table.  value
 ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  (dtype "u8+f64": uint8 / int32 integer work in the blur and labelling kernels, float64 decisions in the NCC
-   (behind a float32 filter), the ellipse fit and the 3-D solve; tables are stored as float32)
+  (dtype "u8+f64": uint8 / int32 integer work in the blur (int8 matrix cores, exact) and labelling kernels, float64
+   decisions in the NCC (behind a float16-operand / float32-accumulate matrix-core filter), the ellipse fit and the
+   3-D solve; tables are stored as float32)
   roofline      threshold+CCL stage (`vbs_marker_center` on uint8 mask + area_mask: k_threshold,
                 k_morph x2, k_label, k_finalize), timed live with HIP events on the launch stream
                 inside libvbs.  achieved = algorithmic bytes / stage time, algorithmic bytes per
                 frame = 2*H*W (the two uint8 images it thresholds) + 24 B per component.
+  roofline_mfma k_blur_mfma (int8) and k_ncc_mfma (float16) against the dense matrix-core peaks: algorithmic
+                operations of the separable filters / live kernel time (same HIP events)
   kernels       live average ms per launch of every kernel of the fused path (one launch = `batch` frames)
   cpu_baseline  the NumPy/SciPy oracle (oracle/stages.py, a port: the reference needs OpenCV) on the
                 box's host cores over a bounded sample of the same frames (rank 0, N = 1 only).
@@ -234,6 +237,22 @@ def main():
             "per_kernel_avg_ms": {k: round(sp[k][1] / sp[k][0], 4) for k in stage},
             "us_per_frame": round(1e3 * stage_ms / nk, 3)}
         result["kernels"] = kernels
+        # the two matrix-core kernels of the front end against the dense MFMA peaks (MI355X_MICROARCH.md: bf16/f16
+        # ~2.5 PFLOP/s, int8 2x that); algorithmic operations = the separable filters as written in the reference
+        # (Toeplitz padding, hi/lo splits and the count product are overhead, not counted)
+        small = H <= 480
+        ta, tb, ln = (21, 35, 33) if small else (39, 101, 80)
+        mf = []
+        for name, ops_px, peak, dt in (("k_blur_mfma", 2 * 2 * (ta + tb), 5000.0, "i8"),
+                                       ("k_ncc_mfma", 2 * 2 * ln, 2500.0, "f16")):
+            if name in prof:
+                c, ms = prof[name]
+                ach = ops_px * H * W * nk / (ms * 1e-3) / 1e12
+                mf.append({"kernel": name, "bound": "mfma", "dtype": dt, "achieved": round(ach, 2), "peak": peak,
+                           "unit": "TOP/s" if dt == "i8" else "TFLOP/s", "frac": round(ach / peak, 5),
+                           "algorithmic_ops_per_pixel": ops_px, "avg_ms": round(ms / c, 4),
+                           "frames_per_launch": round(nk / c, 1)})
+        result["roofline_mfma"] = mf
         del launches_per
     if world > 1:
         td.barrier()

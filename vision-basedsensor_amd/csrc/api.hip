@@ -37,21 +37,6 @@ static std::vector<int> gaussian_taps_q8(int ksize, double sigma) {
     return out;
 }
 
-template <int MAXW>
-static void pack_taps_t(const std::vector<int>& k, int c4, int nw, u32 dst[4][MAXW]) {
-    const int taps = (int)k.size(), c = taps / 2;
-    for (int s = 0; s < 4; ++s)
-        for (int q = 0; q < MAXW; ++q) {
-            u32 w = 0;
-            if (q < nw)
-                for (int b = 0; b < 4; ++b) {
-                    int j = 4 * q + b - (c4 - c + s);
-                    if (j >= 0 && j < taps) w |= (u32)k[j] << (8 * b);
-                }
-            dst[s][q] = w;
-        }
-}
-
 static void ncc_consts(int l, double sigma, NccConst* nc) {
     std::vector<double> ax(l), e(l);
     // np.linspace(-(l-1)/2, (l-1)/2, l): start + i*step, last point exact
@@ -147,21 +132,9 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     double sa, sb, ts;
     if (bp.small) { bp.taps_a = 21; sa = 4.56; bp.taps_b = 35; sb = 11.4; bp.ncc_l = 33; ts = 7.4; bp.thresh = 35; bp.hi = 180; bp.ns = 8; }
     else { bp.taps_a = 39; sa = 8.0; bp.taps_b = 101; sb = 20.0; bp.ncc_l = 80; ts = 13.0; bp.thresh = 20; bp.hi = 200; bp.ns = 14; }
-    bp.c4a = (bp.taps_a / 2 + 3) / 4 * 4;
-    bp.c4b = (bp.taps_b / 2 + 3) / 4 * 4;
-    bp.nwa = (bp.c4a - bp.taps_a / 2 + 3 + bp.taps_a + 3) / 4;
-    bp.nwb = (bp.c4b - bp.taps_b / 2 + 3 + bp.taps_b + 3) / 4;
     bp.ncc_lo = -((bp.ncc_l - 1) - (bp.ncc_l - 1) / 2);
     bp.ncc_hi = (bp.ncc_l - 1) / 2;
     if (height <= bp.taps_b / 2 + 4 || width <= bp.taps_b / 2 + 4) { h->err = "frame smaller than the blur radius"; return VBS_EINVAL; }
-    // the kernels are instantiated for exactly these shapes
-    if (!((bp.small && bp.nwa == 7 && bp.nwb == 11 && bp.c4a == 12 && bp.c4b == 20) ||
-          (!bp.small && bp.nwa == 11 && bp.nwb == 27 && bp.c4a == 20 && bp.c4b == 52))) {
-        h->err = "internal: tap layout mismatch";
-        return VBS_EINVAL;
-    }
-    pack_taps_t<12>(gaussian_taps_q8(bp.taps_a, sa), bp.c4a, bp.nwa, h->taps.a);
-    pack_taps_t<VBS_MAX_TAPS_WORDS>(gaussian_taps_q8(bp.taps_b, sb), bp.c4b, bp.nwb, h->taps.b);
     ncc_consts(bp.ncc_l, ts, &h->ncc);
     std::vector<u32> frags;
     {   // the int8 matrix-core blur needs taps < 128 that sum to 256 (true for every sigma >= 1)
@@ -172,13 +145,11 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
         if (suma != 256 || sumb != 256 || mx > 127) { h->err = "internal: blur taps do not fit int8"; return VBS_EINVAL; }
         frags = bp.small ? blur_mfma_fragments(ka, kb, 3, 0, 3) : blur_mfma_fragments(ka, kb, 5, 1, 3);
     }
-    h->QE = (height + 3) / 4 + bp.nwb - 1;
 
     const size_t B = (size_t)max_batch, HW = (size_t)height * h->WW, HP = (size_t)height * h->P;
     int rc;
 #define ALLOC(field, count) if ((rc = dev_alloc(h, &h->field, (count))) != VBS_OK) return rc
     ALLOC(gray, B * HP);
-    ALLOC(planes, B * 4 * (size_t)h->QE * h->P);
     ALLOC(area_bits, B * HW); ALLOC(mask_bits, B * HW); ALLOC(band_bits, B * HW);
     ALLOC(open_bits, B * HW);
     ALLOC(ncc_rx, (size_t)width); ALLOC(ncc_ry, (size_t)height);

@@ -12,22 +12,12 @@ typedef long long i64;
 typedef uint32_t u32;
 typedef uint8_t u8;
 
-#define VBS_MAX_TAPS_WORDS 28      // (taps + 7) / 4 for the 101-tap blur
 #define VBS_NCC_MAXL 80
 #define VBS_RUN_CAP 30720          // union-find nodes (runs) per mask per frame kept in LDS
 #define VBS_AREA_SUMS 16           // n, 14 moments up to order 4, spare
 
-// Blur taps packed for v_dot4_u32_u8: for output phase s (0..3) word q holds the four taps that
-// multiply input bytes 4q..4q+3 of the aligned window (zero where no tap applies).
-struct BlurTaps {
-    u32 a[4][12];      // small kernel (39 or 21 taps): <= 11 words
-    u32 b[4][VBS_MAX_TAPS_WORDS];   // large kernel (101 or 35 taps): <= 27 words
-};
-
 struct BranchParams {              // marker_detection.py:117-126,129,170
     int taps_a, taps_b;            // GaussianBlur sizes
-    int c4a, c4b;                  // centre offsets rounded up to a multiple of 4
-    int nwa, nwb;                  // words per shifted kernel
     int thresh, hi;                // inRange bounds
     int ncc_l;                     // template size
     int ncc_lo, ncc_hi;            // window offsets of mode='same'
@@ -48,15 +38,12 @@ struct vbs_handle {
     bool prof = false;                     // record a HIP event pair around every kernel launch
     std::vector<ProfRec> recs;
     int device, H, W, P, WW, maxm, maxb;   // P = row pitch (mult. of 64), WW = P/64 words per row
-    int QE;                                // extended row-quads of the blur planes
     BranchParams bp;
-    BlurTaps taps;
     NccConst ncc;
     std::string err;
     // ---- device workspace (per internal pass of maxb frames) ----
     u8* gray;          // [maxb][H][P]
     uint4* blur_frags; // Toeplitz operand fragments of k_blur_mfma (blur_mfma_fragments)
-    u32* planes;       // [maxb][4][QE][P]   hi/lo byte planes of both horizontal blurs, row-quad packed
     u64* area_bits;    // [maxb][H][WW]
     u64* mask_bits;    // [maxb][H][WW]
     u64* band_bits;    // [maxb][H][WW]

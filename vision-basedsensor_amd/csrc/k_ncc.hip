@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
                                                      u64* __restrict__ mbits, u8* __restrict__ mask_u8,
                                                      u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
-                                                     int dbg, NccConst nc) {
+                                                     NccConst nc) {
     constexpr int HI = L - 1 + LO;
     constexpr int NT = (16 + L - 1 + 15) / 16;          // horizontal tiles under one output tile
     constexpr int NKS = (16 * NT + 31) / 32;            // k-steps of 32
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
         }
         // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
         const int x = xw + q;
-        const bool interior = (dbg & 1) || ((yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1));
+        const bool interior = (yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
         float th[4];
         if (interior && th0 > 0.0f) {                    // wave-uniform; th0 > 0: an empty window is background
 #pragma unroll
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
             uw[r] = ~pb & ~fb & vm;                      // neither above theta (1 + e) nor below theta (1 - e)
             any |= uw[r];
         }
-        if (any && !(dbg & 2)) {
+        if (any) {
             // Rare (a handful of pixels per frame): exact float64 G straight from the bits, one pixel at a time by the
             // whole wave: lane i sums rows i and i + 64 of the window from their runs, then the L products are added
             // in ascending row order exactly as ncc_exact_G does.
@@ -569,15 +569,14 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         const int tps = (tilesY + nseg - 1) / nseg;
         nseg = (tilesY + tps - 1) / tps;
         dim3 grid(h->WW, nseg, nb);
-        const int dbg = getenv("VBS_NCC_DBG") ? atoi(getenv("VBS_NCC_DBG")) : 0;
         if (!h->bp.small)
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
                        h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
-                       dbg, h->ncc);
+                       h->ncc);
         else
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
                        h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
-                       dbg, h->ncc);
+                       h->ncc);
         return;
     }
     dim3 grid(h->WW, (h->H + 63) / 64, nb);
