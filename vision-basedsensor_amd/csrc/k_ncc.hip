@@ -264,28 +264,6 @@ __device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, d
     return (sqrt(rhs) - rest) * (NCC_WSCALE * NCC_WSCALE / 255.0);
 }
 
-// The empty window (c = 0, so G = 0 exactly on both paths), reference operation order: +-NCC_NEVER
-__device__ __forceinline__ double ncc_theta_empty(double nn, double sum_t, double mu, const NccConst& nc) {
-    double rest = -mu * (sum_t - nn * nc.tbar);
-    double s1 = -nn * mu, s2 = nn * mu * mu;
-    double var = s2 - s1 * s1 * nc.inv_l2;
-    double rhs = nc.thr2 * var * nc.T2;
-    return (var > 0.0 && rest > 0.0 && rest * rest > rhs) ? -NCC_NEVER : NCC_NEVER;
-}
-
-// theta for a window that leaves the image, c >= 1, with the mean terms collected (a = 1 - nn / l^2):
-//   var = 255^2 c (1 - c / l^2) + a mu (nn mu - 510 c);  sqrt by one Newton step on the float32 rsqrt
-__device__ __forceinline__ double ncc_theta_border(double c, double nn, double sum_t, double mu, const NccConst& nc) {
-    double rest = -nc.tbar * 255.0 * c - mu * (sum_t - nn * nc.tbar);
-    double var = 65025.0 * c * (1.0 - c * nc.inv_l2) + (1.0 - nn * nc.inv_l2) * mu * (nn * mu - 510.0 * c);
-    double rhs = nc.thr2 * nc.T2 * var;
-    if (!(rhs > 1e-30)) return NCC_NEVER;
-    double r0 = (double)__builtin_amdgcn_rsqf((float)rhs);
-    double sq = rhs * r0;
-    sq = __builtin_fma(0.5 * r0, __builtin_fma(-sq, sq, rhs), sq);
-    return (sq - rest) * (NCC_WSCALE * NCC_WSCALE / 255.0);
-}
-
 template <int L, int LO>
 __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
@@ -340,6 +318,11 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
     const float kc = (float)(nc.tbar * (NCC_WSCALE * NCC_WSCALE));
     const float k0 = (float)(mu * (full_t - nc.l2 * nc.tbar) / 255.0 * (NCC_WSCALE * NCC_WSCALE));
     const float th0 = (float)ncc_theta(0.0, nc.l2, full_t, mu, nc);
+    // per-lane constants of the border tiles' threshold (the column is fixed for the whole strip)
+    const int xq = min(xw + q, W - 1);
+    const float nxf = (float)(min(xq + HI, W - 1) - max(xq + LO, 0) + 1), rxf = (float)rx[xq];
+    const float muf = (float)mu, tbarf = (float)nc.tbar, ktf = (float)(nc.tbar * 255.0), il2f = (float)nc.inv_l2;
+    const float krf = (float)(nc.thr2 * nc.T2);
     _Float16* rhi = &ring[wave][0][q * RSTR];
     _Float16* rlo = &ring[wave][1][q * RSTR];
     _Float16* rct = &ring[wave][2][q * RSTR];
@@ -426,6 +409,7 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
         const int x = xw + q;
         const bool interior = (yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
         float th[4];
+        float rel = NCC_REL, abs_ = NCC_ABS;             // margins of this tile (uniform)
         if (interior && th0 > 0.0f) {                    // wave-uniform; th0 > 0: an empty window is background
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -433,25 +417,30 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
                 th[r] = fmaxf(__builtin_fmaf(ks, __builtin_amdgcn_sqrtf(cf * ((float)L2 - cf)), __builtin_fmaf(kc, cf, k0)), 0.01f);
             }
         } else {
-#pragma unroll 1
+            // Border tile (or th0 <= 0): theta in float32 from the collected form of the general window,
+            //   var = 255^2 c (1 - c / l^2) + (1 - nn / l^2) mu (nn mu - 510 c),   rest = -tbar 255 c - mu (sum_t - nn tbar),
+            // whose error stays below 1e-4 theta + 1 in these units (var loses at most 5e-6 to cancellation, the last
+            // subtraction 1e-4 absolute on theta 255): pixels within 1e-3 theta + 2 of it go to the exact path.
+            rel = 1e-3f; abs_ = 2.0f;
+#pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int y = yo + 4 * g + r;
-                const float cr = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
-                int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
-                int nx = min(x + HI, W - 1) - max(x + LO, 0) + 1;
-                float v = (float)NCC_NEVER;
-                if (y < H && x < W) {
-                    const double nn = (double)(ny * nx), sum_t = ry[y] * rx[x];
-                    v = (float)(cr == 0.0f ? ncc_theta_empty(nn, sum_t, mu, nc) : ncc_theta_border((double)cr, nn, sum_t, mu, nc));
-                }
-                th[0] = r == 0 ? v : th[0]; th[1] = r == 1 ? v : th[1]; th[2] = r == 2 ? v : th[2]; th[3] = r == 3 ? v : th[3];
+                const int yc = min(yo + 4 * g + r, H - 1);
+                const float cf = C[r];
+                const float nn = (float)(min(yc + HI, H - 1) - max(yc + LO, 0) + 1) * nxf, st = (float)ry[yc] * rxf;
+                const float rest = -(ktf * cf) - muf * (st - nn * tbarf);
+                const float var = 65025.0f * cf * (1.0f - cf * il2f) + (1.0f - nn * il2f) * muf * (nn * muf - 510.0f * cf);
+                const float t1 = (__builtin_amdgcn_sqrtf(fmaxf(krf * var, 0.0f)) - rest) * (float)(NCC_WSCALE * NCC_WSCALE / 255.0);
+                // empty window: G = 0, num = rest = -mu d0 and rhs = thr2 T2 a nn mu^2: background unless d0 < 0 and
+                // d0^2 > thr2 T2 a nn (mu cancels); decided here with a factor 2 to spare, else left to the exact path
+                const float d0 = st - nn * tbarf, a0 = 1.0f - nn * il2f;
+                th[r] = cf == 0.0f ? ((d0 > -1e-4f || d0 * d0 < 0.5f * krf * a0 * nn) ? (float)NCC_NEVER : 0.0f) : t1;
             }
         }
         const bool allvalid = (yo + 15 < H) && (xw + 15 < W);   // uniform
         u64 pw[4], uw[4], any = 0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const float m = __builtin_fmaf(th[r], NCC_REL, NCC_ABS), d = G[r] - th[r];
+            const float m = __builtin_fmaf(fabsf(th[r]), rel, abs_), d = G[r] - th[r];
             const u64 pb = __ballot(d > m), fb = __ballot(d < -m);
             const u64 vm = allvalid ? ~0ull : __ballot((yo + 4 * g + r < H) && (x < W));
             pw[r] = pb & vm;
