@@ -1027,27 +1027,43 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
     for (int i = tid; i < nb_; i += blockDim.x) claim[i] = 0;
     if (tid == 0) dup_s = force_seq;
     __syncthreads();
-    for (int ci = tid; ci < na; ci += blockDim.x) {
-        const double* e = ell + ci * 8;
-        int bi = -1;
-        if (e[6] != 0.0 && e[5] >= 5.0) {               // len(contour) >= 5 (:204) and a valid fit
-            double ecx = e[0], ecy = e[1], w = e[2], hh = e[3];
-            double minor = (w > hh) ? hh : w;
+    // The polygon test walks global tables (a chain of dependent loads): it is run for the NEAREST candidate only and
+    // by all lanes of a wave together; a rejected candidate (rare) sends its lane round again for the next-nearest,
+    // candidates ordered by (distance, index) as the reference's strict "<" over ascending indices does.
+    for (int c0 = 0; c0 < na; c0 += blockDim.x) {
+        const int ci = c0 + tid;
+        const double* e = ell + min(ci, na - 1) * 8;
+        bool active = false;
+        double ecx = 0, ecy = 0, thr = 0;
+        if (ci < na && e[6] != 0.0 && e[5] >= 5.0) {    // len(contour) >= 5 (:204) and a valid fit
+            ecx = e[0]; ecy = e[1];
+            const double w = e[2], hh = e[3], minor = (w > hh) ? hh : w;
             if (!(minor < 5.0)) {                       // (:219)
-                double thr = (minor / 10.0) * (minor / 10.0);
-                double best = 1e300;
-                for (int i = 0; i < nb_; ++i) {
-                    double dx = bx[i] - ecx, dy = by[i] - ecy;
-                    double d = dx * dx + dy * dy;
-                    if (d < thr && d < best &&
-                        inside_polygon(bits, wbase, node_comp, H, W, WW, bx[i], by[i], (u32)ci)) {
-                        best = d; bi = i;
-                    }
-                }
+                thr = (minor / 10.0) * (minor / 10.0);
+                active = true;
             }
         }
-        best_of[ci] = bi;
-        if (bi >= 0 && atomicAdd(&claim[bi], 1) > 0) dup_s = 1;
+        int bi = -1, lasti = -1;
+        double lastd = -1.0;
+        for (;;) {
+            double best = 1e300;
+            int cand = -1;
+            if (active)
+                for (int i = 0; i < nb_; ++i) {
+                    const double dx = bx[i] - ecx, dy = by[i] - ecy, d = dx * dx + dy * dy;
+                    if (d < thr && d < best && (d > lastd || (d == lastd && i > lasti))) { best = d; cand = i; }
+                }
+            const bool need = active && cand >= 0;
+            if (!__any(need)) break;
+            const bool ok = need && inside_polygon(bits, wbase, node_comp, H, W, WW, bx[max(cand, 0)], by[max(cand, 0)], (u32)ci);
+            if (ok) { bi = cand; active = false; }
+            else if (need) { lastd = best; lasti = cand; }
+            else active = false;
+        }
+        if (ci < na) {
+            best_of[ci] = bi;
+            if (bi >= 0 && atomicAdd(&claim[bi], 1) > 0) dup_s = 1;
+        }
     }
     __syncthreads();
     if (!dup_s) {
