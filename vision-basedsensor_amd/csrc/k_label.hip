@@ -669,35 +669,28 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         if (nholes) atomicAdd(&fstat[n * 8 + 7], nholes);
         return;
     }
+    // One work item per RUN (node): its position comes back from node_pos, its extent from the bits; every lane has
+    // work (a word walk leaves most lanes idle on a marker frame) and the sums go to the component's LDS accumulators.
     if (m == 0) {
-        u32 rowbase = wfirst[wave];
-        u32 curc = NONE32, c_cnt = 0;
-        u64 c_sx = 0, c_sy = 0;
-        PF_INIT(bits, ya, yb)
-        for (int y = ya; y < yb; y += G) {
-            u64 wv; PF_NEXT(bits, y, yb, wv)
-            const int yr = y + g;
-            RowState cur = make_row_state(wv, j, rowbase);
-            u64 w = wv;
-            while (w) {
-                u64 lowbit = w & (~w + 1ull);
-                u64 t = w + lowbit;
-                u64 gg = w & ~t;
-                w &= t;
-                int k0 = __ffsll((long long)gg) - 1;
-                u32 len = __popcll(gg);
-                u32 cid = cid16[node_in_row(cur, k0)];
-                if (cid != curc) {
-                    if (c_cnt) { atomicAdd(&acc_cnt[curc], c_cnt); atomicAdd(&acc_sx[curc], c_sx); atomicAdd(&acc_sy[curc], c_sy); }
-                    curc = cid; c_cnt = 0; c_sx = 0; c_sy = 0;
+        for (u32 i = tid; i < nruns; i += nthr) {
+            const u32 cid = cid16[i], pos = node_pos[i];
+            const u32 y = pos / (u32)W, x0 = pos - y * (u32)W;
+            const u64* row = bits + (int64_t)y * WW;
+            int jw = (int)(x0 >> 6);
+            const int b0 = (int)(x0 & 63);
+            const u64 t = ~(row[jw] >> b0);
+            u32 len = t ? (u32)(__ffsll((long long)t) - 1) : 64u;
+            if (b0 + (int)len == 64)                     // reaches the word's last bit: continues while the next words start with 1s
+                for (++jw; jw < WW; ++jw) {
+                    const u64 nw = ~row[jw];
+                    const u32 tz = nw ? (u32)(__ffsll((long long)nw) - 1) : 64u;
+                    len += tz;
+                    if (tz < 64) break;
                 }
-                u64 x0 = 64 * j + k0;
-                c_cnt += len;
-                c_sx += (u64)len * x0 + (u64)len * (len - 1) / 2;
-                c_sy += (u64)len * (u64)yr;
-            }
+            atomicAdd(&acc_cnt[cid], len);
+            atomicAdd(&acc_sx[cid], (u64)len * x0 + (u64)len * (len - 1) / 2);
+            atomicAdd(&acc_sy[cid], (u64)len * (u64)y);
         }
-        if (c_cnt) { atomicAdd(&acc_cnt[curc], c_cnt); atomicAdd(&acc_sx[curc], c_sx); atomicAdd(&acc_sy[curc], c_sy); }
         __syncthreads();
         u64* bs = band_sums + (int64_t)n * maxm * 4;
         for (u32 c = tid; c < ncomp; c += nthr) {
@@ -706,106 +699,99 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
             bs[c * 4 + 2] = acc_sy[c];
         }
     } else {
-        u32 rowbase = wfirst[wave];
-        u32 curc = NONE32;
-        int ax = 0, ay = 0, e4 = 0;
-        bool any = false;
-        i64 s[NMOM];
-#pragma unroll
-        for (int q = 0; q < NMOM; ++q) s[q] = 0;
-        const int dn_src = (g + 1 < G) ? lane + WW : lane - (G - 1) * WW;   // lane holding the word one row down
-        // raw words of the previous step (for "up" of g == 0): before the first step, row ya-1 sits in group G-1
-        u64 wlast = (act && g == G - 1 && ya > 0) ? bits[(int64_t)(ya - 1) * WW + j] : 0ull;
-        PF_INIT(bits, ya, H)                            // raw rows, also beyond yb: they are some row's "down" row
-        for (int y = ya; y < yb; y += G) {
-            u64 wraw; PF_NEXT(bits, y, H, wraw)
-            const int yr = y + g;
-            const bool mine = act && yr < yb;           // rows >= yb belong to the next strip
-            const u64 wv = mine ? wraw : 0ull;
-            RowState cur = make_row_state(wv, j, rowbase);
-            const u64 ua = __shfl(wraw, up_src), ub = __shfl(wlast, up_src);
-            const u64 da = __shfl(wraw, dn_src), db = __shfl(pf0, dn_src);   // pf0 = the next step's raw words
-            const u64 up = g ? ua : ub;
-            const u64 dn = (g + 1 < G) ? da : db;
-            wlast = wraw;
-            const u64 wn_t = dpp_shl1(wv), wp_t = dpp_shr1(wv);
-            const u64 wn_ = (j + 1 < WW) ? wn_t : 0ull, wp_ = j ? wp_t : 0ull;
-            const u64 un_t = dpp_shl1(up), up_t = dpp_shr1(up), dn_t = dpp_shl1(dn), dp_t = dpp_shr1(dn);
-            const u64 un_ = (j + 1 < WW) ? un_t : 0ull, up_ = j ? up_t : 0ull, dn_ = (j + 1 < WW) ? dn_t : 0ull,
-                      dp_ = j ? dp_t : 0ull;
-            // Euler number by bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the
-            // zero-padded image; window (x, y) = pixels (x..x+1, y..y+1).  A lane counts the windows whose top row is its
-            // own row (and, for row 0, the padding row above it).  holes = components - E.
-            if (mine) {
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    if (q == 1 && yr != 0) continue;
-                    const u64 a = q ? 0ull : wv, an = q ? 0ull : wn_, b = q ? wv : dn, bn = q ? wn_ : dn_;
-                    if (a | b | (an & 1ull) | (bn & 1ull)) {
-                        u64 a1 = (a >> 1) | (an << 63), b1 = (b >> 1) | (bn << 63);
-                        u64 x2 = (a ^ a1) ^ (b ^ b1);
-                        u64 pairs = (a & a1) | (a & b) | (a & b1) | (a1 & b) | (a1 & b1) | (b & b1);
-                        u64 qd = (a & b1 & ~a1 & ~b) | (a1 & b & ~a & ~b1);
-                        e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
-                        if (j == 0) e4 += (int)((a ^ b) & 1ull);             // window x = -1: only (0,y), (0,y+1)
-                    }
-                }
+        // Euler number by bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the
+        // zero-padded image; window (x, y) = pixels (x..x+1, y..y+1).  A work item counts the windows whose top row is
+        // its word's row (and, for row 0, the padding row above it).  holes = components - E.
+        int e4 = 0;
+        for (int idx = tid; idx < NW; idx += nthr) {
+            const int yr = idx / WW, jc = idx - yr * WW;
+            const u64 wv = bits[idx];
+            const u64 dn = yr + 1 < H ? bits[idx + WW] : 0ull;
+            if (!(wv | dn) && !(yr == 0)) {
+                if (jc + 1 >= WW) continue;
+                if (!((bits[idx + 1] | (yr + 1 < H ? bits[idx + 1 + WW] : 0ull)) & 1ull)) continue;
             }
-            const u64 w = wv;
-            if (w) {
-                const u64 E = (w >> 1) | (wn_ << 63), Wd = (w << 1) | (wp_ >> 63);
-                const u64 NE = (up >> 1) | (un_ << 63), NWd = (up << 1) | (up_ >> 63);
-                const u64 SE = (dn >> 1) | (dn_ << 63), SW = (dn << 1) | (dp_ >> 63);
-                const u64 border = w & ~(up & dn & E & Wd);
-                u64 rest = w;
-                while (rest) {                          // one group (= part of one run) at a time
-                    u64 lowbit = rest & (~rest + 1ull);
-                    u64 t = rest + lowbit;
-                    u64 gg = rest & ~t;
-                    rest &= t;
-                    u64 bg = border & gg;
-                    if (!bg) continue;
-                    u32 cid = cid16[node_in_row(cur, __ffsll((long long)gg) - 1)];
-                    if (cid != curc) {
-                        if (any) {
+            const u64 wn_ = jc + 1 < WW ? bits[idx + 1] : 0ull;
+            const u64 dn_ = (jc + 1 < WW && yr + 1 < H) ? bits[idx + 1 + WW] : 0ull;
 #pragma unroll
-                            for (int q = 0; q < NMOM; ++q)
-                                if (s[q]) atomicAdd(&acc[curc * NMOM + q], (u64)s[q]);
-#pragma unroll
-                            for (int q = 0; q < NMOM; ++q) s[q] = 0;
-                            any = false;
-                        }
-                        curc = cid;
-                        u32 fp = acc_cnt[cid];
-                        ax = fp % W; ay = fp / W;
-                    }
-                    while (bg) {
-                        int k = __ffsll((long long)bg) - 1;
-                        bg &= bg - 1;
-                        u32 pat = (u32)((E >> k) & 1ull) | ((u32)((NE >> k) & 1ull) << 1) |
-                                  ((u32)((up >> k) & 1ull) << 2) | ((u32)((NWd >> k) & 1ull) << 3) |
-                                  ((u32)((Wd >> k) & 1ull) << 4) | ((u32)((SW >> k) & 1ull) << 5) |
-                                  ((u32)((dn >> k) & 1ull) << 6) | ((u32)((SE >> k) & 1ull) << 7);
-                        i64 mult = lut[pat];
-                        if (!mult) continue;
-                        any = true;
-                        i64 dx = 64 * j + k - ax, dy = yr - ay;
-                        i64 x2 = dx * dx, y2 = dy * dy;
-                        s[0] += mult;
-                        s[1] += mult * dx;            s[2] += mult * dy;
-                        s[3] += mult * x2;            s[4] += mult * dx * dy;       s[5] += mult * y2;
-                        s[6] += mult * x2 * dx;       s[7] += mult * x2 * dy;       s[8] += mult * dx * y2;
-                        s[9] += mult * y2 * dy;
-                        s[10] += mult * x2 * x2;      s[11] += mult * x2 * dx * dy; s[12] += mult * x2 * y2;
-                        s[13] += mult * dx * dy * y2; s[14] += mult * y2 * y2;
-                    }
+            for (int q = 0; q < 2; ++q) {
+                if (q == 1 && yr != 0) continue;
+                const u64 a = q ? 0ull : wv, an = q ? 0ull : wn_, bq = q ? wv : dn, bn = q ? wn_ : dn_;
+                if (a | bq | (an & 1ull) | (bn & 1ull)) {
+                    u64 a1 = (a >> 1) | (an << 63), b1 = (bq >> 1) | (bn << 63);
+                    u64 x2 = (a ^ a1) ^ (bq ^ b1);
+                    u64 pairs = (a & a1) | (a & bq) | (a & b1) | (a1 & bq) | (a1 & b1) | (bq & b1);
+                    u64 qd = (a & b1 & ~a1 & ~bq) | (a1 & bq & ~a & ~b1);
+                    e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
+                    if (jc == 0) e4 += (int)((a ^ bq) & 1ull);               // window x = -1: only (0,y), (0,y+1)
                 }
             }
         }
-        if (any) {
+        for (u32 i = tid; i < nruns; i += nthr) {
+            const u32 cid = cid16[i], pos = node_pos[i];
+            const int y = (int)(pos / (u32)W), x0 = (int)(pos - (u32)y * (u32)W);
+            const u32 fp = acc_cnt[cid];
+            const int ay = (int)(fp / (u32)W), ax = (int)(fp - (u32)ay * (u32)W);
+            const u64* rowm = bits + (int64_t)y * WW;
+            const bool hasu = y > 0, hasd = y + 1 < H;
+            i64 s[NMOM];
+#pragma unroll
+            for (int q = 0; q < NMOM; ++q) s[q] = 0;
+            bool more = true;
+            for (int jw = x0 >> 6; more && jw < WW; ++jw) {      // word segments of the run
+                const u64 w = rowm[jw];
+                const int lo = jw == (x0 >> 6) ? (x0 & 63) : 0;
+                const u64 t = ~(w >> lo);
+                const int len = t ? __ffsll((long long)t) - 1 : 64;
+                if (len == 0) break;                             // (the run ended exactly at the previous word's last bit)
+                const int hi = lo + len - 1;
+                more = hi == 63;
+                const u64 gg = (hi == 63 ? ~0ull : ((1ull << (hi + 1)) - 1ull)) & ~((1ull << lo) - 1ull);
+                const bool contR = more && jw + 1 < WW && (rowm[jw + 1] & 1ull);     // the run goes on in the next word
+                const u64 up = hasu ? rowm[jw - WW] : 0ull, dn = hasd ? rowm[jw + WW] : 0ull;
+                u64 upL = 0, upR = 0, dnL = 0, dnR = 0;  // edge bits of the neighbouring words, only where a pixel needs them
+                if (lo == 0 && jw > 0) { upL = hasu ? rowm[jw - 1 - WW] >> 63 : 0ull; dnL = hasd ? rowm[jw - 1 + WW] >> 63 : 0ull; }
+                if (hi == 63 && jw + 1 < WW) { upR = hasu ? rowm[jw + 1 - WW] & 1ull : 0ull; dnR = hasd ? rowm[jw + 1 + WW] & 1ull : 0ull; }
+                const u64 E = (gg >> 1) | (contR ? 1ull << 63 : 0ull);
+                const u64 Wd = (gg << 1) | (jw > (x0 >> 6) ? 1ull : 0ull);
+                const u64 NE = (up >> 1) | (upR << 63), NWd = (up << 1) | upL;
+                const u64 SE = (dn >> 1) | (dnR << 63), SW = (dn << 1) | dnL;
+                u64 bg = gg & ~(up & dn & E & Wd);
+                while (bg) {
+                    const int k = __ffsll((long long)bg) - 1;
+                    bg &= bg - 1;
+                    const u32 pat = (u32)((E >> k) & 1ull) | ((u32)((NE >> k) & 1ull) << 1) |
+                                    ((u32)((up >> k) & 1ull) << 2) | ((u32)((NWd >> k) & 1ull) << 3) |
+                                    ((u32)((Wd >> k) & 1ull) << 4) | ((u32)((SW >> k) & 1ull) << 5) |
+                                    ((u32)((dn >> k) & 1ull) << 6) | ((u32)((SE >> k) & 1ull) << 7);
+                    const int mult = lut[pat];
+                    if (!mult) continue;
+                    const int dx = 64 * jw + k - ax, dy = y - ay;
+                    if (max(abs(dx), abs(dy)) <= 150) {          // 4 * 150^4 < 2^31: products in 32 bits, sums in 64
+                        const int x2 = dx * dx, y2 = dy * dy, mx = mult * dx, my = mult * dy;
+                        s[0] += mult;
+                        s[1] += mx;                 s[2] += my;
+                        s[3] += mx * dx;            s[4] += mx * dy;            s[5] += my * dy;
+                        s[6] += mx * x2;            s[7] += my * x2;            s[8] += mx * y2;
+                        s[9] += my * y2;
+                        s[10] += mult * x2 * x2;    s[11] += mx * x2 * dy;      s[12] += mult * x2 * y2;
+                        s[13] += mx * dy * y2;      s[14] += mult * y2 * y2;
+                    } else {
+                        const i64 ml = mult, dl = dx, el = dy, x2 = dl * dl, y2 = el * el;
+                        s[0] += ml;
+                        s[1] += ml * dl;            s[2] += ml * el;
+                        s[3] += ml * x2;            s[4] += ml * dl * el;       s[5] += ml * y2;
+                        s[6] += ml * x2 * dl;       s[7] += ml * x2 * el;       s[8] += ml * dl * y2;
+                        s[9] += ml * y2 * el;
+                        s[10] += ml * x2 * x2;      s[11] += ml * x2 * dl * el; s[12] += ml * x2 * y2;
+                        s[13] += ml * dl * el * y2; s[14] += ml * y2 * y2;
+                    }
+                }
+                if (!contR) break;
+            }
 #pragma unroll
             for (int q = 0; q < NMOM; ++q)
-                if (s[q]) atomicAdd(&acc[curc * NMOM + q], (u64)s[q]);
+                if (s[q]) atomicAdd(&acc[cid * NMOM + q], (u64)s[q]);
         }
         if (e4) atomicAdd(&euler4, e4);
         __syncthreads();
