@@ -80,6 +80,39 @@ def test_find_markers_bit_exact(tag, channels, crop):
     eng.close()
 
 
+@pytest.mark.parametrize("h,w,pitch,dia", [(470, 650, 60, 20), (700, 1003, 72, 40)])
+def test_find_markers_borders_and_odd_sizes(h, w, pitch, dia):
+    """a4-a8 where the matrix-core kernels leave their fast paths: sizes that are no multiple of the 32 / 64 / 128
+    pixel tiles, and dots cut by all four image borders (reflect-101 staging of the blurs; NCC windows that leave the
+    image take the general threshold and, where it is close, the exact float64 path).  Both branches of :117."""
+    n = max(h, w) // pitch + 4
+    spec = S.grid_spec(w + 3 * pitch, h + 3 * pitch, n, pitch, dia, name="cut")
+    gx0, gy0 = spec.grid[2] / 16.0, spec.grid[3] / 16.0
+    big = S.make_frames(spec, [0, 2], seed=9)
+
+    def off(g0, size, far):                # crop origin that puts a dot centre 3 px inside the near / 4 px inside the far border
+        c = g0 + (int(np.ceil((pitch - g0) / pitch)) + 1) * pitch
+        o = int(round(c + 4 - (size - 1))) if far else int(round(c - 3))
+        return o + pitch * max(0, -(o // pitch))
+    offs = [(off(gy0, h, False), off(gx0, w, False)), (off(gy0, h, True), off(gx0, w, True))]
+    frames = np.stack([big[i][oy:oy + h, ox:ox + w] for i, (oy, ox) in enumerate(offs)])
+    cut = np.zeros(4, bool)
+    eng = engine(h, w, max_batch=2)
+    mask, area = eng.find_markers(torch.from_numpy(np.ascontiguousarray(frames)).cuda())
+    stats = eng.frame_stats(2)
+    for i in range(2):
+        om, oa = O.find_markers(frames[i])
+        assert np.array_equal(area[i].cpu().numpy(), oa)
+        assert np.array_equal(mask[i].cpu().numpy(), om)
+        cut |= np.array([oa[0].any() and om[0].any(), oa[-1].any() and om[-1].any(), oa[:, 0].any() and om[:, 0].any(),
+                         oa[:, -1].any() and om[:, -1].any()])
+        assert stats[i, 0] == (oa > 0).sum() and stats[i, 1] == 0
+        from vbs_amd.marker_detection import MarkerTracker
+        compare_markers(MarkerTracker._marker_center(om, oa), O.marker_center(om, oa))      # blobs cut by the border
+    assert cut.all(), "a border without a cut dot in both masks"
+    eng.close()
+
+
 def test_bgr_weights_and_dog_wrap():
     """a3: the cv2 fixed-point BGR weights on a frame with B != G != R; a4/a5: the mod-256 wrap and the
     upper inRange bound on a high-contrast frame (bright discs on black wrap to large values)."""
