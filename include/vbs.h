@@ -178,6 +178,19 @@ int vbs_displacement_f64(int device, const double* table, int n, int m_ref, int 
  * with VBS_FLAG_XYZ, tilt = atan(sqrt(a^2+b^2)) in degrees.  plane [dev] float32 [n,VBS_PLANE_COLS]. */
 int vbs_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane, void* stream);
 
+/* Frame-0 identity assignment on the device — `MarkerTracker._process_first_frame`
+ * (marker_detection.py:275-347; inlined again at tracking.py:106-178): the marker nearest the mean is (0,0), the
+ * others' radii are clustered into `num_layers` rings (exact 1-D k-means, the deterministic stand-in for the
+ * reference's unseeded KMeans) and each ring is ordered by angle from the member nearest angle 0.
+ *   det [dev]     float64 [*count][VBS_DET_COLS] rows of frame 0 as vbs_marker_center / vbs_track_to_3d write them
+ *   count [dev]   int32[1] number of rows (a device status s < 0 comes back as m_out = 1000 s)
+ *   id_mode       0 = "as_written" (the published `(layer,-1)` key collision: 1 + num_layers IDs), 1 = "full"
+ *   ids [dev]     int32 [cap][2] (layer, index) in the reference dict's order; ref_xy [dev] float64 [cap][2] (Ox, Oy):
+ *                 the table vbs_track / vbs_track_to_3d take as `ref_xy`
+ *   m_out [dev]   int32[1] number of IDs; -1 = no markers ("No markers detected in first frame!"), -2 = cap too small */
+int vbs_assign_ids(vbs_handle* h, const double* det, const int32_t* count, int num_layers, int id_mode,
+                   int32_t* ids, double* ref_xy, int cap, int32_t* m_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

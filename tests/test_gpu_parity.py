@@ -398,6 +398,40 @@ def test_marker_tracker_process_frames(tmp_path, tag, id_mode):
         assert len(ref) == spec.n_markers
 
 
+@pytest.mark.parametrize("tag", ["ring", "c1", "c2", "c5"])
+@pytest.mark.parametrize("id_mode", ["as_written", "full"])
+def test_assign_ids_on_device(tag, id_mode):
+    """a14 / f4: `vbs_assign_ids` (frame-0 identities on the device) against the host restatement `ids.assign_ids`
+    (itself pinned to the reference body's golden, tests/test_host_logic.py): same keys in the same dict order, same
+    reference coordinates, on the detections of a real frame 0."""
+    from vbs_amd.pipeline import _det_to_markers
+    spec = {"ring": S.ring65_spec(), "c1": S.config1(), "c2": S.config2(), "c5": S.config5()}[tag]
+    frame = torch.from_numpy(S.make_frames(spec, [0], seed=4)).cuda()
+    eng = engine(spec.height, spec.width, max_batch=1)
+    _, det, counts = eng.track_to_3d(frame, None, want_det=True)
+    n0 = int(counts[0].item())
+    assert n0 == spec.n_markers
+    table = I.assign_ids(_det_to_markers(det[0].cpu().numpy(), n0), 5, id_mode, "optimal")
+    want_ids, want_xy = I.reference_arrays(table)
+    ids, xy = eng.assign_ids(det, counts, 5, id_mode)
+    ids, xy = ids.cpu().numpy().astype(np.int64), xy.cpu().numpy()
+    assert np.array_equal(ids, want_ids)
+    # bit-exact float64 coordinates in the same order - except among markers whose angles are mathematically equal
+    # (collinear with the centre: np.arctan2's last bit orders them on the host, the device's atan2 here)
+    bad = np.where((xy != want_xy).any(axis=1))[0]
+    keys = list(table.keys())
+    for b in bad:
+        tb = table[keys[b]]["angle_rad"]
+        twins = [j for j in bad if j != b and keys[j][0] == keys[b][0] and
+                 abs(table[keys[j]]["angle_rad"] - tb) <= 4 * np.spacing(abs(tb)) and np.array_equal(xy[b], want_xy[j])]
+        assert twins, (keys[b], xy[b], want_xy[b])
+    assert len(bad) <= 4
+    empty = torch.zeros_like(counts)
+    with pytest.raises(ValueError, match="No markers detected"):
+        eng.assign_ids(det, empty, 5, id_mode)
+    eng.close()
+
+
 def test_track_markers_method_and_drop_rules():
     """a15 through the reference-shaped method: nearest (first on ties), > min_distance dropped, two
     references may claim one detection."""

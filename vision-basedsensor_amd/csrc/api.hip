@@ -478,3 +478,15 @@ extern "C" int vbs_plane_fit(vbs_handle* h, const float* table, int n, int m_ref
     if (n) launch_plane_fit(h, table, n, m_ref, plane, (hipStream_t)stream);
     return check_launch(h);
 }
+
+extern "C" int vbs_assign_ids(vbs_handle* h, const double* det, const int32_t* count, int num_layers, int id_mode,
+                              int32_t* ids, double* ref_xy, int cap, int32_t* m_out, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!det || !count || !ids || !ref_xy || !m_out || num_layers < 1 || cap < 1 || (id_mode != 0 && id_mode != 1)) {
+        h->err = "vbs_assign_ids: bad argument";
+        return VBS_EINVAL;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_assign_ids(h, det, count, num_layers, id_mode, ids, ref_xy, cap, m_out, (hipStream_t)stream);
+    return check_launch(h);
+}

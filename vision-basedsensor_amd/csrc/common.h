@@ -112,6 +112,8 @@ void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, in
                          double min_size, double max_disp, int f0, int f1, float* disp, hipStream_t s);
 void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane,
                       hipStream_t s);
+void launch_assign_ids(vbs_handle* h, const double* det, const int32_t* count, int num_layers, int full_mode,
+                       int32_t* ids_out, double* xy_out, int cap, int32_t* m_out, hipStream_t s);
 void make_contour_lut(u8 out[256]);
 std::vector<u32> ncc_mfma_fragments(const NccConst& nc, int l);
 std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::vector<int>& taps_b, int nk,

@@ -236,6 +236,32 @@ class Engine:
         return plane
 
 
+    # ---- a14 / f4 ------------------------------------------------------------------------------
+    def assign_ids(self, det, counts, num_layers=5, id_mode="as_written"):
+        """Frame-0 identities on the device: (ids int32 [M,2], ref_xy float64 [M,2]) as device tensors, in the
+        reference dict's order.  `det` / `counts` are frame 0's rows of `marker_center` / `track_to_3d(want_det=True)`."""
+        if id_mode not in ("as_written", "full"):
+            raise ValueError(f"id_mode must be 'as_written' or 'full', got {id_mode!r}")
+        det0 = (det[0] if det.dim() == 3 else det).contiguous()
+        cnt0 = counts.reshape(-1)[:1].contiguous()
+        cap = det0.shape[0] + 1
+        ids = torch.zeros((cap, 2), dtype=torch.int32, device=self.device)
+        xy = torch.zeros((cap, 2), dtype=torch.float64, device=self.device)
+        m = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_assign_ids(self._h, _ptr(det0), _ptr(cnt0), int(num_layers),
+                                                1 if id_mode == "full" else 0, _ptr(ids), _ptr(xy), cap, _ptr(m),
+                                                self._stream()), "vbs_assign_ids")
+        mm = int(m.item())
+        if mm == -1:
+            raise ValueError("No markers detected in first frame!")
+        if mm <= -1000:
+            raise L.VbsError(f"device status {mm // 1000} in frame 0")
+        if mm < 0:
+            raise L.VbsError(f"vbs_assign_ids: device status {mm}")
+        return ids[:mm], xy[:mm]
+
+
 def _dev_f64(x, dev, cols):
     if isinstance(x, torch.Tensor):
         return x.to(device=dev, dtype=torch.float64).reshape(-1, cols).contiguous()

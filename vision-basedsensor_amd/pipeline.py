@@ -26,9 +26,16 @@ class TrackResult:
     frame_end: int = 0
 
 
-def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mode="full", kmeans="optimal"):
-    """Detect frame 0 on the device and run the host-side ID assignment (once per video)."""
+def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mode="full", kmeans="optimal",
+                          ids_on_device=False):
+    """Detect frame 0 on the device and assign the identities (once per video).  `ids_on_device` runs the assignment
+    on the GPU as well (`vbs_assign_ids`, deterministic clustering only); it equals the host result except that
+    markers at mathematically equal angles (collinear with the centre) are ordered by the device's atan2 instead of
+    libm's, whose last bit decides such ties on the host."""
     _, det, counts = eng.track_to_3d(frame0[:1], None, want_det=True)
+    if ids_on_device and kmeans == "optimal":
+        ids, xy = eng.assign_ids(det, counts, num_layers, id_mode)
+        return ids.cpu().numpy().astype("int64"), xy.cpu().numpy()
     n0 = int(counts[0].item())
     if n0 < 0:
         raise L.VbsError(f"device status {n0} in frame 0")
