@@ -105,8 +105,8 @@ extern "C" int vbs_ncc_template(int l, double sigma, double* g, double* stats) {
 
 extern "C" int vbs_destroy(vbs_handle* h) {
     if (!h) return VBS_EINVAL;
-    hipSetDevice(h->device);
-    for (void* p : h->allocs) hipFree(p);
+    (void)hipSetDevice(h->device);
+    for (void* p : h->allocs) (void)hipFree(p);
     delete h;
     return VBS_OK;
 }

@@ -1080,7 +1080,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
             }
             ++base;
         }
-        if (tid == blockDim.x - 1) { cnt64[n] = base; if (cnt32) cnt32[n] = base; }
+        if (tid == (int)blockDim.x - 1) { cnt64[n] = base; if (cnt32) cnt32[n] = base; }
         return;
     }
     if (tid >= 64) return;
