@@ -110,6 +110,11 @@ def test_find_markers_borders_and_odd_sizes(h, w, pitch, dia):
         from vbs_amd.marker_detection import MarkerTracker
         compare_markers(MarkerTracker._marker_center(om, oa), O.marker_center(om, oa))      # blobs cut by the border
     assert cut.all(), "a border without a cut dot in both masks"
+    # the same crops as strided views of the big gray frames (odd byte offsets: the blur's unaligned staging path)
+    bt = torch.from_numpy(big).cuda()
+    for i, (oy, ox) in enumerate(offs):
+        m2, a2 = eng.find_markers(bt[i:i + 1, oy:oy + h, ox:ox + w])
+        assert torch.equal(m2[0], mask[i]) and torch.equal(a2[0], area[i])
     eng.close()
 
 
