@@ -84,18 +84,23 @@ void launch_threshold(vbs_handle* h, const u8* mask, const u8* area, int nb, hip
 }
 
 // ------------------------------------------------------------------------------------------------
-// horizontal window AND / OR of one row word over dx in [lo, hi] given its left / right neighbour words
+// horizontal window AND / OR of one row word over dx in [lo, hi] (lo <= 0 <= hi, hi - lo < 64) given its left / right
+// neighbour words.  The 128 bits from position lo on are combined with themselves shifted by 1, 2, 4, ... (AND and OR
+// are idempotent, so the last shift may overlap): log2(window) steps instead of one per offset.
 template <bool ERODE>
 __device__ __forceinline__ u64 hmorph(u64 wl, u64 wc, u64 wr, int lo, int hi) {
-    u64 acc = ERODE ? ~0ull : 0ull;
-    for (int dx = lo; dx <= hi; ++dx) {
-        u64 v;
-        if (dx < 0) v = (wc << (-dx)) | (wl >> (64 + dx));
-        else if (dx > 0) v = (wc >> dx) | (wr << (64 - dx));
-        else v = wc;
-        acc = ERODE ? (acc & v) : (acc | v);
+    const int pre = -lo, n = hi - lo + 1;               // bit p of (ulo, uhi) = pixel p - pre
+    u64 ulo = pre ? ((wl >> (64 - pre)) | (wc << pre)) : wc;
+    u64 uhi = pre ? ((wc >> (64 - pre)) | (wr << pre)) : wr;
+    int have = 1;
+    while (have < n) {
+        const int s = min(have, n - have);
+        const u64 slo = (ulo >> s) | (uhi << (64 - s)), shi = uhi >> s;      // (positions past the 128 bits are never used)
+        ulo = ERODE ? (ulo & slo) : (ulo | slo);
+        uhi = ERODE ? (uhi & shi) : (uhi | shi);
+        have += s;
     }
-    return acc;
+    return ulo;                                          // bit i = AND / OR of pixels i + lo .. i + hi
 }
 
 // band = mask & ~erode_ns(mask) and open = dilate5(erode5(area)), separably, one workgroup per tile of MR rows:
