@@ -54,3 +54,23 @@ out = {"tag": tag, "frames_per_launch": frames, "stage": "+".join(stage),
                "taken at face value"}
 json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
 print(json.dumps(out)[:400])
+
+# SQ counters of the matrix-core kernels (optional passes of collect.sh): last launch of each kernel
+sq = {}
+for pat in (f"pmc_sqa_{tag}/**/*counter_collection.csv", f"pmc_sqb_{tag}/**/*counter_collection.csv"):
+    f = sorted(glob.glob(os.path.join(G, pat), recursive=True))
+    if not f:
+        continue
+    for r in csv.DictReader(open(f[-1])):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+        sq.setdefault(k, {})[r["Counter_Name"]] = float(r["Counter_Value"])
+if sq:
+    for k, c in sq.items():
+        if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"]:
+            w = c["SQ_WAVE_CYCLES"]                     # quad-cycles, like the WAIT / ACTIVE counters
+            c["frac_wait_any"] = round(c.get("SQ_WAIT_ANY", 0) / w, 3)
+            c["frac_wait_inst"] = round(c.get("SQ_WAIT_INST_ANY", 0) / w, 3)
+            c["frac_active"] = round(c.get("SQ_ACTIVE_INST_ANY", 0) / w, 3)
+    json.dump({"tag": tag, "frames_per_launch": frames, "note": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles, "
+               "SQ_VALU_MFMA_BUSY_CYCLES in cycles summed over the 1024 SIMDs; one launch over `frames_per_launch` frames",
+               "kernels": sq}, open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters.json"), "w"), indent=1)
