@@ -91,6 +91,15 @@ def test_contour_lut_equals_traced_vertices(seed, opened):
     assert lut_vertices(fg.astype(np.uint8), _lut()) == traced
 
 
+def test_contour_lut_straight_edges_have_no_vertex():
+    """k_label drops the inside of straight horizontal edges by bit operations before the per-pixel table walk:
+    that is exact only because both patterns (E, W and the three pixels below / above set) hold no vertex."""
+    lut = _lut()
+    top = 1 | 16 | 32 | 64 | 128          # E, W, SW, S, SE
+    bottom = 1 | 2 | 4 | 8 | 16           # E, NE, N, NW, W
+    assert lut[top] == 0 and lut[bottom] == 0
+
+
 def test_contour_lut_simple_shapes():
     lut = _lut()
     sq = np.zeros((12, 12), np.uint8)

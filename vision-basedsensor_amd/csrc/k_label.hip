@@ -762,6 +762,9 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                 const u64 NE = (up >> 1) | (upR << 63), NWd = (up << 1) | upL;
                 const u64 SE = (dn >> 1) | (dnR << 63), SW = (dn << 1) | dnL;
                 u64 bg = gg & ~(up & dn & E & Wd);
+                // pixels inside a straight horizontal edge (patterns 241 / 31: no vertex, lut = 0) are dropped by bit
+                // operations, so the long top / bottom rows of a blob do not cost one loop turn per pixel
+                bg &= ~(E & Wd & ((~up & ~NE & ~NWd & dn & SE & SW) | (up & NE & NWd & ~dn & ~SE & ~SW)));
                 while (bg) {
                     const int k = __ffsll((long long)bg) - 1;
                     bg &= bg - 1;
