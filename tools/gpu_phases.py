@@ -6,7 +6,7 @@ import vbs_amd.synth as S
 from vbs_amd.engine import Engine
 
 spec = S.config2()
-for batch in (256,):
+for batch in (512,):
     n = batch
     eng = Engine(spec.height, spec.width, max_markers=512, max_batch=batch)
     ft = S.make_frames_torch(spec, range(n), seed=0, device="cuda")
