@@ -629,6 +629,17 @@ def test_batch_and_chunk_independence():
     assert np.array_equal(ft[3].cpu().numpy(), S.make_frames(spec, [3], seed=2)[0])
     eng_a.close()
     eng_b.close()
+    # a pass of 112 frames: the matrix-core kernels then walk whole columns in one piece (the benchmark's launch
+    # shape), small passes split them into row segments that each re-run the filter ramp: same detections
+    n2 = 112
+    f2 = S.make_frames_torch(spec, range(n2), seed=2, device="cuda")
+    eng_c = engine(spec.height, spec.width, max_batch=n2)
+    eng_d = engine(spec.height, spec.width, max_batch=3)
+    _, dc, cc = eng_c.track_to_3d(f2, None, want_det=True)
+    _, dd, cd = eng_d.track_to_3d(f2, None, want_det=True)
+    assert torch.equal(cc, cd) and torch.equal(dc, dd) and int(cc.min()) == spec.n_markers
+    eng_c.close()
+    eng_d.close()
 
 
 def test_engine_argument_errors():
