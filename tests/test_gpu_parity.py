@@ -437,6 +437,41 @@ def test_assign_ids_on_device(tag, id_mode):
     eng.close()
 
 
+def test_marker_tracker_process_on_avi(tmp_path):
+    """a16 / f4: `MarkerTracker.process()` on a Motion-JPEG AVI (the sensor's recording format) through the package's
+    own reader when OpenCV is absent: the CSV equals `process_frames` on the frames that reader decodes."""
+    import pandas as pd
+    from vbs_amd.marker_detection import MarkerTracker
+    from vbs_amd.video_io import AviReader, write_avi
+    pytest.importorskip("PIL")
+    try:
+        import cv2  # noqa: F401
+        pytest.skip("OpenCV present: VideoCapture is used, as in the reference")
+    except ImportError:
+        pass
+    spec = S.config1()
+    frames = S.make_frames(spec, range(4), seed=6, channels=3)
+    path = str(tmp_path / "clip.avi")
+    write_avi(path, frames, fps=30.0, codec="MJPG")
+    cfg = {"video_path": path, "output_dir": str(tmp_path / "o1"), "crop_ratios": (1 / 8, 1 / 8, 1 / 16, 0),
+           "num_layers": 5, "min_marker_distance": 20, "id_mode": "full"}
+    t1 = MarkerTracker(cfg)
+    t1.process()
+    a = pd.read_csv(t1.output_csv, float_precision="round_trip")
+    cap = AviReader(path)
+    dec = []
+    while True:
+        ok, f = cap.read()
+        if not ok:
+            break
+        dec.append(f)
+    t2 = MarkerTracker({**cfg, "output_dir": str(tmp_path / "o2")})
+    rows = t2.process_frames(np.stack(dec))
+    b = pd.DataFrame(rows)
+    assert len(a) == len(b) > 3 * 40 and list(a.columns) == list(b.columns)
+    assert np.array_equal(a.to_numpy(dtype=np.float64), b.to_numpy(dtype=np.float64))
+
+
 def test_track_markers_method_and_drop_rules():
     """a15 through the reference-shaped method: nearest (first on ties), > min_distance dropped, two
     references may claim one detection."""

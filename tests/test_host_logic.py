@@ -84,6 +84,51 @@ def test_marker_tracker_config_errors(tmp_path):
         process_video(video_dir=str(tmp_path / "v"))
 
 
+def test_avi_reader_and_writer(tmp_path):
+    """f4 front end: the package's AVI reader (the `cv2.VideoCapture` subset `_init_video` uses) on files written by its
+    own writer - uncompressed frames come back bit for bit, Motion-JPEG frames equal Pillow's decode of the same
+    chunks (BGR order), headers carry size / rate / count; anything else is 'not opened'."""
+    import io
+    from PIL import Image
+    from vbs_amd.video_io import AviReader, write_avi, CAP_PROP_FPS, CAP_PROP_FRAME_COUNT, CAP_PROP_FRAME_WIDTH, \
+        CAP_PROP_FRAME_HEIGHT
+    spec = S.config1()
+    bgr = S.make_frames(spec, [0, 1, 2], seed=1, channels=3)
+    bgr[..., 0] //= 2                                             # B != R, so a channel swap would show
+    gray = S.make_frames(spec, [0, 1], seed=1)
+    for frames, codec in ((bgr, "RAW"), (gray, "RAW"), (bgr, "MJPG"), (gray, "MJPG")):
+        p = str(tmp_path / f"{codec}_{frames.ndim}.avi")
+        write_avi(p, frames, fps=25.0, codec=codec)
+        cap = AviReader(p)
+        assert cap.isOpened()
+        assert (cap.get(CAP_PROP_FRAME_WIDTH), cap.get(CAP_PROP_FRAME_HEIGHT)) == (spec.width, spec.height)
+        assert cap.get(CAP_PROP_FPS) == 25.0 and cap.get(CAP_PROP_FRAME_COUNT) == len(frames)
+        got = []
+        while True:
+            ok, f = cap.read()
+            if not ok:
+                break
+            assert f.dtype == np.uint8 and f.shape == (spec.height, spec.width, 3)
+            got.append(f)
+        assert len(got) == len(frames) and cap.read() == (False, None)
+        want3 = frames if frames.ndim == 4 else np.repeat(frames[..., None], 3, axis=3)
+        if codec == "RAW":
+            assert np.array_equal(np.stack(got), want3)
+        else:
+            err = np.abs(np.stack(got).astype(int) - want3.astype(int))                   # JPEG quality 95, 4:2:0 chroma
+            assert err.mean() < 2.0 and err.max() <= 64
+            raw = open(p, "rb").read()
+            k = raw.index(b"00dc")
+            size = int.from_bytes(raw[k + 4:k + 8], "little")
+            ref = np.asarray(Image.open(io.BytesIO(raw[k + 8:k + 8 + size])).convert("RGB"))[:, :, ::-1]
+            assert np.array_equal(got[0], ref)
+        cap.release()
+        assert not cap.isOpened()
+    junk = tmp_path / "junk.avi"
+    junk.write_bytes(b"RIFF\x10\x00\x00\x00AVI junkjunk")
+    assert not AviReader(str(junk)).isOpened() and not AviReader(str(tmp_path / "missing.avi")).isOpened()
+
+
 def test_no_silent_cpu_fallback():
     """Without a GPU every compute entry point must raise — never answer from a CPU path."""
     import torch

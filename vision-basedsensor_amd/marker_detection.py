@@ -108,15 +108,18 @@ class MarkerTracker:
         else:
             try:
                 import cv2
-            except ImportError as e:
-                raise IOError(f"Could not open video: {path} (OpenCV is not installed; pass a .npy/.npz "
-                              f"frame array or call process_frames)") from e
-            self.cap = cv2.VideoCapture(path)
+                self.cap = cv2.VideoCapture(path)
+                props = (cv2.CAP_PROP_FPS, cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT)
+            except ImportError:
+                # no OpenCV: the package's own reader for the sensor's recordings (Motion-JPEG / uncompressed AVI)
+                from . import video_io
+                self.cap = video_io.AviReader(path)
+                props = (video_io.CAP_PROP_FPS, video_io.CAP_PROP_FRAME_WIDTH, video_io.CAP_PROP_FRAME_HEIGHT)
             if not self.cap.isOpened():
                 raise IOError(f"Could not open video: {path}")
-            self.fps = self.cap.get(cv2.CAP_PROP_FPS)
-            self.width = int(self.cap.get(cv2.CAP_PROP_FRAME_WIDTH))
-            self.height = int(self.cap.get(cv2.CAP_PROP_FRAME_HEIGHT))
+            self.fps = self.cap.get(props[0])
+            self.width = int(self.cap.get(props[1]))
+            self.height = int(self.cap.get(props[2]))
         left, right, top, bottom = _crop_box(self.width, self.height, self.config["crop_ratios"])
         self.crop_width, self.crop_height = right - left, bottom - top
 

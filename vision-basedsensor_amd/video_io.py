@@ -1,0 +1,176 @@
+"""Video front end without OpenCV (`MarkerTracker._init_video`, marker_detection.py:50-76).
+
+The sensor's camera is opened with FOURCC MJPG (`Vedio_Capture/collecting.py:100`) and its recordings are AVI files,
+which the reference hands to `cv2.VideoCapture`.  This module reads that container itself: a sequential walk of the
+RIFF 'movi' list, every 'NNdc' / 'NNdb' chunk one frame — Motion-JPEG frames are decoded with Pillow (libjpeg, the
+same decoder family cv2 uses), uncompressed DIB frames (24-bit BGR or 8-bit gray, bottom-up) are reshaped.  The
+reader mimics the four `cv2.VideoCapture` calls the reference makes (`isOpened`, `get`, `read`, `release`) and
+returns BGR frames like cv2 does.  Decoding happens on the host: it is outside the benchmarked path and bounds only
+the real-world end-to-end rate.  Other codecs (XVID, H.264 ...) need a real decoder: IOError, as `cv2` absent did.
+
+`write_avi` is the matching minimal writer (MJPG or uncompressed), used by the tests to make fixtures on the fly.
+"""
+from __future__ import annotations
+
+import io
+import struct
+
+import numpy as np
+
+CAP_PROP_FRAME_WIDTH, CAP_PROP_FRAME_HEIGHT, CAP_PROP_FPS, CAP_PROP_FRAME_COUNT = 3, 4, 5, 7   # cv2's ids
+
+
+def _chunks(buf: memoryview, start: int, end: int):
+    """(fourcc, data_start, size) of the chunks in buf[start:end] (sizes are padded to even)."""
+    pos = start
+    while pos + 8 <= end:
+        cc = bytes(buf[pos:pos + 4])
+        size = struct.unpack_from("<I", buf, pos + 4)[0]
+        yield cc, pos + 8, size
+        pos += 8 + size + (size & 1)
+
+
+class AviReader:
+    """Sequential reader of MJPG / uncompressed AVI files with the `cv2.VideoCapture` calls the reference uses."""
+
+    def __init__(self, path: str):
+        self._ok = False
+        self.width = self.height = 0
+        self.fps = 0.0
+        self._frames = []            # (offset, size) of every video chunk
+        self._next = 0
+        self._codec = b""
+        self._bits = 24
+        try:
+            with open(path, "rb") as f:
+                self._buf = memoryview(f.read())
+        except OSError:
+            return
+        b = self._buf
+        if len(b) < 12 or bytes(b[0:4]) != b"RIFF" or bytes(b[8:12]) != b"AVI ":
+            return
+        riff_end = min(len(b), 8 + struct.unpack_from("<I", b, 4)[0])
+        for cc, ds, size in _chunks(b, 12, riff_end):
+            if cc != b"LIST":
+                continue
+            kind = bytes(b[ds:ds + 4])
+            if kind == b"hdrl":
+                self._parse_hdrl(ds + 4, ds + size)
+            elif kind == b"movi":
+                self._scan_movi(ds + 4, min(ds + size, len(b)))
+        self._ok = bool(self._frames) and self.width > 0 and self.height > 0 and \
+            self._codec.upper() in (b"MJPG", b"\x00\x00\x00\x00", b"DIB ", b"RAW ")
+
+    def _parse_hdrl(self, start, end):
+        b = self._buf
+        for cc, ds, size in _chunks(b, start, end):
+            if cc == b"avih" and size >= 40:
+                usec = struct.unpack_from("<I", b, ds)[0]
+                self.fps = 1e6 / usec if usec else 0.0
+                self.width, self.height = struct.unpack_from("<II", b, ds + 32)
+            elif cc == b"LIST" and bytes(b[ds:ds + 4]) == b"strl":
+                is_video = False
+                for c2, d2, s2 in _chunks(b, ds + 4, ds + size):
+                    if c2 == b"strh" and s2 >= 28:
+                        is_video = bytes(b[d2:d2 + 4]) == b"vids"
+                        scale, rate = struct.unpack_from("<II", b, d2 + 20)
+                        if is_video and scale:
+                            self.fps = rate / scale
+                    elif c2 == b"strf" and is_video and s2 >= 40 and not self._codec:
+                        w, h = struct.unpack_from("<ii", b, d2 + 4)
+                        self._bits = struct.unpack_from("<H", b, d2 + 14)[0]
+                        self._codec = bytes(b[d2 + 16:d2 + 20])
+                        self.width, self.height = abs(w), abs(h)
+
+    def _scan_movi(self, start, end):
+        b = self._buf
+        for cc, ds, size in _chunks(b, start, end):
+            if cc == b"LIST" and bytes(b[ds:ds + 4]) == b"rec ":
+                self._scan_movi(ds + 4, ds + size)
+            elif cc[2:4] in (b"dc", b"db") and size > 0:
+                self._frames.append((ds, size))
+
+    # ---- the cv2.VideoCapture subset ----
+    def isOpened(self) -> bool:
+        return self._ok
+
+    def get(self, prop: int) -> float:
+        return {CAP_PROP_FRAME_WIDTH: float(self.width), CAP_PROP_FRAME_HEIGHT: float(self.height),
+                CAP_PROP_FPS: float(self.fps), CAP_PROP_FRAME_COUNT: float(len(self._frames))}.get(prop, 0.0)
+
+    def read(self):
+        if not self._ok or self._next >= len(self._frames):
+            return False, None
+        off, size = self._frames[self._next]
+        self._next += 1
+        data = self._buf[off:off + size]
+        if self._codec.upper() == b"MJPG":
+            from PIL import Image
+            im = Image.open(io.BytesIO(bytes(data)))
+            rgb = np.asarray(im.convert("RGB"))
+            return True, np.ascontiguousarray(rgb[:, :, ::-1])              # BGR like cv2
+        stride = (self.width * self._bits // 8 + 3) & ~3                    # DIB rows are dword aligned, bottom-up
+        rows = np.frombuffer(data, dtype=np.uint8, count=stride * self.height).reshape(self.height, stride)[::-1]
+        if self._bits == 24:
+            return True, np.ascontiguousarray(rows[:, :self.width * 3].reshape(self.height, self.width, 3))
+        if self._bits == 8:
+            g = rows[:, :self.width]
+            return True, np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
+        return False, None
+
+    def release(self):
+        self._buf = memoryview(b"")
+        self._frames = []
+        self._ok = False
+
+
+def write_avi(path: str, frames: np.ndarray, fps: float = 30.0, codec: str = "MJPG", quality: int = 95):
+    """frames uint8 [N,H,W,3] BGR or [N,H,W] gray -> AVI with one 'movi' list and an 'idx1' index."""
+    frames = np.asarray(frames)
+    if frames.dtype != np.uint8 or frames.ndim not in (3, 4):
+        raise ValueError("frames must be uint8 [N,H,W] or [N,H,W,3]")
+    n, h, w = frames.shape[:3]
+    gray = frames.ndim == 3
+    payloads = []
+    if codec.upper() == "MJPG":
+        from PIL import Image
+        for fr in frames:
+            im = Image.fromarray(fr if gray else np.ascontiguousarray(fr[:, :, ::-1]))
+            bio = io.BytesIO()
+            im.save(bio, format="JPEG", quality=quality, subsampling=0 if gray else 2)
+            payloads.append(bio.getvalue())
+        fourcc, bits = b"MJPG", 24
+    else:
+        bits = 8 if gray else 24
+        stride = (w * bits // 8 + 3) & ~3
+        for fr in frames:
+            rows = np.zeros((h, stride), dtype=np.uint8)
+            rows[:, :w * bits // 8] = fr.reshape(h, -1)
+            payloads.append(rows[::-1].tobytes())
+        fourcc = b"\x00\x00\x00\x00"
+    tag = b"00dc" if fourcc == b"MJPG" else b"00db"
+
+    def chunk(cc, data):
+        return cc + struct.pack("<I", len(data)) + data + (b"\x00" if len(data) & 1 else b"")
+
+    def lst(kind, data):
+        return b"LIST" + struct.pack("<I", len(data) + 4) + kind + data
+
+    maxsz = max(len(p) for p in payloads) if payloads else 0
+    avih = struct.pack("<14I", int(round(1e6 / fps)) if fps else 0, 0, 0, 0x10, n, 0, 1, maxsz, w, h, 0, 0, 0, 0)
+    rate, scale = int(round(fps * 1000)), 1000
+    strh = b"vids" + fourcc + struct.pack("<IHHIIIIIIII4h", 0, 0, 0, 0, scale, rate, 0, n, maxsz, 0xFFFFFFFF, 0,
+                                         0, 0, w, h)
+    strf = struct.pack("<IiiHH4sIiiII", 40, w, h, 1, bits, fourcc, maxsz, 0, 0, 256 if bits == 8 else 0, 0)
+    if bits == 8:
+        strf += b"".join(struct.pack("<4B", i, i, i, 0) for i in range(256))
+    hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    movi_body, index, off = b"", b"", 4
+    for p in payloads:
+        index += tag + struct.pack("<III", 0x10, off, len(p))
+        c = chunk(tag, p)
+        movi_body += c
+        off += len(c)
+    body = b"AVI " + hdrl + lst(b"movi", movi_body) + chunk(b"idx1", index)
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
