@@ -229,14 +229,19 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
                     reinterpret_cast<u32*>(bits)[(((int64_t)n * H + y) * WW + (xw >> 6)) * 2 + ((xw >> 5) & 1)] = full;
                     total += __popc(full);
                 }
-                if (U8OUT && y < H) {
-#pragma unroll 1
+                if (U8OUT && y < H) {                    // uint8 image for the staged API: 4 pixels per store where possible
+#pragma unroll
                     for (int q = 0; q < 4; ++q) {
-                        int x = xw + 8 * q + 4 * hh;
-                        u32 nib = (w32 >> (8 * q + 4 * hh)) & 15u;
+                        const int x = xw + 8 * q + 4 * hh;
+                        const u32 nib = (w32 >> (8 * q + 4 * hh)) & 15u;
+                        const u32 four = ((nib * 0x00204081u) & 0x01010101u) * 0xFFu;      // bit r -> byte r = 0 / 255
                         u8* dst = area_u8 + ((int64_t)n * H + y) * W + x;
-                        for (int r = 0; r < 4; ++r)
-                            if (x + r < W) dst[r] = ((nib >> r) & 1u) ? 255 : 0;
+                        if (((W & 3) == 0) && x + 3 < W && ((reinterpret_cast<uintptr_t>(area_u8) & 3) == 0)) {
+                            *reinterpret_cast<u32*>(dst) = four;
+                        } else {
+                            for (int r = 0; r < 4; ++r)
+                                if (x + r < W) dst[r] = (u8)(four >> (8 * r));
+                        }
                     }
                 }
             }
