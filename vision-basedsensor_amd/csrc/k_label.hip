@@ -541,6 +541,11 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         for (int y = ya; y < yb; y += G) {
             u64 w; PF_NEXT(bits, y, yb, w)
             const int yr = y + g;                       // this lane's row
+            if (!__any(w != 0ull)) {                    // empty step (a third of a marker frame's rows): no run starts,
+                if (act && yr < yb) wbase[(int64_t)yr * WW + j] = rowbase;     // nothing to link below either
+                last = zero_state();
+                continue;
+            }
             RowState cur = make_row_state(w, j, rowbase);
             if (act && yr < yb) wbase[(int64_t)yr * WW + j] = cur.base;
             u64 st = cur.st;
