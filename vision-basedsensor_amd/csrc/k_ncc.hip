@@ -9,7 +9,8 @@
 //     num = 255 G - tbar 255 c - mu (Rx Ry - n tbar),     G = sum_i g_i sum_j g_j b(y+i, x+j)
 //     var = 255^2 c - 2 mu 255 c + n mu^2 - (255 c - n mu)^2 / l^2
 //     mask = num / sqrt(var * T2) > 0.1   <=>   var > 0, num > 0, num^2 > 0.01 var T2
-// k_ncc: both passes in one kernel, the horizontal one from bit runs into LDS (no float64 image in HBM).
+// k_ncc_mfma (the hot path): both passes as Toeplitz products on the float16 matrix cores, a filter in front of the
+//             float64 decision.  k_ncc: the float64 MAP of the diagnostic APIs, horizontal pass from bit runs into LDS.
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
