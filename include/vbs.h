@@ -63,6 +63,14 @@ int vbs_create(int device, int height, int width, int max_markers, int max_batch
 int vbs_destroy(vbs_handle* h);
 const char* vbs_last_error(const vbs_handle* h);
 int vbs_version(void);
+/* Handle options.  VBS_OPT_GRAY_COEFFS: fixed-point coefficient set of cv2.cvtColor(BGR2GRAY) (marker_detection.py:114)
+ * - 15 (default): OpenCV 4.x, (3735 B + 19235 G + 9798 R + 2^14) >> 15;  14: OpenCV <= 3.4.1, (1868 B + 9617 G +
+ * 4899 R + 2^13) >> 14.  The two agree wherever B = G = R.  VBS_OPT_FORCE_SEQ_MATCH (test hook): 1 makes
+ * vbs_marker_center replay the reference's sequential contour <-> centre matching (:203-243) instead of the parallel
+ * form that is proven equal to it. */
+#define VBS_OPT_GRAY_COEFFS      1
+#define VBS_OPT_FORCE_SEQ_MATCH  2
+int vbs_set_option(vbs_handle* h, int option, int value);
 /* host-only helper: the 256-entry table that classifies a border pixel's 8-neighbourhood into the
  * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain
  * direction d is foreground; 0=E,1=NE,2=N,...,7=SE). */
@@ -84,6 +92,12 @@ int vbs_set_undistort(vbs_handle* h, const double* K9, const double* dist, int n
 /* The remap alone: frames [dev] uint8 (same addressing as below) -> out [dev] uint8 [n,h,w,channels] dense. */
 int vbs_undistort_frames(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
                          int64_t stride_row, uint8_t* out, void* stream);
+
+/* cv2.cvtColor(frame, COLOR_BGR2GRAY) (marker_detection.py:114) on its own: frames [dev] uint8 BGR (3 channels,
+ * addressing as above) -> gray [dev] uint8 [n,h,w] dense, with the handle's coefficient set (VBS_OPT_GRAY_COEFFS).
+ * (Stage entry for parity tests; the hot path converts inside the blur kernel's loader.) */
+int vbs_bgr2gray(vbs_handle* h, const uint8_t* frames, int n, int64_t stride_n, int64_t stride_row, uint8_t* gray,
+                 void* stream);
 
 /* MarkerTracker._find_markers (marker_detection.py:112-135): BGR2GRAY -> 2x GaussianBlur -> uint8
  * difference +15 (mod 256) -> inRange -> area_mask {0,255}; NCC with the Gaussian template

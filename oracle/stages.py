@@ -45,12 +45,19 @@ def crop_box(width: int, height: int, crop_ratios: Sequence[float]) -> Tuple[int
 # a3  BGR -> gray                                                  marker_detection.py:114 (cv2)
 # ------------------------------------------------------------------------------------------------
 
-def bgr2gray(frame: np.ndarray) -> np.ndarray:
-    """OpenCV 8-bit `COLOR_BGR2GRAY`: (1868 B + 9617 G + 4899 R + 2^13) >> 14  [OpenCV-knowledge]."""
+GRAY_COEFFS = {15: (3735, 19235, 9798), 14: (1868, 9617, 4899)}     # (B, G, R) weights, sum 2^bits
+
+
+def bgr2gray(frame: np.ndarray, bits: int = 15) -> np.ndarray:
+    """OpenCV 8-bit `COLOR_BGR2GRAY` in fixed point  [OpenCV-knowledge; the version is not pinned by the reference]:
+    bits=15 (default): OpenCV 4.x `RGB2Gray<uchar>`, (3735 B + 19235 G + 9798 R + 2^14) >> 15;
+    bits=14: OpenCV <= 3.4.1, (1868 B + 9617 G + 4899 R + 2^13) >> 14.
+    Both are the identity where B = G = R; on coloured pixels they differ by at most one grey level."""
     if frame.ndim == 2:
         return frame
+    cb, cg, cr = GRAY_COEFFS[bits]
     f = frame.astype(np.int64)
-    return ((f[..., 0] * 1868 + f[..., 1] * 9617 + f[..., 2] * 4899 + 8192) >> 14).astype(np.uint8)
+    return ((f[..., 0] * cb + f[..., 1] * cg + f[..., 2] * cr + (1 << (bits - 1))) >> bits).astype(np.uint8)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -201,9 +208,9 @@ def in_range(img: np.ndarray, lo: int, hi: int) -> np.ndarray:
     return np.where((img >= lo) & (img <= hi), 255, 0).astype(np.uint8)
 
 
-def find_markers(frame: np.ndarray, ncc: str = "fft") -> Tuple[np.ndarray, np.ndarray]:
+def find_markers(frame: np.ndarray, ncc: str = "fft", gray_bits: int = 15) -> Tuple[np.ndarray, np.ndarray]:
     """`_find_markers(frame)` -> (mask uint8 {0,1}, area_mask uint8 {0,255})."""
-    gray = bgr2gray(frame)
+    gray = bgr2gray(frame, gray_bits)
     p = branch_params(gray.shape[0])
     area_mask = in_range(dog_image(gray), p["thresh"], p["hi"])
     template = gkern(p["tl"], p["tsig"])

@@ -246,6 +246,15 @@ def main():
     print("golden vectors written to", HERE)
 
 
+def real_frame():
+    """The one real sensor frame the reference holds (`img/raw_markers.png`, README.md; 65 printed dots in the layout
+    `code/ForceDistribution/ForceDistribution.py:29-95`): decoded pixels only, stored BGR like cv2.imread would."""
+    from PIL import Image
+    rgb = np.array(Image.open("/root/reference/img/raw_markers.png").convert("RGB"))
+    np.savez_compressed(os.path.join(HERE, "raw_markers_bgr.npz"), bgr=np.ascontiguousarray(rgb[..., ::-1]))
+    print("raw_markers_bgr.npz", rgb.shape)
+
+
 def rot(rx, ry, rz):
     cx, sx, cy, sy, cz, sz = np.cos(rx), np.sin(rx), np.cos(ry), np.sin(ry), np.cos(rz), np.sin(rz)
     Rx = np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
@@ -264,4 +273,5 @@ def ndimage_blobs(rng, shape):
 
 
 if __name__ == "__main__":
+    real_frame()
     main()

@@ -288,9 +288,14 @@ def test_matching_sequential_replay_equals_parallel(monkeypatch):
     spec = S.config2()
     frame = S.make_frames(spec, [7], seed=8)[0]
     om, oa = O.find_markers(frame)
+    from vbs_amd.marker_detection import _engine
     par = MarkerTracker._marker_center(om, oa)
-    monkeypatch.setenv("VBS_FORCE_SEQ_MATCH", "1")
-    seq = MarkerTracker._marker_center(om, oa)
+    eng = _engine(om.shape[0], om.shape[1])
+    eng.set_option(L.OPT_FORCE_SEQ_MATCH, 1)
+    try:
+        seq = MarkerTracker._marker_center(om, oa)
+    finally:
+        eng.set_option(L.OPT_FORCE_SEQ_MATCH, 0)
     assert par == seq and len(par) == spec.n_markers
 
 
@@ -691,4 +696,107 @@ def test_engine_argument_errors():
     _, _, counts = eng.track_to_3d(torch.full((2, 480, 640), 190, dtype=torch.uint8, device="cuda"),
                                    np.array([[10.0, 10.0]]))
     assert counts.tolist() == [0, 0]
+    det = torch.zeros((2, eng.max_markers, 6), dtype=torch.float64, device="cuda")
+    cnt = torch.zeros((2,), dtype=torch.int32, device="cuda")
+    with pytest.raises(ValueError):                     # wrong row count per frame
+        eng.track(det[:, :7].contiguous(), cnt, np.array([[10.0, 10.0]]))
+    with pytest.raises(ValueError):                     # counts of the wrong length / dtype
+        eng.track(det, cnt[:1], np.array([[10.0, 10.0]]))
+    with pytest.raises(ValueError):
+        eng.track(det, cnt.long(), np.array([[10.0, 10.0]]))
+    big = torch.full((2,), 5000, dtype=torch.int32, device="cuda")      # a count beyond the table is clamped, not trusted
+    t = eng.track(det, big, np.array([[10.0, 10.0]]))
+    torch.cuda.synchronize()
+    assert t.shape == (2, 1, 10)
+    with pytest.raises(ValueError):
+        eng.set_option(L.OPT_GRAY_COEFFS, 13)
+    eng.close()
+
+
+def test_real_sensor_frame(golden_dir, tmp_path):
+    """The reference's one real frame (img/raw_markers.png -> tests/golden/raw_markers_bgr.npz, 467x437 BGR, 65 printed
+    dots): HIP vs oracle under both BGR2GRAY coefficient sets - masks exact, 65 detections, centroids exact, axes
+    within 1e-3 px; identities in both modes through `MarkerTracker` (physical layout 1+6+12+18+24+4)."""
+    from collections import Counter
+    from vbs_amd.marker_detection import MarkerTracker
+    bgr = np.load(os.path.join(golden_dir, "raw_markers_bgr.npz"))["bgr"]
+    h, w = bgr.shape[:2]
+    ft = torch.from_numpy(bgr[None]).cuda()
+    for bits in (15, 14):
+        eng = engine(h, w, max_markers=1024, max_batch=1)
+        eng.set_option(L.OPT_GRAY_COEFFS, bits)
+        assert np.array_equal(eng.bgr2gray(ft)[0].cpu().numpy(), O.bgr2gray(bgr, bits))
+        om, oa = O.find_markers(bgr, gray_bits=bits)
+        mask, area = eng.find_markers(ft)
+        assert np.array_equal(mask[0].cpu().numpy(), om) and np.array_equal(area[0].cpu().numpy(), oa)
+        want = O.marker_center(om, oa)
+        det, counts = eng.marker_center(mask, area)
+        assert int(counts[0]) == 65 == len(want)
+        _, det2, counts2 = eng.track_to_3d(ft, None, want_det=True)           # the fused path sees the same frame
+        assert int(counts2[0]) == 65 and torch.equal(det2[0, :65], det[0, :65])
+        from vbs_amd.marker_detection import _det_to_markers
+        compare_markers(_det_to_markers(det[0].cpu().numpy(), 65), want)
+        assert eng.frame_stats(1)[0, 5] == 65 and eng.frame_stats(1)[0, 6] == 65
+        eng.close()
+    clip = np.stack([bgr, bgr])
+    np.save(tmp_path / "real.npy", clip)
+    for id_mode, n_ids in (("as_written", 6), ("full", 65)):
+        cfg = {"video_path": str(tmp_path / "real.npy"), "output_dir": str(tmp_path / id_mode), "crop_ratios": (0, 0, 0, 0),
+               "num_layers": 5, "min_marker_distance": 20, "id_mode": id_mode}
+        trk = MarkerTracker(cfg)
+        trk.process()
+        rows, ref = O.process_frames(list(clip), crop_ratios=(0, 0, 0, 0), id_mode=id_mode)
+        assert list(trk.first_frame_markers.keys()) == list(ref.keys()) and len(ref) == n_ids
+        import pandas as pd
+        df = pd.read_csv(trk.output_csv, float_precision="round_trip")
+        assert len(df) == len(rows) == 2 * n_ids
+        wantdf = pd.DataFrame(rows)
+        for c in ("frameno", "row", "col", "Cx", "Cy", "Ox", "Oy"):
+            assert (df[c].to_numpy() == wantdf[c].to_numpy()).all(), c
+        if id_mode == "full":
+            assert Counter(df[df.frameno == 0].row.tolist()) == {0: 1, 1: 6, 2: 12, 3: 18, 4: 24, 5: 4}
+
+
+def test_bgr2gray_both_coefficient_sets():
+    """a3 on coloured pixels, where the 15-bit (OpenCV 4) and 14-bit sets differ; also through `find_markers`."""
+    rng = np.random.default_rng(9)
+    f = rng.integers(0, 256, (2, 480, 640, 3), dtype=np.uint8)
+    ft = torch.from_numpy(f).cuda()
+    eng = engine(480, 640, max_batch=2)
+    g = {}
+    for bits in (15, 14):
+        eng.set_option(L.OPT_GRAY_COEFFS, bits)
+        g[bits] = eng.bgr2gray(ft).cpu().numpy()
+        assert np.array_equal(g[bits], np.stack([O.bgr2gray(x, bits) for x in f]))
+        # a crop view (odd offsets) through the strided addressing
+        assert np.array_equal(eng.bgr2gray(torch.from_numpy(np.pad(f, ((0, 0), (3, 5), (7, 9), (0, 0)))).cuda()
+                                           [:, 3:483, 7:647]).cpu().numpy(), g[bits])
+    assert (g[15] != g[14]).any()
+    eng.close()
+
+
+def test_capacity_frame_inside_a_batch_is_reported(tmp_path):
+    """A frame that exceeds the workspace (more runs than the labelling tables hold) in the MIDDLE of a batch must not
+    vanish from the output: `counts` carries the status and the drop-in raises, naming the frame."""
+    from vbs_amd.marker_detection import MarkerTracker
+    from vbs_amd.pipeline import track_shard
+    spec = S.config2()
+    frames = S.make_frames(spec, range(4), seed=2)
+    yy, xx = np.indices(frames.shape[1:])
+    # 4-px checker of 190 / 40 blocks: thousands of small blobs, far beyond max_markers components
+    frames[2] = np.where(((yy // 6) + (xx // 6)) % 2 == 0, 190, 40).astype(np.uint8)
+    eng = engine(spec.height, spec.width, max_markers=256, max_batch=4)
+    ft = torch.from_numpy(frames).cuda()
+    _, _, counts = eng.track_to_3d(ft, np.array([[100.0, 100.0]]))
+    c = counts.cpu().numpy()
+    if c[2] >= 0:
+        pytest.skip("the crafted frame did not exceed the capacity")
+    assert c[2] == L.VBS_ECAPACITY and (c[[0, 1, 3]] == spec.n_markers).all()
+    with pytest.raises(L.VbsError, match="frame 2"):
+        track_shard(eng, ft, 4, cam=None)
+    np.save(tmp_path / "clip.npy", frames)
+    trk = MarkerTracker({"video_path": str(tmp_path / "clip.npy"), "output_dir": str(tmp_path / "o"),
+                         "crop_ratios": (0, 0, 0, 0), "id_mode": "full"})
+    with pytest.raises(L.VbsError, match="frame 2"):
+        trk.process()
     eng.close()

@@ -194,6 +194,116 @@ def test_marker_analysis_files(tmp_path):
         ma.load_marker_data(tmp_path / "bad.csv")
 
 
+def _openpyxl_style_workbook(path, header, rows):
+    """An .xlsx laid out the way pandas/openpyxl writes one (shared strings, t="s" cells, a styles part, a docProps
+    part): built by hand so the reader is tested on that layout without an Excel engine."""
+    import zipfile
+    from xml.sax.saxutils import escape
+    strings, sidx = [], {}
+
+    def sref(v):
+        if v not in sidx:
+            sidx[v] = len(strings)
+            strings.append(v)
+        return sidx[v]
+
+    def col(i):
+        return chr(65 + i)
+
+    xml_rows = []
+    for r, row in enumerate([header] + rows, start=1):
+        cells = []
+        for c, v in enumerate(row):
+            if v is None or v == "":
+                continue
+            if isinstance(v, str):
+                cells.append(f'<c r="{col(c)}{r}" s="1" t="s"><v>{sref(v)}</v></c>')
+            else:
+                cells.append(f'<c r="{col(c)}{r}"><v>{v!r}</v></c>')
+        xml_rows.append(f'<row r="{r}" spans="1:3">{"".join(cells)}</row>')
+    ns = "http://schemas.openxmlformats.org/spreadsheetml/2006/main"
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("[Content_Types].xml", '<?xml version="1.0"?><Types xmlns="http://schemas.openxmlformats.org/package/2006/content-types"/>')
+        z.writestr("docProps/app.xml", "<Properties/>")
+        z.writestr("xl/workbook.xml", f'<?xml version="1.0"?><workbook xmlns="{ns}" xmlns:r="http://schemas.openxmlformats.org/'
+                   'officeDocument/2006/relationships"><sheets><sheet name="Sheet1" sheetId="1" r:id="rId7"/></sheets></workbook>')
+        z.writestr("xl/_rels/workbook.xml.rels", '<?xml version="1.0"?><Relationships xmlns="http://schemas.openxmlformats.org/package/'
+                   '2006/relationships"><Relationship Id="rId3" Type="x/styles" Target="styles.xml"/>'
+                   '<Relationship Id="rId7" Type="x/worksheet" Target="/xl/worksheets/sheet1.xml"/></Relationships>')
+        z.writestr("xl/styles.xml", f'<styleSheet xmlns="{ns}"/>')
+        z.writestr("xl/sharedStrings.xml", f'<?xml version="1.0"?><sst xmlns="{ns}" count="{len(strings)}">' + "".join(
+            f"<si><t>{escape(t)}</t></si>" if i % 2 == 0 else f"<si><r><t>{escape(t[:1])}</t></r><r><t>{escape(t[1:])}</t></r></si>"
+            for i, t in enumerate(strings)) + "</sst>")
+        z.writestr("xl/worksheets/sheet1.xml", f'<?xml version="1.0"?><worksheet xmlns="{ns}"><sheetData>' + "".join(xml_rows) +
+                   "</sheetData></worksheet>")
+
+
+def test_xlsx_parameter_sheets_and_result_sheet(tmp_path):
+    """f2: the two parameter workbooks as the reference's calibration scripts lay them out (`intrinsic_calibration.py:33-51`
+    key column `Param`; `extrinsic_calibration.py:135-151` five title rows, keys `T_wc_X/Y/Z`) and as `load_parameters`
+    itself expects them (`Parameter`, `Tx_wc` ... `3d_reconstruction.py:84,121`), read without an Excel engine; the
+    result sheet (`:296-307,430-433`) written and read back bit-exactly."""
+    import pandas as pd
+    from vbs_amd import xlsx_io as X
+    from vbs_amd.reconstruction3d import MarkerAnalysis, Config
+    cfg = Config(data_dir=tmp_path / "d", output_dir=tmp_path / "d" / "r", plots_dir=tmp_path / "d" / "r" / "p")
+    ma = MarkerAnalysis(cfg)
+    c, s_ = np.cos(0.3), np.sin(0.3)
+    R = np.array([[c, -s_, 0.0], [s_, c, 0.0], [0.0, 0.0, 1.0]])
+    intr_rows = [["fx", 1400.123456789, "Focal length x"], ["fy", 1399.5, "Focal length y"], ["cx", 640.25, ""],
+                 ["cy", 512.75, ""], ["skew", 0.0, ""], ["k1", -0.1234567, ""], ["k2", 0.0123, ""], ["p1", 1e-4, ""],
+                 ["p2", -2e-4, ""], ["k3", 0.0, ""], ["Reproj Error", 0.21, "Mean error (px)"]]
+    ext_rows = [["--- Camera Extrinsic Parameters ---", "", ""], ["Calibration Date", "2025-01-01 10:00:00", ""],
+                ["Reprojection Error (px)", 0.4, ""], ["", "", ""], ["--- World to Camera Transformation ---", "", ""]]
+    ext_rows += [[f"R_wc_{i + 1}{j + 1}", float(R[i, j]), f"Rotation matrix element ({i + 1},{j + 1})"]
+                 for i in range(3) for j in range(3)]
+    # (a) as the calibration scripts write them, through the package's writer
+    X.write_xlsx(tmp_path / "IntrinsicParameters.xlsx", ["Param", "Value", "Desc"], intr_rows)
+    X.write_xlsx(tmp_path / "ExtrinsicParameters.xlsx", ["Parameter", "Value", "Description"],
+                 ext_rows + [[f"T_wc_{a}", v, ""] for a, v in zip("XYZ", (1.5, -2.25, 30.125))])
+    ma.load_parameters(tmp_path / "IntrinsicParameters.xlsx", tmp_path / "ExtrinsicParameters.xlsx")
+    K = ma.camera.matrix.copy()
+    assert K.dtype == np.float32 and K[0, 0] == np.float32(1400.123456789) and K[1, 2] == np.float32(512.75)
+    assert np.array_equal(ma.camera.dist_coeffs, np.array([-0.1234567, 0.0123, 1e-4, -2e-4, 0.0], np.float32))
+    assert np.array_equal(ma.camera.R_world_to_cam, R.astype(np.float32))
+    assert ma.camera.T_world_to_cam.ravel().tolist() == [1.5, -2.25, 30.125]
+    # (b) the spellings `load_parameters` itself names, in an openpyxl-style workbook (shared strings, rich text)
+    _openpyxl_style_workbook(tmp_path / "i2.xlsx", ["Parameter", "Value", "Desc"], intr_rows)
+    _openpyxl_style_workbook(tmp_path / "e2.xlsx", ["Parameter", "Value", "Description"],
+                             ext_rows + [[f"T{a}_wc", v, ""] for a, v in zip("xyz", (1.5, -2.25, 30.125))])
+    df = X.read_xlsx(tmp_path / "e2.xlsx")
+    assert list(df.columns) == ["Parameter", "Value", "Description"] and len(df) == len(ext_rows) + 3
+    assert df["Parameter"][0] == "--- Camera Extrinsic Parameters ---" and df["Parameter"][5] == "R_wc_11"
+    assert df["Value"][3] is None or pd.isna(df["Value"][3])          # the blank row survives as a row
+    mb = MarkerAnalysis(cfg)
+    mb.load_parameters(tmp_path / "i2.xlsx", tmp_path / "e2.xlsx")
+    assert np.array_equal(mb.camera.matrix, K) and np.array_equal(mb.camera.T_world_to_cam, ma.camera.T_world_to_cam)
+    assert np.array_equal(mb.camera.R_world_to_cam, ma.camera.R_world_to_cam)
+    # errors keep the reference's types
+    X.write_xlsx(tmp_path / "nokey.xlsx", ["A", "B"], [["fx", 1.0]])
+    with pytest.raises(ValueError):
+        ma.load_parameters(tmp_path / "nokey.xlsx", tmp_path / "e2.xlsx")
+    with pytest.raises(FileNotFoundError):
+        ma.load_parameters(tmp_path / "absent.xlsx", tmp_path / "e2.xlsx")
+    (tmp_path / "junk.xlsx").write_bytes(b"not a zip")
+    with pytest.raises(ValueError):
+        X.read_xlsx(tmp_path / "junk.xlsx")
+    # (c) result sheet: float64 values round-trip exactly, integer columns stay integers
+    rng = np.random.default_rng(3)
+    res = pd.DataFrame({"frameno": np.arange(101, 107), "row": [0, 1, 1, 2, 2, 2], "col": [0, 0, 1, 0, 1, 2]})
+    for ccol in ("X", "Y", "Z", "dX", "dY", "dZ", "displacement"):
+        res[ccol] = rng.normal(size=6) * 10.0 ** rng.integers(-8, 3, size=6)
+    X.dataframe_to_xlsx(res, tmp_path / "marker_3d_coordinates.xlsx")
+    back = X.read_xlsx(tmp_path / "marker_3d_coordinates.xlsx")
+    assert list(back.columns) == ["frameno", "row", "col", "X", "Y", "Z", "dX", "dY", "dZ", "displacement"]
+    assert back["frameno"].tolist() == res["frameno"].tolist() and all(isinstance(v, int) for v in back["row"])
+    for ccol in ("X", "Y", "Z", "dX", "dY", "dZ", "displacement"):
+        assert np.array_equal(back[ccol].to_numpy(dtype=np.float64), res[ccol].to_numpy())
+    # special characters and leading blanks in strings
+    X.write_xlsx(tmp_path / "s.xlsx", ["k"], [["a<b & c"], ["  padded "], [None], [True]])
+    assert X.read_rows(tmp_path / "s.xlsx") == [["k"], ["a<b & c"], ["  padded "], [None], [True]]
+
+
 def test_shard_bounds():
     from vbs_amd.dist import shard_bounds
     for n, w in ((32768, 8), (10, 4), (7, 8), (0, 2)):

@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvbs.so")
-SOURCES = ("api.hip", "k_blur.hip", "k_ncc.hip", "k_label.hip", "k_solve.hip", "k_undistort.hip", "k_ids.hip")
+SOURCES = ("api.hip", "k_blur.hip", "k_ncc.hip", "k_label.hip", "k_ccl.hip", "k_solve.hip", "k_undistort.hip", "k_ids.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 

@@ -161,6 +161,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(area_first, B * max_markers); ALLOC(area_sums, B * max_markers * VBS_AREA_SUMS);
     ALLOC(ell, B * max_markers * 8); ALLOC(det64, B * max_markers * 6);
     ALLOC(cnt, B);
+    ALLOC(probe, B * max_markers * 4); ALLOC(slow_list, B + 1); ALLOC(slow_flag, B);
     ALLOC(lut, 256);
     ALLOC(blur_frags, frags.size() / 4);
     std::vector<u32> nfrags = ncc_mfma_fragments(h->ncc, bp.ncc_l);
@@ -236,6 +237,15 @@ extern "C" int vbs_find_markers(vbs_handle* h, const uint8_t* frames, int n, int
     return VBS_OK;
 }
 
+extern "C" int vbs_bgr2gray(vbs_handle* h, const uint8_t* frames, int n, int64_t stride_n, int64_t stride_row,
+                            uint8_t* gray, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!frames || !gray || n < 0 || stride_row < (int64_t)h->W * 3) { h->err = "vbs_bgr2gray: bad argument"; return VBS_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->device));
+    if (n) launch_gray_dense(h, frames, n, stride_n, stride_row, gray, (hipStream_t)stream);
+    return check_launch(h);
+}
+
 extern "C" int vbs_ncc_map(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
                            int64_t stride_row, double* ncc, void* stream) {
     if (!h) return VBS_EINVAL;
@@ -272,6 +282,20 @@ extern "C" int vbs_normxcorr2(vbs_handle* h, const uint8_t* area_mask, int n, do
         if (rc != VBS_OK) return rc;
     }
     return VBS_OK;
+}
+
+extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
+    if (!h) return VBS_EINVAL;
+    switch (option) {
+        case VBS_OPT_FORCE_SEQ_MATCH: h->force_seq_match = value != 0; return VBS_OK;
+        case VBS_OPT_GRAY_COEFFS:
+            if (value != 14 && value != 15) break;
+            h->gray_bits = value;
+            return VBS_OK;
+        default: break;
+    }
+    h->err = "vbs_set_option: unknown option or bad value";
+    return VBS_EINVAL;
 }
 
 extern "C" int vbs_profile(vbs_handle* h, int enable) {

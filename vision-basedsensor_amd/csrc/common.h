@@ -32,6 +32,19 @@ struct NccConst {
     double inv_l2;
 };
 
+// cv2.cvtColor(BGR2GRAY) on uint8 (marker_detection.py:114): (cb B + cg G + cr R + 2^(shift-1)) >> shift
+struct GrayCoef { u32 cb, cg, cr, half, shift; };
+static inline GrayCoef gray_coef(int bits) {
+    return bits == 14 ? GrayCoef{1868u, 9617u, 4899u, 1u << 13, 14u} : GrayCoef{3735u, 19235u, 9798u, 1u << 14, 15u};
+}
+
+#ifdef VBS_DEBUG_KNOBS                                  // tools/ builds only: phase timing by early exit
+#include <cstdlib>
+#define VBS_KNOB(name) (getenv(name) ? atoi(getenv(name)) : 0)
+#else
+#define VBS_KNOB(name) 0
+#endif
+
 struct ProfRec { const char* name; hipEvent_t a, b; };
 
 struct vbs_handle {
@@ -63,6 +76,11 @@ struct vbs_handle {
     double* ell;       // [maxb][maxm][8]   cx, cy, w, h, angle, nvert, ok, spare
     double* det64;     // [maxb][maxm][6]
     int32_t* cnt;      // [maxb]
+    unsigned short* probe;   // [maxb][maxm][4]  component ids of the 2x2 cell around every band centroid
+    u32* slow_flag;    // [maxb]  1 = the fast labelling path handed the frame on
+    u32* slow_list;    // [1 + maxb]  frames handed from the fast labelling path to the general kernels
+    int gray_bits = 15;             // BGR2GRAY fixed-point coefficient set: 15 (OpenCV 4) | 14 (OpenCV <= 3.4.1)
+    bool force_seq_match = false;   // vbs_set_option(VBS_OPT_FORCE_SEQ_MATCH)
     u8* lut;           // [256] contour vertex table
     short* umap1;      // [H][W][2] int16 undistortion source pixel (CV_16SC2)
     unsigned short* umap2;   // [H][W] fractional index into the bilinear weight table
@@ -95,6 +113,8 @@ struct vbs_handle {
 // ---- launchers (each enqueues on `s`; nb = frames in this pass) --------------------------------
 void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
                  int64_t stride_row, hipStream_t s);
+void launch_gray_dense(vbs_handle* h, const u8* frames, int nb, int64_t stride_n, int64_t stride_row, u8* out,
+                       hipStream_t s);
 void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,
                  u8* area_u8, hipStream_t s);
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s);

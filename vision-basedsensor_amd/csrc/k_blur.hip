@@ -17,7 +17,7 @@ __device__ __forceinline__ int reflect101(int i, int n) {
 }
 
 __global__ void k_gray(const u8* __restrict__ frames, int channels, int64_t stride_n,
-                       int64_t stride_row, u8* __restrict__ gray, int H, int W, int P) {
+                       int64_t stride_row, u8* __restrict__ gray, int H, int W, int P, GrayCoef gc) {
     int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
     int y = blockIdx.y, n = blockIdx.z;
     if (x4 >= P) return;
@@ -29,14 +29,30 @@ __global__ void k_gray(const u8* __restrict__ frames, int channels, int64_t stri
         if (x < W) {
             if (channels == 1) {
                 v = src[x];
-            } else {   // cv2 8-bit BGR2GRAY: (1868 B + 9617 G + 4899 R + 2^13) >> 14
+            } else {   // cv2 8-bit BGR2GRAY, fixed point (coefficient set: common.h gray_coef)
                 const u8* p = src + (int64_t)x * channels;
-                v = (1868u * p[0] + 9617u * p[1] + 4899u * p[2] + 8192u) >> 14;
+                v = (gc.cb * p[0] + gc.cg * p[1] + gc.cr * p[2] + gc.half) >> gc.shift;
             }
         }
         out |= v << (8 * k);
     }
     *reinterpret_cast<u32*>(gray + ((int64_t)n * H + y) * P + x4) = out;
+}
+
+// the cvtColor stage on its own (vbs_bgr2gray): dense [n,H,W] output, one pixel per thread
+__global__ void k_gray_dense(const u8* __restrict__ frames, int64_t stride_n, int64_t stride_row,
+                             u8* __restrict__ out, int H, int W, GrayCoef gc) {
+    const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y, n = blockIdx.z;
+    if (x >= W) return;
+    const u8* p = frames + (int64_t)n * stride_n + (int64_t)y * stride_row + (int64_t)x * 3;
+    out[((int64_t)n * H + y) * W + x] = (u8)((gc.cb * p[0] + gc.cg * p[1] + gc.cr * p[2] + gc.half) >> gc.shift);
+}
+
+void launch_gray_dense(vbs_handle* h, const u8* frames, int nb, int64_t stride_n, int64_t stride_row, u8* out,
+                       hipStream_t s) {
+    dim3 grid((h->W + 255) / 256, h->H, nb);
+    VBS_LAUNCH(h, s, "k_gray_dense", k_gray_dense, grid, dim3(256), 0, s, frames, stride_n, stride_row, out, h->H, h->W,
+               gray_coef(h->gray_bits));
 }
 
 // ---- MFMA path -------------------------------------------------------------------------------------
@@ -287,7 +303,7 @@ void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t 
                  int64_t stride_row, hipStream_t s) {
     dim3 grid((h->P / 4 + 255) / 256, h->H, nb);
     VBS_LAUNCH(h, s, "k_gray", k_gray, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row, h->gray,
-                       h->H, h->W, h->P);
+                       h->H, h->W, h->P, gray_coef(h->gray_bits));
 }
 
 void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,

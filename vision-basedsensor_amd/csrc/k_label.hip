@@ -474,6 +474,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                                                 u32* __restrict__ band_first, u64* __restrict__ band_sums,
                                                 u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                 u32* __restrict__ fstat, const u8* __restrict__ lut_g,
+                                                const u32* __restrict__ slow_list,
                                                 int H, int W, int WW, int maxm, int stop, int mode) {
     __shared__ u32 parent[VBS_RUN_CAP];                // union-find parents; later [m=1] the moment accumulators
     __shared__ u64 bnd_w[16][64];                      // last row of every strip: words,
@@ -484,19 +485,23 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     __shared__ u32 tmp[32];
     __shared__ u8 lut[256];
     __shared__ int euler4;                             // 4 x Euler number of the opened mask (bit quads)
-    const int n = blockIdx.x;
+    // frames the fast path (k_ccl.hip) handed on: slow_list = {count, frame indices ...}; every exit of the body below
+    // is workgroup-uniform, so it is a `continue` of this loop
+    for (u32 li = blockIdx.x; li < slow_list[0]; li += gridDim.x) {
+    __syncthreads();                                    // the previous frame's readers of the tables are done
+    const int n = (int)slow_list[1 + li];
     const int m = mode == 0 ? (int)blockIdx.y : (mode == 1 ? 2 : 1);   // 0 band (4-conn), 1 open (8-conn), 2 background of open
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int NW = H * WW;
-    if (mode == 1 && fstat[n * 8 + 4] == 0) return;    // no holes in this frame
-    if (mode == 2 && fstat[n * 8 + 7] == 0) return;    // nothing was filled
+    if (mode == 1 && fstat[n * 8 + 4] == 0) continue;    // no holes in this frame
+    if (mode == 2 && fstat[n * 8 + 7] == 0) continue;    // nothing was filled
     const bool inv = (m == 2);                          // walk the complement of the opened mask
     const int mslot = (m == 2) ? 0 : m;                 // the background pass borrows the band pass's scratch tables
     const u64* bits = (m == 0 ? band_bits : open_bits) + (int64_t)n * NW;
     u32* wbase = wbase_all + ((int64_t)n * 2 + mslot) * NW;
     u32* node_pos = node_pos_all + ((int64_t)n * 2 + mslot) * VBS_RUN_CAP;
     u32* node_comp = node_comp_all + ((int64_t)n * 2 + mslot) * VBS_RUN_CAP;
-    if (stop == 9) return;
+    if (stop == 9) continue;
     if (tid < 256) lut[tid] = lut_g[tid];
     if (tid == 0) euler4 = 0;
     for (int i = tid; i < 1024; i += nthr) { acc_cnt[i] = 0; acc_sx[i] = 0; acc_sy[i] = 0; }
@@ -529,7 +534,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     if (lane == 0) wfirst[wave] = mybase;
     if (nruns > VBS_RUN_CAP) {                          // block-uniform
         if (tid == 0) { if (m != 2) ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
-        return;
+        continue;
     }
 
     // ---- 2: label the strip, G rows per step ------------------------------------------------------------
@@ -583,7 +588,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         link_rows(parent, cur, prev, j, WW, m == 1 ? 1 : 0);
     }
     __syncthreads();
-    if ((stop & 15) == 2) return;
+    if ((stop & 15) == 2) continue;
 
     // ---- D: flatten -------------------------------------------------------------------------------
     for (u32 i = tid; i < nruns; i += nthr) {
@@ -601,7 +606,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     u32 cbase = block_exclusive_scan(nroot, tmp, &ncomp);
     if ((m != 2 && ncomp > (u32)maxm) || ncomp > 1024u || (m == 1 && ncomp * NMOM * 8u > sizeof(parent) / 2)) {
         if (tid == 0) { if (m != 2) ncomp_all[n * 2 + m] = 0; atomicMin((int*)&fstat[n * 8 + 2], VBS_ECAPACITY); }
-        return;
+        continue;
     }
     u32* first = (m == 0 ? band_first : area_first) + (int64_t)n * maxm;
     for (u32 i = r0; i < r1; ++i) {
@@ -640,7 +645,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     u64* acc = reinterpret_cast<u64*>(parent) + VBS_RUN_CAP / 4;           // upper half: [ncomp][15] moments (m = 1)
     if (m == 1) for (u32 c = tid; c < ncomp * NMOM; c += nthr) acc[c] = 0;
     __syncthreads();
-    if ((stop & 15) == 4) return;
+    if ((stop & 15) == 4) continue;
 
     // ---- F: per-component sums, same walk; sums stay in registers and are flushed with LDS atomics when the
     //         component under the lane changes (a lane sees rows y0 + g, y0 + g + G, ... of one word column) --------
@@ -677,7 +682,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         u32 nholes = 0;
         for (u32 c = tid; c < ncomp; c += nthr) nholes += (acc_cnt[c] == 0);
         if (nholes) atomicAdd(&fstat[n * 8 + 7], nholes);
-        return;
+        continue;
     }
     // One work item per RUN (node): its position comes back from node_pos, its extent from the bits; every lane has
     // work (a word walk leaves most lanes idle on a marker frame) and the sums go to the component's LDS accumulators.
@@ -812,15 +817,62 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         for (u32 c = tid; c < ncomp * NMOM; c += nthr) as[(c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
         if (tid == 0) fstat[n * 8 + 4] = (u32)((int)ncomp - euler4 / 4);       // holes in the opened mask
     }
+    }                                                   // frames of the slow list
 }
 
+// component id of pixel (x, y) of the opened mask from the general path's tables, 0xFFFF when it is not foreground
+__device__ __forceinline__ u32 comp_at(const u64* __restrict__ bits, const u32* __restrict__ wbase,
+                                       const u32* __restrict__ node_comp, int H, int W, int WW, int x, int y) {
+    if (x < 0 || y < 0 || x >= W || y >= H) return 0xFFFFu;
+    const u64* row = bits + (int64_t)y * WW;
+    if (!((row[x >> 6] >> (x & 63)) & 1ull)) return 0xFFFFu;
+    return node_comp[node_of(row, wbase + (int64_t)y * WW, x >> 6, x & 63)];
+}
+
+// probes (component ids of the 2x2 pixel cell around every band centroid) for the frames of the slow list; the fast
+// path writes them itself
+__global__ __launch_bounds__(256) void k_probe_slow(const u32* __restrict__ slow_list, const u32* __restrict__ ncomp_all,
+                                                    const u64* __restrict__ band_sums, const u64* __restrict__ open_bits,
+                                                    const u32* __restrict__ wbase_all, const u32* __restrict__ node_comp_all,
+                                                    const u32* __restrict__ fstat, unsigned short* __restrict__ probe_all,
+                                                    int H, int W, int WW, int maxm) {
+    for (u32 li = blockIdx.x; li < slow_list[0]; li += gridDim.x) {
+        const int n = (int)slow_list[1 + li];
+        if ((int)fstat[n * 8 + 2] != 0) continue;
+        const int NW = H * WW;
+        const u64* bits = open_bits + (int64_t)n * NW;
+        const u32* wbase = wbase_all + ((int64_t)n * 2 + 1) * NW;
+        const u32* node_comp = node_comp_all + ((int64_t)n * 2 + 1) * VBS_RUN_CAP;
+        const u64* bs = band_sums + (int64_t)n * maxm * 4;
+        unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
+        const u32 nband = ncomp_all[n * 2 + 0];
+        for (u32 i = threadIdx.x; i < nband; i += blockDim.x) {
+            const double cn = (double)bs[i * 4 + 0];
+            const float xf = (float)((double)bs[i * 4 + 1] / cn), yf = (float)((double)bs[i * 4 + 2] / cn);
+            const int ix = (int)floorf(xf), iy = (int)floorf(yf);
+            pr[i * 4 + 0] = (unsigned short)comp_at(bits, wbase, node_comp, H, W, WW, ix, iy);
+            pr[i * 4 + 1] = (unsigned short)comp_at(bits, wbase, node_comp, H, W, WW, ix + 1, iy);
+            pr[i * 4 + 2] = (unsigned short)comp_at(bits, wbase, node_comp, H, W, WW, ix, iy + 1);
+            pr[i * 4 + 3] = (unsigned short)comp_at(bits, wbase, node_comp, H, W, WW, ix + 1, iy + 1);
+        }
+    }
+}
+
+void launch_ccl(vbs_handle* h, int nb, hipStream_t s);
+
+// a9-a13 labelling: the parallel fast path (k_ccl.hip), then the general kernels over the frames it handed on
+// (none on marker frames: their workgroups find an empty list and exit)
 void launch_label(vbs_handle* h, int nb, hipStream_t s) {
-    const int stop = getenv("VBS_LABEL_STOP") ? atoi(getenv("VBS_LABEL_STOP")) : 0;     // debug: phase timing
+    const int stop = VBS_KNOB("VBS_LABEL_STOP");
+    launch_ccl(h, nb, s);
+    const int gs = nb < 64 ? nb : 64;
     for (int mode = 0; mode < 3; ++mode)       // label; fill holes (frames that have any); relabel those frames
         VBS_LAUNCH(h, s, mode == 0 ? "k_label" : (mode == 1 ? "k_label_fill" : "k_label_redo"), k_label,
-                   dim3(nb, mode == 0 ? 2 : 1), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase, h->node_pos,
+                   dim3(gs, mode == 0 ? 2 : 1), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase, h->node_pos,
                    h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first, h->area_sums, h->fstat, h->lut,
-                   h->H, h->W, h->WW, h->maxm, stop, mode);
+                   h->slow_list, h->H, h->W, h->WW, h->maxm, stop, mode);
+    VBS_LAUNCH(h, s, "k_probe_slow", k_probe_slow, dim3(gs), dim3(256), 0, s, h->slow_list, h->ncomp, h->band_sums,
+               h->open_bits, h->wbase, h->node_comp, h->fstat, h->probe, h->H, h->W, h->WW, h->maxm);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -935,31 +987,18 @@ __device__ void fit_ellipse_moments(const i64* S, int ax, int ay, double* out) {
     out[6] = 1.0;
 }
 
-__device__ __forceinline__ bool in_comp(const u64* __restrict__ bits, const u32* __restrict__ wbase,
-                                        const u32* __restrict__ node_comp, int H, int W, int WW, int x,
-                                        int y, u32 cid) {
-    if (x < 0 || y < 0 || x >= W || y >= H) return false;
-    const u64* row = bits + (int64_t)y * WW;
-    if (!((row[x >> 6] >> (x & 63)) & 1ull)) return false;
-    return node_comp[node_of(row, wbase + (int64_t)y * WW, x >> 6, x & 63)] == cid;
-}
-
-// cv2.pointPolygonTest(contour, pt, False) >= 0 for the outer border polygon of component cid,
-// decided from the 2x2 pixel cell around the (float32-rounded) point.
-__device__ bool inside_polygon(const u64* bits, const u32* wbase, const u32* node_comp, int H, int W,
-                               int WW, double px, double py, u32 cid) {
-    float xf = (float)px, yf = (float)py;
-    float fxl = floorf(xf), fyl = floorf(yf);
-    int ix = (int)fxl, iy = (int)fyl;
-    float fx = xf - fxl, fy = yf - fyl;
-    bool c00 = in_comp(bits, wbase, node_comp, H, W, WW, ix, iy, cid);
+// cv2.pointPolygonTest(contour, pt, False) >= 0 for the outer border polygon of component cid, decided from the 2x2
+// pixel cell around the (float32-rounded) point; pr = component ids of the cell's pixels (x, y), (x+1, y), (x, y+1),
+// (x+1, y+1) as left by k_ccl / k_probe_slow (0xFFFF = background or outside the image).
+__device__ bool inside_polygon(const unsigned short* __restrict__ pr, double px, double py, u32 cid) {
+    const float xf = (float)px, yf = (float)py;
+    const float fx = xf - floorf(xf), fy = yf - floorf(yf);
+    const bool c00 = pr[0] == cid;
     if (fx == 0.f && fy == 0.f) return c00;
-    if (fy == 0.f) return c00 && in_comp(bits, wbase, node_comp, H, W, WW, ix + 1, iy, cid);
-    if (fx == 0.f) return c00 && in_comp(bits, wbase, node_comp, H, W, WW, ix, iy + 1, cid);
-    bool c10 = in_comp(bits, wbase, node_comp, H, W, WW, ix + 1, iy, cid);
-    bool c01 = in_comp(bits, wbase, node_comp, H, W, WW, ix, iy + 1, cid);
-    bool c11 = in_comp(bits, wbase, node_comp, H, W, WW, ix + 1, iy + 1, cid);
-    int cnt = (int)c00 + c10 + c01 + c11;
+    if (fy == 0.f) return c00 && pr[1] == cid;
+    if (fx == 0.f) return c00 && pr[2] == cid;
+    const bool c10 = pr[1] == cid, c01 = pr[2] == cid, c11 = pr[3] == cid;
+    const int cnt = (int)c00 + c10 + c01 + c11;
     if (cnt == 4) return true;
     if (cnt == 3) {
         if (!c11) return fx + fy <= 1.f;
@@ -978,9 +1017,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
                                                   const u64* __restrict__ band_sums,
                                                   const u32* __restrict__ area_first,
                                                   const i64* __restrict__ area_sums,
-                                                  const u64* __restrict__ open_bits,
-                                                  const u32* __restrict__ wbase_all,
-                                                  const u32* __restrict__ node_comp_all,
+                                                  const unsigned short* __restrict__ probe_all,
                                                   const u32* __restrict__ fstat, double* __restrict__ ell_all,
                                                   double* __restrict__ det64, int32_t* __restrict__ cnt64,
                                                   double* __restrict__ det32, int32_t* __restrict__ cnt32,
@@ -1011,10 +1048,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
     }
     __syncthreads();
     if (stop == 1) return;
-    const int NW = H * WW;
-    const u64* bits = open_bits + (int64_t)n * NW;
-    const u32* wbase = wbase_all + ((int64_t)n * 2 + 1) * NW;
-    const u32* node_comp = node_comp_all + ((int64_t)n * 2 + 1) * VBS_RUN_CAP;
+    const unsigned short* probe = probe_all + (int64_t)n * maxm * 4;
     double* d64 = det64 + (int64_t)n * maxm * 6;
     double* d32 = det32 ? det32 + (int64_t)n * maxm * 6 : nullptr;
 
@@ -1054,7 +1088,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
                 }
             const bool need = active && cand >= 0;
             if (!__any(need)) break;
-            const bool ok = need && inside_polygon(bits, wbase, node_comp, H, W, WW, bx[max(cand, 0)], by[max(cand, 0)], (u32)ci);
+            const bool ok = need && inside_polygon(probe + max(cand, 0) * 4, bx[max(cand, 0)], by[max(cand, 0)], (u32)ci);
             if (ok) { bi = cand; active = false; }
             else if (need) { lastd = best; lasti = cand; }
             else active = false;
@@ -1115,7 +1149,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
             double dx = bx[i] - ecx, dy = by[i] - ecy;
             double d = dx * dx + dy * dy;
             if (d < thr && d < best &&
-                inside_polygon(bits, wbase, node_comp, H, W, WW, bx[i], by[i], (u32)ci)) {
+                inside_polygon(probe + i * 4, bx[i], by[i], (u32)ci)) {
                 best = d; bi = i;
             }
         }
@@ -1144,8 +1178,7 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
 
 void launch_finalize(vbs_handle* h, int nb, double* det, int32_t* counts, hipStream_t s) {
     VBS_LAUNCH(h, s, "k_finalize", k_finalize, dim3(nb), dim3(256), 0, s, h->ncomp, h->band_sums, h->area_first,
-                       h->area_sums, h->open_bits, h->wbase, h->node_comp, h->fstat, h->ell, h->det64,
-                       h->cnt, det, counts, h->H, h->W, h->WW, h->maxm,
-                       getenv("VBS_FINAL_STOP") ? atoi(getenv("VBS_FINAL_STOP")) : 0,
-                       getenv("VBS_FORCE_SEQ_MATCH") ? 1 : 0);     // debug: exercise the sequential replay
+                       h->area_sums, h->probe, h->fstat, h->ell, h->det64,
+                       h->cnt, det, counts, h->H, h->W, h->WW, h->maxm, VBS_KNOB("VBS_FINAL_STOP"),
+                       h->force_seq_match ? 1 : 0);                 // (vbs_set_option: exercises the sequential replay)
 }

@@ -553,7 +553,7 @@ void launch_popcount(vbs_handle* h, int nb, hipStream_t s) {
 }
 
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s) {
-    if (!ncc_out && !getenv("VBS_NCC_VALU")) {
+    if (!ncc_out && !VBS_KNOB("VBS_NCC_VALU")) {
         const int tilesY = (h->H + 15) / 16;
         int nseg = std::min(tilesY, std::max(1, (2048 + h->WW * nb - 1) / (h->WW * nb)));   // few frames: split columns
         const int tps = (tilesY + nseg - 1) / nseg;
@@ -570,7 +570,7 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         return;
     }
     dim3 grid(h->WW, (h->H + 63) / 64, nb);
-    const int stop = getenv("VBS_NCC_STOP") ? atoi(getenv("VBS_NCC_STOP")) : 0;   // debug: phase timing
+    const int stop = VBS_KNOB("VBS_NCC_STOP");
     if (!h->bp.small) {
         VBS_LAUNCH(h, s, "k_ncc", (k_ncc<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx, h->ncc_ry,
                    h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->WW, stop, h->ncc);

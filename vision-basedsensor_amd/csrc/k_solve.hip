@@ -70,8 +70,7 @@ __global__ __launch_bounds__(256) void k_track(const double* __restrict__ det64,
                                                double min_size) {
     __shared__ double mx[1024], my[1024];
     const int n = blockIdx.x, tid = threadIdx.x;
-    int cnt = counts[n];
-    if (cnt < 0) cnt = 0;
+    const int cnt = min(max(counts[n], 0), min(maxm, 1024));     // a status (< 0) tracks nothing; never past the tables
     for (int i = tid; i < cnt; i += blockDim.x) {
         mx[i] = det64[((int64_t)n * maxm + i) * 6 + 0];
         my[i] = det64[((int64_t)n * maxm + i) * 6 + 1];

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_undist_map(short2* __restrict__ map1, u
 __global__ __launch_bounds__(256) void k_remap(const u8* __restrict__ frames, int channels, int64_t stride_n,
                                                int64_t stride_row, const short2* __restrict__ map1,
                                                const unsigned short* __restrict__ map2, const int* __restrict__ wtab,
-                                               u8* __restrict__ out, int to_gray, int H, int W, int P) {
+                                               u8* __restrict__ out, int to_gray, int H, int W, int P, GrayCoef gc) {
     int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, n = blockIdx.z;
     if (x >= W) return;
     short2 m = map1[(int64_t)y * W + x];
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_remap(const u8* __restrict__ frames, in
         val[c] = (u32)((p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15);
     }
     if (to_gray) {
-        u32 g = channels == 1 ? val[0] : (1868u * val[0] + 9617u * val[1] + 4899u * val[2] + 8192u) >> 14;
+        u32 g = channels == 1 ? val[0] : (gc.cb * val[0] + gc.cg * val[1] + gc.cr * val[2] + gc.half) >> gc.shift;
         out[((int64_t)n * H + y) * P + x] = (u8)g;
     } else {
         for (int c = 0; c < channels; ++c) out[(((int64_t)n * H + y) * W + x) * channels + c] = (u8)val[c];
@@ -141,5 +141,5 @@ void launch_remap(vbs_handle* h, const u8* frames, int nb, int channels, int64_t
     dim3 grid((h->W + 255) / 256, h->H, nb);
     VBS_LAUNCH(h, s, "k_remap", k_remap, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row,
                (const short2*)h->umap1, (const unsigned short*)h->umap2, (const int*)h->uwtab, out, to_gray, h->H, h->W,
-               h->P);
+               h->P, gray_coef(h->gray_bits));
 }

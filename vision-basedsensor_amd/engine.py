@@ -105,6 +105,16 @@ class Engine:
         return out
 
     # ---- a3-a8 -------------------------------------------------------------------------------
+    def bgr2gray(self, frames):
+        """cv2.cvtColor(BGR2GRAY) of [N,H,W,3] frames -> uint8 [N,H,W] (coefficient set: OPT_GRAY_COEFFS)."""
+        frames, n, ch, sn, sr = self._frames(frames)
+        if ch != 3:
+            raise ValueError("bgr2gray needs 3-channel frames")
+        out = torch.empty((n, self.H, self.W), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_bgr2gray(self._h, _ptr(frames), n, sn, sr, _ptr(out), self._stream()), "vbs_bgr2gray")
+        return out
+
     def find_markers(self, frames):
         frames, n, ch, sn, sr = self._frames(frames)
         mask = torch.empty((n, self.H, self.W), dtype=torch.uint8, device=self.device)
@@ -136,6 +146,10 @@ class Engine:
             self._check(self.lib.vbs_normxcorr2(self._h, _ptr(area_mask), n, _ptr(out), _ptr(mask),
                                                 self._stream()), "vbs_normxcorr2")
         return (out, mask) if want_mask else out
+
+    def set_option(self, option: int, value: int):
+        """`vbs_set_option`: L.OPT_GRAY_COEFFS (15 | 14), L.OPT_FORCE_SEQ_MATCH (test hook)."""
+        self._check(self.lib.vbs_set_option(self._h, int(option), int(value)), "vbs_set_option")
 
     def profile(self, enable: bool):
         self._check(self.lib.vbs_profile(self._h, 1 if enable else 0), "vbs_profile")
@@ -175,8 +189,13 @@ class Engine:
     # ---- a15 ---------------------------------------------------------------------------------
     def track(self, det, counts, ref_xy, min_dist=20.0):
         ref = torch.as_tensor(ref_xy, dtype=torch.float64, device=self.device).contiguous().reshape(-1, 2)
-        if det.dtype != torch.float64 or not det.is_contiguous():
-            raise ValueError("det must be a contiguous float64 tensor [n, max_markers, 6]")
+        if det.dtype != torch.float64 or not det.is_contiguous() or det.device != self.device or det.dim() != 3 \
+                or tuple(det.shape[1:]) != (self.max_markers, L.DET_COLS):
+            raise ValueError(f"det must be a contiguous float64 tensor [n, {self.max_markers}, {L.DET_COLS}] on the "
+                             "engine's device")
+        if counts.dtype != torch.int32 or counts.device != self.device or not counts.is_contiguous() \
+                or counts.numel() != det.shape[0]:
+            raise ValueError("counts must be a contiguous int32 tensor [n] on the engine's device")
         n, m = det.shape[0], ref.shape[0]
         table = torch.empty((n, m, L.TABLE_COLS), dtype=torch.float32, device=self.device)
         with torch.cuda.device(self.device):

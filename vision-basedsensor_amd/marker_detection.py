@@ -11,7 +11,8 @@ Differences a maintainer should know (all deliberate):
    array of frames [N,H,W(,3)] uint8, and `process_frames(frames)` takes frames already in memory;
    the annotated AVI (`:69-76,453`) and the drawing calls are not produced (visual only);
  * extra optional config keys: `id_mode` ("as_written" | "full"), `kmeans` ("optimal" | "sklearn"),
-   `device` (GPU index), `batch` (frames per device batch).
+   `device` (GPU index), `batch` (frames per device batch), `gray_coeffs` (15 = OpenCV 4's BGR2GRAY fixed-point
+   set, the default; 14 = the older set; identical on grey frames).
 There is no CPU fallback: without a GPU or without the built library every compute call raises.
 """
 from __future__ import annotations
@@ -27,8 +28,8 @@ CSV_COLUMNS = ["frameno", "row", "col", "Ox", "Oy", "Cx", "Cy", "major_axis", "m
 _ENGINES = {}
 
 
-def _engine(height, width, device=None, max_batch=16, calibration=None):
-    """One cached engine per (frame size, device, undistortion setup)."""
+def _engine(height, width, device=None, max_batch=16, calibration=None, gray_coeffs=15):
+    """One cached engine per (frame size, device, undistortion setup, BGR2GRAY coefficient set)."""
     import torch
     from .engine import Engine
     dev = torch.cuda.current_device() if (device is None and torch.cuda.is_available()) else (device or 0)
@@ -37,12 +38,15 @@ def _engine(height, width, device=None, max_batch=16, calibration=None):
         K = np.asarray(calibration["camera_matrix"], dtype=np.float64).reshape(3, 3)
         D = np.asarray(calibration["dist_coeffs"], dtype=np.float64).ravel()
         ukey = (K.tobytes(), D.tobytes())
-    key = (int(height), int(width), int(dev), ukey)
+    key = (int(height), int(width), int(dev), ukey, int(gray_coeffs))
     eng = _ENGINES.get(key)
     if eng is None or eng.max_batch < max_batch:
         eng = Engine(height, width, max_markers=1024, max_batch=max_batch, device=int(dev))
         if calibration is not None:
             eng.set_undistort(K, D)
+        if int(gray_coeffs) != 15:
+            from . import _lib as L
+            eng.set_option(L.OPT_GRAY_COEFFS, int(gray_coeffs))
         _ENGINES[key] = eng
     return eng
 
@@ -65,6 +69,39 @@ def _det_to_markers(det, count):
     """det rows [x, y, major, minor, angle, label] -> the reference's marker dicts (`:238-243`)."""
     return [{"center": (float(r[0]), float(r[1])), "major_axis": float(r[2]), "minor_axis": float(r[3]),
              "angle": float(r[4])} for r in det[:count]]
+
+
+class _RowBlock:
+    """The CSV rows of one device batch as columns (NumPy arrays); iterates / indexes as the reference's row dicts."""
+
+    def __init__(self, cols):
+        self.cols = cols
+        self.n = len(cols["frameno"])
+
+    def __len__(self):
+        return self.n
+
+    def __iter__(self):
+        names = CSV_COLUMNS
+        arrs = [self.cols[c].tolist() for c in names]
+        return (dict(zip(names, vals)) for vals in zip(*arrs))
+
+
+class _Rows:
+    """What `process_frames` returns: the batches' blocks; behaves as the flat list of row dicts."""
+
+    def __init__(self, blocks):
+        self.blocks = blocks
+
+    def __len__(self):
+        return sum(len(b) for b in self.blocks)
+
+    def __iter__(self):
+        for b in self.blocks:
+            yield from b
+
+    def __getitem__(self, i):
+        return list(self)[i]
 
 
 class MarkerTracker:
@@ -232,16 +269,16 @@ class MarkerTracker:
     def process(self):
         self._init_video()
         if self._frames is not None:
-            data = self.process_frames(self._frames)
+            data = self.process_frames(self._frames).blocks
         else:
-            batch = int(self.config.get("batch", 16))
+            batch = int(self.config.get("batch", 64))
             data, buf = [], []
             while True:
                 ret, frame = self.cap.read()
                 if ret:
                     buf.append(frame)
                 if buf and (len(buf) == batch or not ret):
-                    data.extend(self._process_batch(np.stack(buf)))
+                    data.append(self._process_batch(np.stack(buf)))
                     buf = []
                 if not ret:
                     break
@@ -254,20 +291,21 @@ class MarkerTracker:
             self.height, self.width = int(frames.shape[1]), int(frames.shape[2])
             left, right, top, bottom = _crop_box(self.width, self.height, self.config["crop_ratios"])
             self.crop_width, self.crop_height = right - left, bottom - top
-        batch = int(self.config.get("batch", 16))
+        batch = int(self.config.get("batch", 256))
         data = []
         for s in range(0, frames.shape[0], batch):
-            data.extend(self._process_batch(frames[s:s + batch]))
-        return data
+            data.append(self._process_batch(frames[s:s + batch]))
+        return _Rows(data)
 
     def _process_batch(self, frames):
         import torch
         left, right, top, bottom = _crop_box(self.width, self.height, self.config["crop_ratios"])
-        eng = _engine(bottom - top, right - left, self.config.get("device"), int(self.config.get("batch", 16)),
-                      calibration=self.config.get("calibration_params"))    # undistortion, if any, runs inside the engine
+        eng = _engine(bottom - top, right - left, self.config.get("device"),
+                      min(int(self.config.get("batch", 64)), max(int(frames.shape[0]), 1)),
+                      calibration=self.config.get("calibration_params"),    # undistortion, if any, runs inside the engine
+                      gray_coeffs=self.config.get("gray_coeffs", 15))
         ft = frames if isinstance(frames, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(frames))
         ft = ft.to(eng.device)[:, top:bottom, left:right]           # crop = strided view, no copy
-        rows = []
         if self.frame_count == 0:
             _, det, counts = eng.track_to_3d(ft[:1], None, want_det=True)
             n0 = int(counts[0].item())
@@ -278,24 +316,36 @@ class MarkerTracker:
         ids, ref_xy = _ids.reference_arrays(self.first_frame_markers)
         table, det, counts = eng.track_to_3d(ft, ref_xy, self.config.get("min_marker_distance", 20),
                                              want_det=True)
+        counts = counts.cpu().numpy()
+        if (counts < 0).any():                  # the reference would have emitted rows: never drop a frame silently
+            from ._lib import VbsError
+            bad = int(np.nonzero(counts < 0)[0][0])
+            raise VbsError(f"device status {int(counts[bad])} in frame {self.frame_count + bad} "
+                           f"(capacity exceeded: more runs / components than the workspace holds)")
         table = table.cpu().numpy()
         det = det.cpu().numpy()                 # float64 rows: the CSV keeps the reference's precision
-        refs = list(self.first_frame_markers.values())
-        for f in range(table.shape[0]):
-            for slot in np.nonzero(table[f, :, 0].astype(np.int64) & 1)[0]:
-                d = det[f, int(table[f, slot, 9])]
-                rows.append({"frameno": self.frame_count, "row": int(ids[slot, 0]), "col": int(ids[slot, 1]),
-                             "Ox": refs[slot]["Ox"], "Oy": refs[slot]["Oy"], "Cx": d[0], "Cy": d[1],
-                             "major_axis": d[2], "minor_axis": d[3], "angle": d[4]})
-            self.frame_count += 1
-            if self.frame_count % 100 == 0:
-                print(f"Processed frame {self.frame_count}")
-        return rows
+        # all rows of the batch at once: (frame, slot) pairs in frame-major, reference-dict order
+        fi, si = np.nonzero(table[:, :, 0].astype(np.int64) & 1)
+        d = det[fi, table[fi, si, 9].astype(np.int64)]
+        refs = np.array([(r["Ox"], r["Oy"]) for r in self.first_frame_markers.values()], dtype=np.float64).reshape(-1, 2)
+        block = {"frameno": self.frame_count + fi, "row": np.asarray(ids)[si, 0].astype(np.int64),
+                 "col": np.asarray(ids)[si, 1].astype(np.int64), "Ox": refs[si, 0], "Oy": refs[si, 1],
+                 "Cx": d[:, 0], "Cy": d[:, 1], "major_axis": d[:, 2], "minor_axis": d[:, 3], "angle": d[:, 4]}
+        n_before = self.frame_count
+        self.frame_count += table.shape[0]
+        for k in range(n_before // 100 + 1, self.frame_count // 100 + 1):
+            print(f"Processed frame {100 * k}")
+        return _RowBlock(block)
 
     def _save_results(self, data):
-        """`:464-468`."""
+        """`:464-468`.  `data`: row dicts (the reference's form) or the per-batch column blocks of `_process_batch`."""
         import pandas as pd
-        df = pd.DataFrame(data, columns=CSV_COLUMNS if not data else None)
+        if isinstance(data, _Rows):
+            data = data.blocks
+        if data and all(isinstance(b, _RowBlock) for b in data):
+            df = pd.DataFrame({c: np.concatenate([b.cols[c] for b in data]) for c in CSV_COLUMNS}, columns=CSV_COLUMNS)
+        else:
+            df = pd.DataFrame(list(data), columns=CSV_COLUMNS if not data else None)
         df.to_csv(self.output_csv, index=False)
         print(f"Saved tracking data to {self.output_csv}")
 

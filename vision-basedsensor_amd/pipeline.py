@@ -24,6 +24,7 @@ class TrackResult:
     plane: Optional[torch.Tensor]    # [n_local,5]
     frame_begin: int = 0
     frame_end: int = 0
+    counts: Optional[torch.Tensor] = None   # [n_local] int32 detections per frame of this rank (never negative here)
 
 
 def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mode="full", kmeans="optimal",
@@ -58,6 +59,11 @@ def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None,
         ids, xy = ref
     local, _, counts = eng.track_to_3d(frames_local, xy, min_dist, cam, min_marker_size_px)
     table = D.gather_tables(local, n_total)
+    bad = torch.nonzero(counts < 0)            # (after the collective, so a failing rank cannot leave the others waiting in it)
+    if bad.numel():
+        f = int(bad[0].item())
+        raise L.VbsError(f"device status {int(counts[f].item())} in frame {D.shard_bounds(n_total, ws, rank)[0] + f} "
+                         f"(capacity exceeded): the reference would have emitted rows for it")
     a, b = D.shard_bounds(n_total, ws, rank)
     disp = plane = None
     if cam is not None:
@@ -66,4 +72,4 @@ def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None,
         disp = eng.displacement(table, warmup_frames, min_marker_size_px, max_displacement, frame_range=(a, b))
         if with_plane:
             plane = eng.plane_fit(local)
-    return TrackResult(ids, xy, table, disp, plane, a, b)
+    return TrackResult(ids, xy, table, disp, plane, a, b, counts)

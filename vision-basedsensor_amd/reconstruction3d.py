@@ -6,8 +6,9 @@ vbs_displacement).
 Published defects that a literal copy would inherit are fixed, nothing else is changed:
  * `Config.column_mapping` is a `default_factory` (the mutable default at `:28` raises at import);
  * no module-level FileHandler into a directory that does not exist yet (`:42`);
- * parameter tables: `.xlsx` is read with pandas when an Excel engine is installed, and `.csv` / `.json`
-   with the same `Parameter, Value` layout are accepted; both spellings of the translation keys
+ * parameter tables: `.xlsx` is read by the package's own reader (`xlsx_io`: zipfile + xml.etree, no Excel engine
+   needed) and the result sheet `marker_3d_coordinates.xlsx` (`:430-433`) is written by its writer; `.csv` / `.json`
+   with the same `Parameter, Value` layout are accepted too; both spellings of the translation keys
    (`Tx_wc` `:121` / `T_wc_X` `extrinsic_calibration.py:135-151`) and of the key column
    (`Parameter` `:84` / `Param` `intrinsic_calibration.py:51`) are understood.
 Plots (`:336-394`) are out of scope; `analyze_displacement` writes the statistics CSV only.
@@ -64,8 +65,12 @@ def _read_params(path: Path) -> pd.Series:
     if path.suffix.lower() == ".csv":
         df = pd.read_csv(path)
     else:
-        df = pd.read_excel(path)                   # needs an Excel engine (openpyxl)
+        from .xlsx_io import read_xlsx
+        df = read_xlsx(path)                       # what pd.read_excel(path) returns, without an Excel engine
     key = "Parameter" if "Parameter" in df.columns else "Param"
+    if key not in df.columns or "Value" not in df.columns:
+        raise ValueError(f"{path}: expected columns 'Parameter' (or 'Param') and 'Value', got {list(df.columns)}")
+    # the extrinsics sheet carries title / date / blank rows (`extrinsic_calibration.py:135-141`): keep numeric values
     df = df[pd.to_numeric(df["Value"], errors="coerce").notna()]
     return df.set_index(key)["Value"].astype(float)
 
@@ -235,11 +240,8 @@ class MarkerAnalysis:
                 raise ValueError("No valid 3D positions calculated")
             logger.info(f"Calculated 3D positions for {len(results_df)} marker observations")
             output_path = Path(self.config.output_dir) / "marker_3d_coordinates.xlsx"
-            try:
-                results_df.to_excel(output_path, index=False)
-            except (ImportError, ModuleNotFoundError):          # no Excel engine installed
-                output_path = output_path.with_suffix(".csv")
-                results_df.to_csv(output_path, index=False)
+            from .xlsx_io import dataframe_to_xlsx
+            dataframe_to_xlsx(results_df, output_path)          # `results_df.to_excel(output_path, index=False)` :432
             logger.info(f"Saved 3D coordinates to {output_path}")
             self.analyze_displacement(results_df)
             logger.info("Analysis completed successfully")
