@@ -16,17 +16,25 @@ Extra objects on the JSON line:
   (dtype "u8+f64": uint8 / int32 integer work in the blur (int8 matrix cores, exact) and labelling kernels, float64
    decisions in the NCC (behind a float16-operand / float32-accumulate matrix-core filter), the ellipse fit and the
    3-D solve; tables are stored as float32)
-  roofline      threshold+CCL stage (`vbs_marker_center` on uint8 mask + area_mask: k_threshold,
-                k_morph x2, k_label, k_finalize), timed live with HIP events on the launch stream
-                inside libvbs.  achieved = algorithmic bytes / stage time, algorithmic bytes per
-                frame = 2*H*W (the two uint8 images it thresholds) + 24 B per component.
+  roofline      threshold+CCL stage AS IT RUNS ON THE TIMED PATH (bit-packed masks in -> detections out: k_morph,
+                k_ccl_band, k_ccl_open, k_slow_list, k_label*, k_probe_slow, k_finalize), timed live with HIP events
+                on the launch stream inside libvbs.  achieved = SURVEY 8(d) algorithmic bytes (H*W + 24 B per label,
+                per frame) x frames per launch / sum of the kernels' average launch durations.  `staged_u8` repeats it
+                for the staged entry `vbs_marker_center` on two uint8 images (k_threshold + the same kernels), with the
+                one-image (8d) and the two-image numerators.  `traffic` = HBM bytes per launch from the newest
+                profiles/*_pmc_traffic_<workload>.json (separate rocprofv3 --pmc passes), null when there is none.
   roofline_mfma k_blur_mfma (int8) and k_ncc_mfma (float16) against the dense matrix-core peaks: algorithmic
                 operations of the separable filters / live kernel time (same HIP events)
   kernels       live average ms per launch of every kernel of the fused path (one launch = `batch` frames)
-  cpu_baseline  the NumPy/SciPy oracle (oracle/stages.py, a port: the reference needs OpenCV) on the
-                box's host cores over a bounded sample of the same frames (rank 0, N = 1 only).
+  cpu_baseline  BASELINE.md 3: the NumPy/SciPy oracle (oracle/stages.py, a port: the reference needs OpenCV) on the
+                box's host cores over a bounded sample of the same frames (rank 0, N = 1 only): single process over
+                >= 32 frames after 2 warm-ups, and one worker process per physical core this job may use.
+  config        also: bgr_fps (the same workload fed as 3-channel BGR frames, the reference's input format),
+                host_path_fps (NumPy frames in host memory -> CSV on disk through MarkerTracker), the NCC decision
+                counters of the timed batch, world size / backend as torch.distributed reports them.
 """
 import argparse
+import glob
 import json
 import os
 import sys
@@ -36,41 +44,78 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
+STAGE = ("k_morph", "k_ccl_band", "k_ccl_open", "k_slow_list", "k_label", "k_label_fill", "k_label_redo", "k_probe_slow",
+         "k_finalize")
 
 
 def _cpu_worker(args):
-    """Oracle over a few frames in one process (cpu_baseline leg only)."""
+    """Oracle over a few frames in one process (cpu_baseline leg only); the first `warm` frames are not timed."""
     import numpy as np
     from oracle import stages as O
-    frames, ref, cam = args
+    frames, ref, cam, warm = args
     K, dist, R, T = cam
     t0 = time.perf_counter()
-    rows = []
+    rows, n = [], 0
     for fc, fr in enumerate(frames):
+        if fc == warm:
+            t0 = time.perf_counter()
+            rows = []
         mask, area = O.find_markers(fr)
         markers = O.marker_center(mask, area)
         rows.extend(O.track_markers(ref, markers, fc + 1, 20))
+        n += fc >= warm
     uv = O.undistort_points(np.array([[r["Cx"], r["Cy"]] for r in rows]), K, dist)
     for r, (u, v) in zip(rows, uv):
         try:
             O.calculate_3d_position(np.float64(u), np.float64(v), np.float64(r["major_axis"]), K, R, T)
         except ValueError:
             pass
-    return time.perf_counter() - t0, len(frames)
+    return time.perf_counter() - t0, n
 
 
-def cpu_baseline(spec, seed, cam, workers, per_worker):
-    import numpy as np
+def _host_cpus():
+    """(logical CPUs, physical cores, CPUs this process may run on, model name) of the host."""
+    phys, model = set(), ""
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+            elif line.startswith("model name") and not model:
+                model = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if pid is not None and cid is not None:
+                    phys.add((pid, cid))
+                pid = cid = None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = os.cpu_count() or 1
+    return os.cpu_count() or 1, len(phys) or (os.cpu_count() or 1), usable, model
+
+
+def cpu_baseline(spec, seed, cam, single_frames, max_workers, per_worker, warm=2):
+    """BASELINE.md 3: (i) single process, default FFT/BLAS threading, fps over >= 32 frames after 2 warm-ups;
+    (ii) one worker process per physical core over disjoint frame ranges (bounded by the CPUs this job may use: a
+    one-GPU box grants a 16-CPU share of the host)."""
     import multiprocessing as mp
     import vbs_amd.synth as S
     from oracle import stages as O
+    logical, physical, usable, model = _host_cpus()
+    workers = max(1, min(physical, usable, max_workers))
     f0 = S.make_frames(spec, [0], seed=seed)[0]
     m0, a0 = O.find_markers(f0)
     ref = O.process_first_frame(O.marker_center(m0, a0), 5, "full", "optimal")
-    frames = S.make_frames(spec, range(1, 1 + workers * per_worker), seed=seed)
-    t_single, n_single = _cpu_worker((frames[:2], ref, cam))
+    nfr = max(single_frames + warm, workers * (per_worker + warm))
+    frames = S.make_frames(spec, range(1, 1 + nfr), seed=seed)
+    t_single, n_single = _cpu_worker((frames[:single_frames + warm], ref, cam, warm))
     single_fps = n_single / t_single
-    chunks = [(frames[i * per_worker:(i + 1) * per_worker], ref, cam) for i in range(workers)]
+    step = per_worker + warm
+    chunks = [(frames[i * step:(i + 1) * step], ref, cam, warm) for i in range(workers)]
     t0 = time.perf_counter()
     with mp.get_context("spawn").Pool(workers) as pool:
         res = pool.map(_cpu_worker, chunks)
@@ -78,10 +123,38 @@ def cpu_baseline(spec, seed, cam, workers, per_worker):
     busy = max(r[0] for r in res)
     total = sum(r[1] for r in res)
     return {"value": round(total / busy, 3), "unit": "frames/s", "cores": workers, "kind": "port",
-            "sample": f"{total} of the benchmark's 1280x1024 frames, {workers} worker processes x {per_worker} "
-                      f"frames, oracle/stages.py end to end (find_markers+marker_center+track+3D); "
-                      f"single process: {single_fps:.3f} frames/s; pool wall incl. spawn {wall:.1f}s; "
-                      f"host has {os.cpu_count()} logical CPUs"}
+            "single_process": {"value": round(single_fps, 3), "frames": n_single, "warmup_frames": warm,
+                               "threads": "default FFT/BLAS threading"},
+            "host": {"logical_cpus": logical, "physical_cores": physical, "usable_cpus": usable, "model": model},
+            "sample": f"oracle/stages.py end to end (find_markers+marker_center+track+3D) on the benchmark's "
+                      f"{spec.width}x{spec.height} frames: single process {n_single} frames after {warm} warm-ups = "
+                      f"{single_fps:.3f} frames/s; {workers} worker processes (one per physical core this job may use: "
+                      f"{physical} physical / {usable} usable / {logical} logical CPUs) x {per_worker} frames after "
+                      f"{warm} warm-ups each = value; pool wall incl. spawn {wall:.1f}s"}
+
+
+def host_path_fps(spec, n, seed, batch):
+    """The drop-in's own rate from frames in HOST memory to the CSV on disk (upload over PCIe, fused kernels, row
+    building, pandas CSV writer): `MarkerTracker.process_frames` + `_save_results`."""
+    import tempfile
+    import vbs_amd.synth as S
+    from vbs_amd.marker_detection import MarkerTracker
+    frames = S.make_frames(spec, range(n), seed=seed)
+    with tempfile.TemporaryDirectory() as td_:
+        clip = os.path.join(td_, "clip.npy")
+        open(clip, "wb").close()                           # `video_path` must exist; frames are passed in memory
+        out = {}
+        for rep in range(2):                               # first repetition warms the engine / allocator
+            trk = MarkerTracker({"video_path": clip, "output_dir": os.path.join(td_, f"o{rep}"),
+                                 "crop_ratios": (0, 0, 0, 0), "id_mode": "full", "batch": batch})
+            t0 = time.perf_counter()
+            rows = trk.process_frames(frames)
+            t1 = time.perf_counter()
+            trk._save_results(rows)
+            t2 = time.perf_counter()
+            out = {"frames": n, "fps": round(n / (t2 - t0), 1), "fps_without_csv_write": round(n / (t1 - t0), 1),
+                   "csv_rows": len(rows), "batch": batch}
+    return out
 
 
 def main():
@@ -93,12 +166,17 @@ def main():
     ap.add_argument("--batch", type=int, default=512, help="frames per internal pass (workspace size)")
     ap.add_argument("--roofline-frames", type=int, default=1024)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-workers", type=int, default=8)
+    ap.add_argument("--no-extras", action="store_true", help="skip the BGR and host-path side measurements")
+    ap.add_argument("--cpu-single-frames", type=int, default=32)
+    ap.add_argument("--cpu-workers", type=int, default=16, help="upper bound; one per physical core the job may use")
     ap.add_argument("--cpu-frames-per-worker", type=int, default=3)
+    ap.add_argument("--host-frames", type=int, default=512)
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
                     help="c3 = BASELINE config 3/4 (1280x1024, 13x13; the headline metric); c5 = config 5 (1920x1200, 21x21, "
                          "adds the plane-fit pose per frame; the JSON line then names that workload)")
+    ap.add_argument("--channels", type=int, default=1, choices=[1, 3],
+                    help="1 = gray frames (headline); 3 = the whole benchmark on BGR frames (the line then says so)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) | gloo (rehearsal of N>1 on one GPU)")
     args = ap.parse_args()
 
@@ -136,16 +214,22 @@ def main():
 
     # synthetic frames of this rank's contiguous block, rendered on the device (same bytes as NumPy)
     a, b = D.shard_bounds(n_total, world, rank)
-    frames = S.make_frames_torch(spec, range(a, b), seed=args.seed, device=dev, chunk=16)
-    f0 = frames[:1] if rank == 0 else None
+    gray = S.make_frames_torch(spec, range(a, b), seed=args.seed, device=dev, chunk=16)
+
+    def as_bgr(g):
+        return g.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+
+    frames = gray if args.channels == 1 else as_bgr(gray)
+    if args.channels == 3:
+        del gray
     ids = xy = None
     if rank == 0:
-        ids, xy = reference_from_frame0(eng, f0, 5, "full", "optimal")
+        ids, xy = reference_from_frame0(eng, frames[:1], 5, "full", "optimal")
     ids, xy = D.broadcast_reference(ids, xy, dev)
     assert len(ids) == M, f"frame 0 gave {len(ids)} IDs, expected {M}"
 
-    def step():
-        table, _, counts = eng.track_to_3d(frames, xy, 20.0, cam, 5.0)
+    def step(fr):
+        table, _, counts = eng.track_to_3d(fr, xy, 20.0, cam, 5.0)
         table = D.gather_tables(table, n_total)
         disp = eng.displacement(table, 0, 5.0, 50.0, frame_range=(a, b))    # this rank's frames of the gathered table
         if args.workload == "c5":
@@ -157,18 +241,24 @@ def main():
             td.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        out = step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
-        td.all_reduce(t, op=td.ReduceOp.MAX)
-        elapsed = float(t.item())
+    def timed(fr, steps, warmup):
+        for _ in range(warmup):
+            out = step(fr)
+        barrier()
+        eng.ncc_counters(reset=True)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out = step(fr)
+        barrier()
+        el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev if args.backend != "gloo" else "cpu")
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+            el = float(t.item())
+        return el, out
+
+    elapsed, out = timed(frames, args.steps, args.warmup)
+    ncc_ctr = eng.ncc_counters()
     table, disp, counts = out
     tracked = int((table[..., 0].int() & 1).sum().item())
     solved = int(((table[..., 0].int() & 2) > 0).sum().item())
@@ -178,89 +268,138 @@ def main():
     result = None
     if rank == 0:
         fps = n_total * args.steps / elapsed
+        fmt = "gray uint8" if args.channels == 1 else "BGR uint8 (3-channel)"
         result = {
             "metric": f"frames/sec (track->3D) at {W}x{H}, {M} markers", "value": round(fps, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u8+f64", "data": "synthetic",
-            "config": {"workload": (f"BASELINE config 3/4: {args.frames} synthetic 1280x1024 gray uint8 frames per GPU "
+            "config": {"workload": (f"BASELINE config 3/4: {args.frames} synthetic 1280x1024 {fmt} frames per GPU "
                                     f"(13x13 dots, seeded jitter+noise)" if args.workload == "c3" else
-                                    f"BASELINE config 5: {args.frames} synthetic 1920x1200 gray uint8 frames per GPU "
+                                    f"BASELINE config 5: {args.frames} synthetic 1920x1200 {fmt} frames per GPU "
                                     f"(21x21 dots), plus plane-fit pose") +
                                    f", resident in HBM; fused track->3D table + "
                                    f"{'RCCL all-gather + ' if world > 1 else ''}last-seen displacement",
-                       "frames_per_gpu": args.frames, "internal_batch": args.batch, "markers": M,
+                       "frames_per_gpu": args.frames, "internal_batch": args.batch, "markers": M, "channels": args.channels,
+                       "world_size": td.get_world_size() if world > 1 else 1,
+                       "backend": td.get_backend() if world > 1 else "none (single process)",
                        "tracked_observations": tracked, "xyz_solved": solved,
                        "us_per_frame_per_gpu": round(1e6 * elapsed / args.steps / args.frames, 2),
-                       "whole_path_hbm_frac": round(fps / world * (H * W + M * 40) / 1e9 / HBM_PEAK_GBS, 6)},
+                       "whole_path_hbm_frac": round(fps / world * (H * W * args.channels + M * 40) / 1e9 / HBM_PEAK_GBS, 6),
+                       # every NCC decision equals the float64 one iff ambiguous == 0 (rank 0's frames of the timed steps)
+                       "ncc_ambiguous_pixels": ncc_ctr["ambiguous"], "ncc_exact_pixels": ncc_ctr["exact"],
+                       "ncc_counter_frames": ncc_ctr["frames"]},
         }
+
+    # ---- the same workload on BGR frames (the reference's input format; gray stays the headline) ----------------------
+    if args.channels == 1 and not args.no_extras:
+        nb_ = min(n_local, 1024)
+        fb = as_bgr(gray[:nb_])
+        n_keep = n_total
+        # (single-rank side measurement on rank 0's device; the other ranks wait at the barrier below)
+        if rank == 0:
+            for _ in range(1):
+                eng.track_to_3d(fb, xy, 20.0, cam, 5.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 3
+            for _ in range(reps):
+                tb, _, cb = eng.track_to_3d(fb, xy, 20.0, cam, 5.0)
+            torch.cuda.synchronize()
+            el_b = time.perf_counter() - t0
+            for _ in range(1):
+                eng.track_to_3d(gray[:nb_], xy, 20.0, cam, 5.0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                tg, _, cg = eng.track_to_3d(gray[:nb_], xy, 20.0, cam, 5.0)
+            torch.cuda.synchronize()
+            el_g = time.perf_counter() - t0
+            assert torch.equal(tb, tg), "BGR (B=G=R) and gray frames must give the same table"
+            result["config"]["bgr_fps"] = round(nb_ * reps / el_b, 1)
+            result["config"]["bgr_vs_gray_same_frames"] = round(el_g / el_b, 4)
+            result["config"]["bgr_frames"] = nb_
+        del fb, n_keep
 
     # ---- live per-kernel timing + the threshold+CCL roofline (rank 0; other ranks idle at the barrier) ----
     if rank == 0:
         nk = min(args.roofline_frames, n_local)
         eng.profile(True)
-        eng.track_to_3d(frames[:nk], xy, 20.0, cam, 5.0)
-        prof = eng.profile_read()
-        launches_per = {k: v[0] for k, v in prof.items()}
-        kernels = {k: {"launches": c, "avg_ms": round(ms / c, 4), "us_per_frame": round(1e3 * ms / nk, 3)}
-                   for k, (c, ms) in prof.items()}
-        # stage on uint8 images (the reference's `_marker_center(mask, area_mask)` interface)
-        mask, area = eng.find_markers(frames[:nk])
-        torch.cuda.synchronize()
-        eng.marker_center(mask, area)                       # warm
-        eng.profile(True)
-        reps = 3
+        reps = 2
         for _ in range(reps):
-            det, cnts = eng.marker_center(mask, area)
-        sp = eng.profile_read()
-        eng.profile(False)
-        stage = ("k_threshold", "k_morph", "k_label", "k_finalize")
-        stage_ms = sum(sp[k][1] for k in stage) / reps                      # per nk frames
-        n_passes = sp["k_label"][0] / reps                                   # launches of each kernel per call
-        ncomp = 2 * M
-        alg_bytes_frame = 2 * H * W + ncomp * 24
-        achieved = alg_bytes_frame * nk / (stage_ms * 1e-3) / 1e9
-        # HBM bytes per launch from the committed PMC passes (rocprofv3 cannot run inside this process):
-        # the newest profiles/*_pmc_traffic.json, scaled to this run's frames per launch
-        traffic = None
-        import glob
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+            eng.track_to_3d(frames[:nk], xy, 20.0, cam, 5.0)
+        prof = eng.profile_read()
+        kernels = {k: {"launches": c, "avg_ms": round(ms / c, 4), "us_per_frame": round(1e3 * ms / (nk * reps), 3)}
+                   for k, (c, ms) in prof.items()}
+        n_passes = prof["k_finalize"][0] / reps                              # launches of each kernel per call
+        fpl = nk / n_passes                                                  # frames per launch
+        stage_ms_launch = sum(prof[k][1] / prof[k][0] for k in STAGE if k in prof)      # sum of average launch durations
+        alg_bytes_frame = H * W + 24 * M                                     # image read + moment sums
+        achieved = alg_bytes_frame * fpl / (stage_ms_launch * 1e-3) / 1e9
+        traffic = traffic_src = None
+        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_{args.workload}.json")))
         if pm:
             pj = json.load(open(pm[-1]))
-            traffic = round(pj["traffic_bytes_per_frame"] * nk / n_passes)
+            traffic = round(pj["traffic_bytes_per_frame"] * fpl)
+            traffic_src = os.path.basename(pm[-1])
         result["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-            "kernel": "+".join(stage), "stage": "threshold+CCL (vbs_marker_center on uint8 mask+area_mask)",
-            "algorithmic_bytes_per_frame": alg_bytes_frame, "frames_per_launch": round(nk / n_passes, 1),
-            "stage_ms_per_launch": round(stage_ms / n_passes, 4),
-            "per_kernel_avg_ms": {k: round(sp[k][1] / sp[k][0], 4) for k in stage},
-            "us_per_frame": round(1e3 * stage_ms / nk, 3)}
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
+            "kernel": "+".join(k for k in STAGE if k in prof),
+            "stage": "threshold+CCL as it runs on the timed path (bit-packed masks -> detections)",
+            "algorithmic_bytes_per_frame": alg_bytes_frame, "frames_per_launch": round(fpl, 1),
+            "stage_ms_per_launch": round(stage_ms_launch, 4),
+            "per_kernel_avg_ms": {k: round(prof[k][1] / prof[k][0], 4) for k in STAGE if k in prof},
+            "us_per_frame": round(1e3 * stage_ms_launch / fpl, 3)}
+        # the staged entry on uint8 images (the reference's `_marker_center(mask, area_mask)` interface)
+        if args.channels == 1:
+            mask, area = eng.find_markers(frames[:nk])
+            torch.cuda.synchronize()
+            eng.marker_center(mask, area)                       # warm
+            eng.profile(True)
+            for _ in range(3):
+                eng.marker_center(mask, area)
+            sp = eng.profile_read()
+            st_ms = sum(sp[k][1] / sp[k][0] for k in ("k_threshold",) + STAGE if k in sp)
+            result["roofline"]["staged_u8"] = {
+                "entry": "vbs_marker_center (uint8 mask + area_mask)", "stage_ms_per_launch": round(st_ms, 4),
+                "k_threshold_avg_ms": round(sp["k_threshold"][1] / sp["k_threshold"][0], 4),
+                "k_threshold_GBps_of_2HW": round(2 * H * W * fpl / (sp["k_threshold"][1] / sp["k_threshold"][0] * 1e-3) / 1e9, 1),
+                "frac_8d_one_image": round(alg_bytes_frame * fpl / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                "frac_two_images": round((2 * H * W + 48 * M) * fpl / (st_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5)}
+            del mask, area
+        eng.profile(False)
         result["kernels"] = kernels
         # the two matrix-core kernels of the front end against the dense MFMA peaks (MI355X_MICROARCH.md: bf16/f16
         # ~2.5 PFLOP/s, int8 2x that); algorithmic operations = the separable filters as written in the reference
         # (Toeplitz padding, hi/lo splits and the count product are overhead, not counted)
         small = H <= 480
-        ta, tb, ln = (21, 35, 33) if small else (39, 101, 80)
+        ta, tb_, ln = (21, 35, 33) if small else (39, 101, 80)
         mf = []
-        for name, ops_px, peak, dt in (("k_blur_mfma", 2 * 2 * (ta + tb), 5000.0, "i8"),
+        for name, ops_px, peak, dt in (("k_blur_mfma", 2 * 2 * (ta + tb_), 5000.0, "i8"),
                                        ("k_ncc_mfma", 2 * 2 * ln, 2500.0, "f16")):
             if name in prof:
                 c, ms = prof[name]
-                ach = ops_px * H * W * nk / (ms * 1e-3) / 1e12
+                ach = ops_px * H * W * fpl / (ms / c * 1e-3) / 1e12
                 mf.append({"kernel": name, "bound": "mfma", "dtype": dt, "achieved": round(ach, 2), "peak": peak,
                            "unit": "TOP/s" if dt == "i8" else "TFLOP/s", "frac": round(ach / peak, 5),
                            "algorithmic_ops_per_pixel": ops_px, "avg_ms": round(ms / c, 4),
-                           "frames_per_launch": round(nk / c, 1)})
+                           "frames_per_launch": round(fpl, 1)})
         result["roofline_mfma"] = mf
-        del launches_per
     if world > 1:
         td.barrier()
 
+    if rank == 0 and world == 1 and not args.no_extras:
+        try:
+            del frames
+            torch.cuda.empty_cache()
+            result["config"]["host_path_fps"] = host_path_fps(spec, args.host_frames, args.seed, 256)
+        except Exception as e:
+            result["config"]["host_path_fps"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
-            result["cpu_baseline"] = cpu_baseline(spec, args.seed, (K, dist, R, T), args.cpu_workers,
-                                                  args.cpu_frames_per_worker)
+            result["cpu_baseline"] = cpu_baseline(spec, args.seed, (K, dist, R, T), args.cpu_single_frames,
+                                                  args.cpu_workers, args.cpu_frames_per_worker)
         except Exception as e:                                  # the baseline must not sink the GPU number
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
                                       "sample": f"failed: {type(e).__name__}: {e}"}

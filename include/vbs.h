@@ -117,6 +117,12 @@ int vbs_ncc_map(vbs_handle* h, const uint8_t* frames, int n, int channels, int64
  * float64 [n,h,w] and / or mask [dev] uint8 [n,h,w] = ncc > 0.1 (:133); either may be NULL. */
 int vbs_normxcorr2(vbs_handle* h, const uint8_t* area_mask, int n, double* ncc, uint8_t* mask,
                    void* stream);
+/* MarkerTracker._normxcorr2(template, image, mode) (marker_detection.py:146-164) for ARBITRARY operands, no handle needed:
+ * tmpl [dev] float64 [th,tw] (tw <= 256), image [dev] float64 [h,w], mode 0 'full' | 1 'same' | 2 'valid' (the window
+ * scipy.signal.fftconvolve returns), out [dev] float64 of that mode's size ([h+th-1,w+tw-1] | [h,w] | [h-th+1,w-tw+1]).
+ * Direct float64 evaluation; agrees with the reference's FFT route to its rounding.  Not on the hot path. */
+int vbs_normxcorr2_general(int device, const double* tmpl, int th, int tw, const double* image, int h, int w, int mode,
+                           double* out, void* stream);
 /* Live kernel timing: while enabled, every kernel launch of this handle is bracketed by a HIP event
  * pair on the launch stream.  vbs_profile(h, on) clears the records; vbs_profile_read synchronises
  * and writes one text line per kernel: "<name> <launches> <total_ms>". */
@@ -128,6 +134,10 @@ int vbs_profile_read(vbs_handle* h, char* buf, int cap);
  * cv2.findContours(RETR_EXTERNAL) ignores them, so this is 0 unless the fill pass ran out of capacity), 5 / 6: connected
  * components of the band / opened mask, 7: holes that were filled}] (synchronises). */
 int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n);
+/* Running totals over EVERY internal pass of the detection stage since the last reset (vbs_frame_stats only sees the
+ * last pass): out = {NCC pixels inside the ambiguity band of the 0.1 threshold (`:133`; 0 = every decision equals the
+ * float64 one), NCC pixels re-evaluated in float64, frames}.  Synchronises. */
+int vbs_ncc_counters(vbs_handle* h, uint64_t out[3], int reset);
 
 /* MarkerAnalysis._undistort_points (3d_reconstruction.py:185-193) and _calculate_3d_position
  * (:195-238) on float64 points, no handle needed: pts/out [dev] float64 [n,2]; uvd [dev] float64

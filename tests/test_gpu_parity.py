@@ -219,8 +219,39 @@ def test_normxcorr2_golden_from_reference_body(golden_dir):
     assert out.shape == ref.shape
     assert np.max(np.abs(out - ref)) < 1e-6
     assert np.array_equal(out > 0.1, ref > 0.1)
+
+
+def test_normxcorr2_general_operands(golden_dir):
+    """`_normxcorr2(template, image, mode)` for operands outside the pipeline's (`marker_detection.py:146-164`): other
+    template sizes (even and odd), a non-Gaussian template, a float image, all three modes - against the reference
+    body's goldens and against the oracle's literal FFT evaluation."""
+    from scipy.signal import fftconvolve
+    from vbs_amd.marker_detection import MarkerTracker
+    G = np.load(os.path.join(golden_dir, "stages.npz"))
+    img = G["ncc_image"]                                 # 64 x 72 uint8 {0, 255}
+    for l, sig in ((8, 2.0), (9, 2.0), (14, 3.0)):
+        out = MarkerTracker._normxcorr2(MarkerTracker._gkern(l, sig), img)
+        ref = G[f"ncc_out_l{l}"]
+        d = np.abs(out - ref)                            # (flat windows: 0 here, FFT noise / noise in the reference)
+        assert out.shape == ref.shape and d.max() < 1e-6 and np.median(d) < 1e-12
+        assert np.array_equal(out > 0.1, ref > 0.1)
+    rng = np.random.default_rng(4)
+    t = rng.normal(size=(7, 12))                         # arbitrary rectangular template
+    im = rng.normal(size=(40, 57)) * 3.0 + 1.0           # arbitrary float image
+    for mode in ("full", "same", "valid"):
+        with np.errstate(all="ignore"):
+            ref = O.normxcorr2(t, im, mode)
+        out = MarkerTracker._normxcorr2(t, im, mode)
+        assert out.shape == ref.shape and np.max(np.abs(out - ref)) < 1e-9, mode
     with pytest.raises(ValueError):
-        MarkerTracker._normxcorr2(MarkerTracker._gkern(9, 2.0), eng_img)
+        MarkerTracker._normxcorr2(t, im, "circular")
+    # a grey-valued uint8 image with the pipeline's template goes the general way too (not two-valued)
+    big = G["ncc_big_image"].copy()
+    big[10:20, 10:20] = 77
+    out = MarkerTracker._normxcorr2(MarkerTracker._gkern(33, 7.4), big)
+    with np.errstate(all="ignore"):
+        ref = O.normxcorr2(O.gkern(33, 7.4), big)
+    assert np.max(np.abs(out - ref)) < 1e-6 and np.median(np.abs(out - ref)) < 1e-12
 
 
 # ------------------------------------------------------------------------------------------------
@@ -782,15 +813,12 @@ def test_capacity_frame_inside_a_batch_is_reported(tmp_path):
     from vbs_amd.pipeline import track_shard
     spec = S.config2()
     frames = S.make_frames(spec, range(4), seed=2)
-    yy, xx = np.indices(frames.shape[1:])
-    # 4-px checker of 190 / 40 blocks: thousands of small blobs, far beyond max_markers components
-    frames[2] = np.where(((yy // 6) + (xx // 6)) % 2 == 0, 190, 40).astype(np.uint8)
-    eng = engine(spec.height, spec.width, max_markers=256, max_batch=4)
+    # 33 x 33 dots of 14 px at pitch 30: 928 contours in the opened area mask, beyond the 512 the workspace holds
+    frames[2] = S.make_frames(S.grid_spec(spec.width, spec.height, 33, 30, 14, name="dense"), [1], seed=0)[0]
+    eng = engine(spec.height, spec.width, max_markers=1024, max_batch=4)
     ft = torch.from_numpy(frames).cuda()
     _, _, counts = eng.track_to_3d(ft, np.array([[100.0, 100.0]]))
     c = counts.cpu().numpy()
-    if c[2] >= 0:
-        pytest.skip("the crafted frame did not exceed the capacity")
     assert c[2] == L.VBS_ECAPACITY and (c[[0, 1, 3]] == spec.n_markers).all()
     with pytest.raises(L.VbsError, match="frame 2"):
         track_shard(eng, ft, 4, cam=None)
@@ -799,4 +827,47 @@ def test_capacity_frame_inside_a_batch_is_reported(tmp_path):
                          "crop_ratios": (0, 0, 0, 0), "id_mode": "full"})
     with pytest.raises(L.VbsError, match="frame 2"):
         trk.process()
+    eng.close()
+
+
+def test_track_shard_two_ranks_on_one_gpu(tmp_path):
+    """e (config 4's path at small scale): two ranks as fresh child processes sharing GPU 0 (gloo), contiguous shards of
+    12 config-2 frames, reference-table broadcast, all-gather of the tables, per-rank last-seen displacement with a
+    look-back across the shard edge - everything equal to the single-rank result."""
+    import socket
+    import subprocess
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "helpers"))
+    import shard_worker as SW
+    from vbs_amd.pipeline import track_shard
+    n_total = 12
+    spec, frames = SW.make_clip(n_total)
+    K, dist, R, T = S.default_camera(spec)
+    cam = L.make_camera(K, dist, R, T, 2.0)
+    eng = engine(spec.height, spec.width, max_batch=4)
+    one = track_shard(eng, torch.from_numpy(frames).cuda(), n_total, cam=cam, warmup_frames=0)
+    table1, disp1 = one.table.cpu().numpy(), one.disp.cpu().numpy()
+    assert (one.counts.cpu().numpy() == np.where(np.arange(n_total) == n_total // 2, spec.n_markers - 1, spec.n_markers)).all()
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    worker = os.path.join(os.path.dirname(__file__), "helpers", "shard_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(n_total), str(tmp_path)],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    for r in range(2):
+        z = np.load(tmp_path / f"rank{r}.npz")
+        a, b = int(z["span"][0]), int(z["span"][1])
+        assert (a, b) == ((0, 6), (6, 12))[r]
+        assert np.array_equal(z["ids"], one.ids) and np.array_equal(z["xy"], one.ref_xy)
+        assert np.array_equal(z["table"], table1)                      # the gathered table, bit for bit
+        assert np.array_equal(z["disp"], disp1[a:b], equal_nan=True)   # this rank's frames of the displacement
+        assert np.array_equal(z["plane"], one.plane.cpu().numpy()[a:b], equal_nan=True)
+    # the look-back did cross the edge: the painted-out marker is unseen in frame 6 and measured in frame 7 against frame 5
+    slot = int(np.nonzero((table1[6, :, 0].astype(int) & 1) == 0)[0][0])
+    assert disp1[7, slot, 0] == 1 and disp1[6, slot, 0] == 0
+    want = table1[7, slot, 6:9] - table1[5, slot, 6:9]
+    assert np.allclose(disp1[7, slot, 1:4], want, atol=2e-6)
     eng.close()

@@ -18,15 +18,18 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
+def build(force: bool = False, verbose: bool = False, extra_flags=(), suffix: str = "") -> str:
+    """`extra_flags` / `suffix`: a second library next to the product one, e.g. tools/ build `libvbs_dbg.so` with
+    -DVBS_DEBUG_KNOBS (phase-timing early exits read from the environment); the product library never has them."""
     hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "..", "..", "include", "vbs.h")]
+    lib = LIB.replace(".so", suffix + ".so")
     objs, jobs = [], []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", suffix + ".o"))
         objs.append(o)
         if force or _stale(o, [s] + hdrs):
-            jobs.append([HIPCC] + FLAGS + ["-c", s, "-o", o])
+            jobs.append([HIPCC] + FLAGS + list(extra_flags) + ["-c", s, "-o", o])
 
     def run(cmd):
         if verbose:
@@ -40,9 +43,9 @@ def build(force: bool = False, verbose: bool = False) -> str:
         for warn in ex.map(run, jobs):
             if verbose and warn:
                 print(warn, file=sys.stderr)
-    if force or jobs or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
-    return LIB
+    if force or jobs or _stale(lib, objs):
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+    return lib
 
 
 if __name__ == "__main__":

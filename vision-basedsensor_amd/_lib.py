@@ -15,7 +15,7 @@ SYMBOLS = ("vbs_create", "vbs_destroy", "vbs_last_error", "vbs_version", "vbs_co
            "vbs_gaussian_taps_q8", "vbs_ncc_template", "vbs_set_undistort", "vbs_undistort_frames", "vbs_find_markers", "vbs_ncc_map", "vbs_normxcorr2",
            "vbs_profile", "vbs_profile_read", "vbs_frame_stats", "vbs_undistort_points", "vbs_calculate_3d", "vbs_marker_center",
            "vbs_track", "vbs_solve3d", "vbs_track_to_3d", "vbs_displacement", "vbs_displacement_range", "vbs_displacement_f64",
-           "vbs_plane_fit", "vbs_assign_ids", "vbs_set_option", "vbs_bgr2gray")
+           "vbs_plane_fit", "vbs_assign_ids", "vbs_set_option", "vbs_bgr2gray", "vbs_ncc_counters", "vbs_normxcorr2_general")
 
 
 class Camera(C.Structure):
@@ -71,6 +71,8 @@ def lib():
         "vbs_assign_ids": (i32, [vp, vp, vp, i32, i32, vp, vp, i32, vp, vp]),
         "vbs_set_option": (i32, [vp, i32, i32]),
         "vbs_bgr2gray": (i32, [vp, vp, i32, i64, i64, vp, vp]),
+        "vbs_ncc_counters": (i32, [vp, vp, i32]),
+        "vbs_normxcorr2_general": (i32, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)            # AttributeError here = stale library

@@ -161,7 +161,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(area_first, B * max_markers); ALLOC(area_sums, B * max_markers * VBS_AREA_SUMS);
     ALLOC(ell, B * max_markers * 8); ALLOC(det64, B * max_markers * 6);
     ALLOC(cnt, B);
-    ALLOC(probe, B * max_markers * 4); ALLOC(slow_list, B + 1); ALLOC(slow_flag, B);
+    ALLOC(probe, B * max_markers * 4); ALLOC(slow_flag, B); ALLOC(ncc_tot, 4);
     ALLOC(lut, 256);
     ALLOC(blur_frags, frags.size() / 4);
     std::vector<u32> nfrags = ncc_mfma_fragments(h->ncc, bp.ncc_l);
@@ -191,6 +191,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
         bilinear_weights_i16(wt.data());
         HIPCHK(h, hipMemcpy(h->uwtab, wt.data(), 4096 * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    HIPCHK(h, hipMemset(h->ncc_tot, 0, 4 * sizeof(u64)));
     HIPCHK(h, hipDeviceSynchronize());
     return VBS_OK;
 }
@@ -214,6 +215,7 @@ static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, in
         launch_blur(h, h->gray, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
     }
     launch_ncc(h, nb, mask_u8, ncc_out, s);
+    launch_stat_accum(h, nb, s);
     return check_launch(h);
 }
 
@@ -298,6 +300,18 @@ extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
     return VBS_EINVAL;
 }
 
+extern "C" int vbs_normxcorr2_general(int device, const double* tmpl, int th, int tw, const double* image, int h, int w,
+                                      int mode, double* out, void* stream) {
+    if (!tmpl || !image || !out || th < 1 || tw < 1 || h < 1 || w < 1 || mode < 0 || mode > 2) return VBS_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return VBS_EHIP;
+    double* stats = nullptr;
+    if (hipMallocAsync((void**)&stats, 4 * sizeof(double), (hipStream_t)stream) != hipSuccess) return VBS_ENOMEM;
+    const int rc = launch_ncc_general(tmpl, th, tw, image, h, w, mode, out, stats, (hipStream_t)stream);
+    (void)hipFreeAsync(stats, (hipStream_t)stream);
+    if (rc != VBS_OK) return rc;
+    return hipGetLastError() == hipSuccess ? VBS_OK : VBS_EHIP;
+}
+
 extern "C" int vbs_profile(vbs_handle* h, int enable) {
     if (!h) return VBS_EINVAL;
     for (auto& r : h->recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -362,6 +376,15 @@ extern "C" int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n) {
     if (!h || !out || n < 0 || n > h->maxb) return VBS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipMemcpy(out, h->fstat, (size_t)n * 8 * sizeof(u32), hipMemcpyDeviceToHost));
+    return VBS_OK;
+}
+
+extern "C" int vbs_ncc_counters(vbs_handle* h, uint64_t out[3], int reset) {
+    if (!h || !out) return VBS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out, h->ncc_tot, 3 * sizeof(u64), hipMemcpyDeviceToHost));
+    if (reset) HIPCHK(h, hipMemset(h->ncc_tot, 0, 4 * sizeof(u64)));
     return VBS_OK;
 }
 

@@ -77,8 +77,8 @@ struct vbs_handle {
     double* det64;     // [maxb][maxm][6]
     int32_t* cnt;      // [maxb]
     unsigned short* probe;   // [maxb][maxm][4]  component ids of the 2x2 cell around every band centroid
+    u64* ncc_tot;      // [4]  running NCC decision counters (vbs_ncc_counters)
     u32* slow_flag;    // [maxb]  1 = the fast labelling path handed the frame on
-    u32* slow_list;    // [1 + maxb]  frames handed from the fast labelling path to the general kernels
     int gray_bits = 15;             // BGR2GRAY fixed-point coefficient set: 15 (OpenCV 4) | 14 (OpenCV <= 3.4.1)
     bool force_seq_match = false;   // vbs_set_option(VBS_OPT_FORCE_SEQ_MATCH)
     u8* lut;           // [256] contour vertex table
@@ -141,6 +141,9 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s);
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s);
+int launch_ncc_general(const double* T, int th, int tw, const double* I, int h, int w, int mode, double* out,
+                       double* stats, hipStream_t s);
+void launch_stat_accum(vbs_handle* h, int nb, hipStream_t s);
 void launch_displacement64(const double* table, int n, int m_ref, int warmup, double min_size, double max_disp,
                            double* disp, int* fmin_scratch, hipStream_t s);
 int setup_undistort(vbs_handle* h, const double* K9, const double* dist, int ndist, hipStream_t s);

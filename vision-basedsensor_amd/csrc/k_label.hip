@@ -442,6 +442,15 @@ __device__ __forceinline__ void link_rows(u32* parent, const RowState& cur, cons
     }
 }
 
+// component id of pixel (x, y) of the opened mask from the general path's tables, 0xFFFF when it is not foreground
+__device__ __forceinline__ u32 comp_at(const u64* __restrict__ bits, const u32* __restrict__ wbase,
+                                       const u32* __restrict__ node_comp, int H, int W, int WW, int x, int y) {
+    if (x < 0 || y < 0 || x >= W || y >= H) return 0xFFFFu;
+    const u64* row = bits + (int64_t)y * WW;
+    if (!((row[x >> 6] >> (x & 63)) & 1ull)) return 0xFFFFu;
+    return node_comp[node_of(row, wbase + (int64_t)y * WW, x >> 6, x & 63)];
+}
+
 // 4-deep register ring of step words: PF_INIT issues the loads of steps y0, y0+G, .., PF_NEXT hands out the step at
 // y and issues the one at y + 4 G, so a step never waits for a load it has just issued.  Lane (g, j) holds word j of
 // row y + g; rows >= ylim read as 0.
@@ -474,8 +483,8 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                                                 u32* __restrict__ band_first, u64* __restrict__ band_sums,
                                                 u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                 u32* __restrict__ fstat, const u8* __restrict__ lut_g,
-                                                const u32* __restrict__ slow_list,
-                                                int H, int W, int WW, int maxm, int stop, int mode) {
+                                                const u32* __restrict__ slow_flag, unsigned short* __restrict__ probe_all,
+                                                int nb, int all, int H, int W, int WW, int maxm, int stop) {
     __shared__ u32 parent[VBS_RUN_CAP];                // union-find parents; later [m=1] the moment accumulators
     __shared__ u64 bnd_w[16][64];                      // last row of every strip: words,
     __shared__ u32 bnd_base[16][64], bnd_cin[16][64];  //   first-node indices, entering nodes
@@ -485,12 +494,17 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     __shared__ u32 tmp[32];
     __shared__ u8 lut[256];
     __shared__ int euler4;                             // 4 x Euler number of the opened mask (bit quads)
-    // frames the fast path (k_ccl.hip) handed on: slow_list = {count, frame indices ...}; every exit of the body below
-    // is workgroup-uniform, so it is a `continue` of this loop
-    for (u32 li = blockIdx.x; li < slow_list[0]; li += gridDim.x) {
-    __syncthreads();                                    // the previous frame's readers of the tables are done
-    const int n = (int)slow_list[1 + li];
-    const int m = mode == 0 ? (int)blockIdx.y : (mode == 1 ? 2 : 1);   // 0 band (4-conn), 1 open (8-conn), 2 background of open
+    // Only the frames the fast path (k_ccl.hip) handed on (slow_flag; all of them when `all`): a workgroup takes such a
+    // frame through the four stages in turn - label the band mask, label the opened mask, fill its holes (if any),
+    // relabel it (if any was filled) - and then writes the probes k_finalize's polygon test reads.  Every exit of a
+    // stage's body is workgroup-uniform, so it is a `continue` of the stage loop.
+    for (int n = blockIdx.x; n < nb; n += gridDim.x) {
+    if (!all && !slow_flag[n]) continue;
+    for (int stage = 0; stage < 4; ++stage) {
+    __threadfence();                                    // the previous stage's global writes (holes, filled bits, tables)
+    __syncthreads();                                    // are visible; its readers of the LDS tables are done
+    const int mode = stage < 2 ? 0 : stage - 1;
+    const int m = stage == 0 ? 0 : (stage == 2 ? 2 : 1);    // 0 band (4-conn), 1 open (8-conn), 2 background of open
     const int tid = threadIdx.x, nthr = blockDim.x, lane = tid & 63, wave = tid >> 6;
     const int NW = H * WW;
     if (mode == 1 && fstat[n * 8 + 4] == 0) continue;    // no holes in this frame
@@ -817,32 +831,15 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
         for (u32 c = tid; c < ncomp * NMOM; c += nthr) as[(c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
         if (tid == 0) fstat[n * 8 + 4] = (u32)((int)ncomp - euler4 / 4);       // holes in the opened mask
     }
-    }                                                   // frames of the slow list
-}
-
-// component id of pixel (x, y) of the opened mask from the general path's tables, 0xFFFF when it is not foreground
-__device__ __forceinline__ u32 comp_at(const u64* __restrict__ bits, const u32* __restrict__ wbase,
-                                       const u32* __restrict__ node_comp, int H, int W, int WW, int x, int y) {
-    if (x < 0 || y < 0 || x >= W || y >= H) return 0xFFFFu;
-    const u64* row = bits + (int64_t)y * WW;
-    if (!((row[x >> 6] >> (x & 63)) & 1ull)) return 0xFFFFu;
-    return node_comp[node_of(row, wbase + (int64_t)y * WW, x >> 6, x & 63)];
-}
-
-// probes (component ids of the 2x2 pixel cell around every band centroid) for the frames of the slow list; the fast
-// path writes them itself
-__global__ __launch_bounds__(256) void k_probe_slow(const u32* __restrict__ slow_list, const u32* __restrict__ ncomp_all,
-                                                    const u64* __restrict__ band_sums, const u64* __restrict__ open_bits,
-                                                    const u32* __restrict__ wbase_all, const u32* __restrict__ node_comp_all,
-                                                    const u32* __restrict__ fstat, unsigned short* __restrict__ probe_all,
-                                                    int H, int W, int WW, int maxm) {
-    for (u32 li = blockIdx.x; li < slow_list[0]; li += gridDim.x) {
-        const int n = (int)slow_list[1 + li];
-        if ((int)fstat[n * 8 + 2] != 0) continue;
+    }                                                   // stages
+    // probes: component ids of the 2x2 pixel cell around every band centroid (the fast path writes them itself)
+    __threadfence();
+    __syncthreads();
+    if ((int)fstat[n * 8 + 2] == 0) {
         const int NW = H * WW;
-        const u64* bits = open_bits + (int64_t)n * NW;
-        const u32* wbase = wbase_all + ((int64_t)n * 2 + 1) * NW;
-        const u32* node_comp = node_comp_all + ((int64_t)n * 2 + 1) * VBS_RUN_CAP;
+        const u64* obits = open_bits + (int64_t)n * NW;
+        const u32* wb1 = wbase_all + ((int64_t)n * 2 + 1) * NW;
+        const u32* nc1 = node_comp_all + ((int64_t)n * 2 + 1) * VBS_RUN_CAP;
         const u64* bs = band_sums + (int64_t)n * maxm * 4;
         unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
         const u32 nband = ncomp_all[n * 2 + 0];
@@ -850,29 +847,24 @@ __global__ __launch_bounds__(256) void k_probe_slow(const u32* __restrict__ slow
             const double cn = (double)bs[i * 4 + 0];
             const float xf = (float)((double)bs[i * 4 + 1] / cn), yf = (float)((double)bs[i * 4 + 2] / cn);
             const int ix = (int)floorf(xf), iy = (int)floorf(yf);
-            pr[i * 4 + 0] = (unsigned short)comp_at(bits, wbase, node_comp, H, W, WW, ix, iy);
-            pr[i * 4 + 1] = (unsigned short)comp_at(bits, wbase, node_comp, H, W, WW, ix + 1, iy);
-            pr[i * 4 + 2] = (unsigned short)comp_at(bits, wbase, node_comp, H, W, WW, ix, iy + 1);
-            pr[i * 4 + 3] = (unsigned short)comp_at(bits, wbase, node_comp, H, W, WW, ix + 1, iy + 1);
+            pr[i * 4 + 0] = (unsigned short)comp_at(obits, wb1, nc1, H, W, WW, ix, iy);
+            pr[i * 4 + 1] = (unsigned short)comp_at(obits, wb1, nc1, H, W, WW, ix + 1, iy);
+            pr[i * 4 + 2] = (unsigned short)comp_at(obits, wb1, nc1, H, W, WW, ix, iy + 1);
+            pr[i * 4 + 3] = (unsigned short)comp_at(obits, wb1, nc1, H, W, WW, ix + 1, iy + 1);
         }
     }
+    }                                                   // frames
 }
 
-void launch_ccl(vbs_handle* h, int nb, hipStream_t s);
+bool launch_ccl(vbs_handle* h, int nb, hipStream_t s);   // false: geometry outside the fast path
 
-// a9-a13 labelling: the parallel fast path (k_ccl.hip), then the general kernels over the frames it handed on
-// (none on marker frames: their workgroups find an empty list and exit)
+// a9-a13 labelling: the parallel fast path (k_ccl.hip), then the general kernel over the frames it handed on (none on
+// marker frames: its workgroups find no flagged frame and exit)
 void launch_label(vbs_handle* h, int nb, hipStream_t s) {
-    const int stop = VBS_KNOB("VBS_LABEL_STOP");
-    launch_ccl(h, nb, s);
-    const int gs = nb < 64 ? nb : 64;
-    for (int mode = 0; mode < 3; ++mode)       // label; fill holes (frames that have any); relabel those frames
-        VBS_LAUNCH(h, s, mode == 0 ? "k_label" : (mode == 1 ? "k_label_fill" : "k_label_redo"), k_label,
-                   dim3(gs, mode == 0 ? 2 : 1), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase, h->node_pos,
-                   h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first, h->area_sums, h->fstat, h->lut,
-                   h->slow_list, h->H, h->W, h->WW, h->maxm, stop, mode);
-    VBS_LAUNCH(h, s, "k_probe_slow", k_probe_slow, dim3(gs), dim3(256), 0, s, h->slow_list, h->ncomp, h->band_sums,
-               h->open_bits, h->wbase, h->node_comp, h->fstat, h->probe, h->H, h->W, h->WW, h->maxm);
+    const int all = launch_ccl(h, nb, s) ? 0 : 1;
+    VBS_LAUNCH(h, s, "k_label", k_label, dim3(nb < 64 ? nb : 64), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
+               h->node_pos, h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first, h->area_sums, h->fstat,
+               h->lut, h->slow_flag, h->probe, nb, all, h->H, h->W, h->WW, h->maxm, VBS_KNOB("VBS_LABEL_STOP"));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -536,6 +536,83 @@ std::vector<u32> ncc_mfma_fragments(const NccConst& nc, int l) {
     return out;
 }
 
+// ---- _normxcorr2 for ARBITRARY operands (marker_detection.py:146-164) -------------------------------------------------
+// Any float64 template / image, mode 'full' | 'same' | 'valid', evaluated directly in the spatial domain in float64
+// (the reference goes through three FFT convolutions; the two agree to the FFT's rounding, ~1e-12 of the map's scale).
+// Not on the hot path: the pipeline's own operands (binary area_mask, Gaussian template) take k_ncc_mfma / k_ncc.
+//   stats[0] = mean(template), stats[1] = mean(image), stats[2] = sum((template - mean)^2)
+__global__ __launch_bounds__(1024) void k_nccg_stats(const double* __restrict__ T, int nt, const double* __restrict__ I, int ni,
+                                                     double* __restrict__ stats) {
+    __shared__ double part[1024];
+    const int tid = threadIdx.x;
+    auto block_sum = [&](double v) {                    // fixed order: the result does not depend on scheduling
+        part[tid] = v;
+        __syncthreads();
+        for (int s = 512; s > 0; s >>= 1) { if (tid < s) part[tid] += part[tid + s]; __syncthreads(); }
+        const double r = part[0];
+        __syncthreads();
+        return r;
+    };
+    double a = 0;
+    for (int i = tid; i < nt; i += 1024) a += T[i];
+    const double mt = block_sum(a) / (double)nt;
+    a = 0;
+    for (int i = tid; i < ni; i += 1024) a += I[i];
+    const double mi = block_sum(a) / (double)ni;
+    a = 0;
+    for (int i = tid; i < nt; i += 1024) { const double d = T[i] - mt; a += d * d; }
+    const double t2 = block_sum(a);
+    if (tid == 0) { stats[0] = mt; stats[1] = mi; stats[2] = t2; }
+}
+
+// block = 8 output rows x 64 output columns; for every template row the image rows under it are staged in LDS
+#define NCCG_MAXTW 256
+__global__ __launch_bounds__(512) void k_nccg(const double* __restrict__ T, int th, int tw, const double* __restrict__ I, int h,
+                                              int w, int oy, int ox, int oh, int ow, const double* __restrict__ stats,
+                                              double* __restrict__ out) {
+    __shared__ double rows[8][64 + NCCG_MAXTW];
+    __shared__ double trow[NCCG_MAXTW];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + tx, y = blockIdx.y * 8 + ty;
+    const double mt = stats[0], mi = stats[1], t2 = stats[2];
+    double s_it = 0, s_i = 0, s_ii = 0;
+    for (int u = 0; u < th; ++u) {
+        __syncthreads();
+        const int yy = y + oy + u;
+        for (int k = tx; k < 64 + tw - 1; k += 64) {
+            const int xx = blockIdx.x * 64 + ox + k;
+            rows[ty][k] = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? I[(int64_t)yy * w + xx] - mi : 0.0;   // zero padding AFTER
+        }                                                                                                  // the mean went
+        for (int k = threadIdx.x; k < tw; k += 512) trow[k] = T[(int64_t)u * tw + k] - mt;
+        __syncthreads();
+        for (int v = 0; v < tw; ++v) {
+            const double iv = rows[ty][tx + v];
+            s_it = __builtin_fma(iv, trow[v], s_it);
+            s_i += iv;
+            s_ii = __builtin_fma(iv, iv, s_ii);
+        }
+    }
+    if (x >= ow || y >= oh) return;
+    double var = s_ii - s_i * s_i / ((double)th * (double)tw);
+    if (var < 0.0) var = 0.0;
+    double r = s_it / sqrt(var * t2);
+    if (!isfinite(r)) r = 0.0;
+    out[(int64_t)y * ow + x] = r;
+}
+
+int launch_ncc_general(const double* T, int th, int tw, const double* I, int h, int w, int mode, double* out,
+                       double* stats, hipStream_t s) {
+    if (tw > NCCG_MAXTW) return VBS_EINVAL;
+    // scipy.signal.fftconvolve output window: 0 full, 1 same (size of the image, start (t - 1) // 2), 2 valid
+    const int sy = mode == 0 ? 0 : mode == 1 ? (th - 1) / 2 : th - 1, sx = mode == 0 ? 0 : mode == 1 ? (tw - 1) / 2 : tw - 1;
+    const int oh = mode == 0 ? h + th - 1 : mode == 1 ? h : h - th + 1, ow = mode == 0 ? w + tw - 1 : mode == 1 ? w : w - tw + 1;
+    if (oh < 1 || ow < 1) return VBS_EINVAL;
+    hipLaunchKernelGGL(k_nccg_stats, dim3(1), dim3(1024), 0, s, T, th * tw, I, h * w, stats);
+    hipLaunchKernelGGL(k_nccg, dim3((ow + 63) / 64, (oh + 7) / 8), dim3(512), 0, s, T, th, tw, I, h, w, sy - (th - 1),
+                       sx - (tw - 1), oh, ow, stats, out);
+    return VBS_OK;
+}
+
 // area popcount per frame (feeds the global mean of _normxcorr2 :153) when the bits did not come from k_blur_v
 __global__ __launch_bounds__(256) void k_popcount(const u64* __restrict__ bits, u32* __restrict__ fstat, int NW) {
     __shared__ u32 part[4];
@@ -546,6 +623,24 @@ __global__ __launch_bounds__(256) void k_popcount(const u64* __restrict__ bits, 
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
     __syncthreads();
     if (threadIdx.x == 0) fstat[n * 8 + 0] = part[0] + part[1] + part[2] + part[3];
+}
+
+// running totals over every internal pass since the last vbs_ncc_counters(reset): {pixels within the ambiguity band of
+// the 0.1 threshold, pixels re-evaluated in float64, frames}
+__global__ __launch_bounds__(256) void k_stat_accum(const u32* __restrict__ fstat, u64* __restrict__ tot, int nb) {
+    u64 a = 0, e = 0;
+    for (int n = blockIdx.x * 256 + threadIdx.x; n < nb; n += gridDim.x * 256) { a += fstat[n * 8 + 1]; e += fstat[n * 8 + 3]; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) { a += __shfl_xor(a, off); e += __shfl_xor(e, off); }
+    if ((threadIdx.x & 63) == 0) {
+        if (a) atomicAdd(&tot[0], a);
+        if (e) atomicAdd(&tot[1], e);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tot[2], (u64)nb);
+}
+
+void launch_stat_accum(vbs_handle* h, int nb, hipStream_t s) {
+    VBS_LAUNCH(h, s, "k_stat_accum", k_stat_accum, dim3(1), dim3(256), 0, s, h->fstat, h->ncc_tot, nb);
 }
 
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s) {

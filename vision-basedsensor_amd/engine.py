@@ -169,6 +169,13 @@ class Engine:
         self._check(self.lib.vbs_frame_stats(self._h, out.ctypes.data_as(C.c_void_p), n), "vbs_frame_stats")
         return out
 
+    def ncc_counters(self, reset=False):
+        """{ambiguous, exact, frames} over every detection pass since the last reset (`vbs_ncc_counters`)."""
+        out = np.zeros(3, dtype=np.uint64)
+        self._check(self.lib.vbs_ncc_counters(self._h, out.ctypes.data_as(C.c_void_p), 1 if reset else 0),
+                    "vbs_ncc_counters")
+        return {"ambiguous": int(out[0]), "exact": int(out[1]), "frames": int(out[2])}
+
     # ---- a9-a13 ------------------------------------------------------------------------------
     def marker_center(self, mask, area_mask):
         for t in (mask, area_mask):
@@ -298,6 +305,32 @@ def undistort_points(points, cam: L.Camera, device=None):
                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != L.VBS_OK:
         raise L.VbsError(f"vbs_undistort_points failed ({rc})")
+    return out
+
+
+def normxcorr2_general(template, image, mode="same", device=None):
+    """`_normxcorr2` for arbitrary operands: float64 map of the mode's size on the GPU (`vbs_normxcorr2_general`)."""
+    if not torch.cuda.is_available():
+        raise L.VbsError("no GPU visible: vbs_amd has no CPU path")
+    modes = {"full": 0, "same": 1, "valid": 2}
+    if mode not in modes:
+        raise ValueError("acceptable mode flags are 'valid', 'same', or 'full'")        # scipy's message
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else device)
+    t = torch.as_tensor(np.asarray(template, dtype=np.float64), device=dev).contiguous()
+    im = torch.as_tensor(np.asarray(image, dtype=np.float64), device=dev).contiguous()
+    if t.dim() != 2 or im.dim() != 2:
+        raise ValueError("template and image must be 2-D")
+    (th, tw), (h, w) = t.shape, im.shape
+    if tw > 256:
+        raise NotImplementedError("vbs_normxcorr2_general holds template rows of at most 256 samples")
+    oh, ow = {0: (h + th - 1, w + tw - 1), 1: (h, w), 2: (h - th + 1, w - tw + 1)}[modes[mode]]
+    if oh < 1 or ow < 1:
+        raise ValueError("For 'valid' mode, one must be at least as large as the other in every dimension")
+    out = torch.empty((oh, ow), dtype=torch.float64, device=dev)
+    rc = L.lib().vbs_normxcorr2_general(dev.index, _ptr(t), th, tw, _ptr(im), h, w, modes[mode], _ptr(out),
+                                        C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != L.VBS_OK:
+        raise L.VbsError(f"vbs_normxcorr2_general failed ({rc})")
     return out
 
 

@@ -196,20 +196,26 @@ class MarkerTracker:
 
     @staticmethod
     def _normxcorr2(template, image, mode="same"):
-        """`:146-164` for the operands the pipeline uses: `image` a two-valued uint8 area_mask and
-        `template` the `_gkern` of that image size's branch (80/13 above 480 rows, 33/7.4 otherwise)."""
+        """`:146-164`.  The operands the pipeline uses (`image` a uint8 area_mask with values in {0, 255}, `template` the
+        `_gkern` of that image size's branch, mode 'same') run on the hot path's NCC kernel; any other template / image /
+        mode is evaluated by the general float64 kernel (`vbs_normxcorr2_general`)."""
         image = np.asarray(image)
         template = np.asarray(template)
-        small = image.shape[0] <= 480
-        l, sig = (33, 7.4) if small else (80, 13.0)
-        if mode != "same" or template.shape != (l, l) or \
-                not np.allclose(template, MarkerTracker._gkern(l, sig), rtol=1e-12, atol=0):
-            raise ValueError("the GPU _normxcorr2 supports mode='same' with the pipeline's template "
-                             f"_gkern({l}, {sig}) for this image height")
-        if image.dtype != np.uint8:
-            raise ValueError("image must be the uint8 area_mask")
-        eng = _engine(image.shape[0], image.shape[1])
-        return eng.normxcorr2(_to_device(image[None], eng))[0].cpu().numpy()
+        if np.ndim(template) > np.ndim(image) or any(t > i for t, i in zip(template.shape, image.shape)):
+            print("Warning: Template larger than image. Arguments may be swapped.")          # `:147-149`
+        if image.ndim == 2 and image.dtype == np.uint8 and mode == "same" and image.shape[0] >= 64 \
+                and 128 <= image.shape[1] <= 4096:
+            l, sig = (33, 7.4) if image.shape[0] <= 480 else (80, 13.0)
+            if template.shape == (l, l) and not np.any((image != 0) & (image != 255)) and \
+                    np.allclose(template, MarkerTracker._gkern(l, sig), rtol=1e-12, atol=0):
+                eng = _engine(image.shape[0], image.shape[1])
+                return eng.normxcorr2(_to_device(image[None], eng))[0].cpu().numpy()
+        return MarkerTracker._normxcorr2_general(template, image, mode)
+
+    @staticmethod
+    def _normxcorr2_general(template, image, mode="same"):
+        from .engine import normxcorr2_general
+        return normxcorr2_general(template, image, mode).cpu().numpy()
 
     @staticmethod
     def _marker_center(mask, area_mask, frame=None):
