@@ -17,10 +17,12 @@
 //   C  flatten; roots ranked in raster order = ndimage.label's numbering (reversed: cv2's contour order); the parent
 //      table becomes the component id of every node (bit 15 marks the root = the component's first run)
 //   D  band: pixel count / sum x / sum y per component (center_of_mass :181)
-//      open: bounding boxes; contour-vertex moments about the component's first pixel (see k_label.hip) by ONE WAVE PER
-//            COMPONENT (lane = row of its box, wave reduction, no atomics); bit-quad Euler number (holes); and for every
-//            band centroid the component ids of the 2x2 pixel cell around it ("probes"): k_finalize's
-//            pointPolygonTest needs nothing else, so no label image or run table goes to HBM.
+//      open: contour-vertex moments about the component's first pixel (see k_label.hip), LDS atomics; bit-quad Euler
+//            number (holes); and for every band centroid the component ids of the 2x2 pixel cell around it ("probes"):
+//            k_finalize's pointPolygonTest needs nothing else, so no label image or run table goes to HBM.
+//      The accumulating walks of D visit the chunks in an order that puts rows 64 apart on neighbouring lanes: in
+//      raster order 16 lanes of a wave sit on one marker and their atomics serialise on one address (measured: the
+//      moment pass 0.33 -> see profiles/README.md).
 // LDS is laid out per handle (ccl_layout): <= 80 KB and <= 64 VGPRs put two workgroups (32 waves) on a CU at
 // 1280x1024; larger frames take up to the whole 160 KB (one workgroup per CU).  Frames outside the fast path's limits
 // (more runs than the node table holds - at most 32767 -, more than 512 contours, holes in the opened mask) set their
@@ -29,6 +31,7 @@
 
 #define CCL_NT 1024
 #define CCL_NODE_MAX 32767         // node indices are 15-bit (bit 15 of a resolved entry marks the root)
+#define CCL_MOM_COMPS 256          // components per moment pass (15 x 8 B x 256 = 30 KB of accumulators)
 #define CCL_OPEN_COMPS 512         // contour components (k_finalize's limit)
 #define NMOM 15
 #define NONE16 0xFFFFu
@@ -111,13 +114,15 @@ __device__ __forceinline__ u64 ccl_starts(u64 B, u32 p) { return B & ~((B << 1) 
 // runs of A it touches, above-right diagonal, the run to its left.
 //   PASS 0: the parent of every run that STARTS in this word = its first link (itself if it has none)
 //   PASS 1: every other link (all links of a segment that continues a run from the previous word) -> ccl_union
+//   PASS 0 returns true when the word has such links (pass 1 skips the chunks that have none)
 template <int M8, int PASS>
-__device__ __forceinline__ void ccl_link_word(unsigned short* P, u64 B, u64 A, u32 pB, u32 pA, u32 aL, u32 aR,
+__device__ __forceinline__ bool ccl_link_word(unsigned short* P, u64 B, u64 A, u32 pB, u32 pA, u32 aL, u32 aR,
                                               bool aR_same, bool left, u32 bc, u32 ba) {
     u64 adj = A;
     if (M8) adj |= (A << 1) | (A >> 1) | (u64)aL | ((u64)aR << 63);
     const u64 stB = ccl_starts(B, pB);
-    if (PASS == 1 && !(B & adj) && !left) return;
+    if (PASS == 1 && !(B & adj) && !left) return false;
+    bool extra = false;
     const u64 stA = ccl_starts(A, pA);
     u64 mB = B;
     while (mB) {
@@ -133,7 +138,7 @@ __device__ __forceinline__ void ccl_link_word(unsigned short* P, u64 B, u64 A, u
             u64 rm = g;
             if (M8) rm |= (g << 1) | (g >> 1);
             if (M8 && (g & 1ull) && aL) {
-                if (!have) { par = ba - 1u; have = true; } else if (PASS == 1) ccl_union(P, node, ba - 1u);
+                if (!have) { par = ba - 1u; have = true; } else if (PASS == 1) ccl_union(P, node, ba - 1u); else extra = true;
             }
             u64 mA = A & rm;
             while (mA) {                                // the runs of A under it
@@ -141,41 +146,26 @@ __device__ __forceinline__ void ccl_link_word(unsigned short* P, u64 B, u64 A, u
                 const u64 t2 = mA + lb;
                 mA &= t2;
                 const u32 na = ba + (u32)__popcll(stA & ((lb << 1) - 1ull)) - 1u;
-                if (!have) { par = na; have = true; if (PASS == 0) break; } else if (PASS == 1) ccl_union(P, node, na);
+                if (!have) { par = na; have = true; } else if (PASS == 1) ccl_union(P, node, na); else { extra = true; break; }
             }
             if (M8 && (g >> 63) && aR) {
                 const u32 na = ba + (u32)__popcll(stA) - (((A >> 63) && aR_same) ? 1u : 0u);
-                if (!have) { par = na; have = true; } else if (PASS == 1) ccl_union(P, node, na);
+                if (!have) { par = na; have = true; } else if (PASS == 1) ccl_union(P, node, na); else extra = true;
             }
         }
         if (left && (g & 1ull)) {                       // (only the chunk's first word passes left = true)
-            if (!have) { par = node - 1u; have = true; } else if (PASS == 1) ccl_union(P, node, node - 1u);
+            if (!have) { par = node - 1u; have = true; } else if (PASS == 1) ccl_union(P, node, node - 1u); else extra = true;
         }
         if (PASS == 0 && starts) P[node] = (unsigned short)par;
     }
-}
-
-// sum over the 64 lanes, valid in lane 63 (DPP row shifts + row broadcasts, no LDS)
-__device__ __forceinline__ i64 ccl_wave_sum(i64 x) {
-#define CCL_DPP_STEP(ctrl, rmask)                                                                                         \
-    {                                                                                                                     \
-        const u32 lo_ = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)x, ctrl, rmask, 0xf, false);                        \
-        const u32 hi_ = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)((u64)x >> 32), ctrl, rmask, 0xf, false);           \
-        x += (i64)(((u64)hi_ << 32) | lo_);                                                                               \
-    }
-    CCL_DPP_STEP(0x111, 0xf)                              // row_shr:1
-    CCL_DPP_STEP(0x112, 0xf)                              // row_shr:2
-    CCL_DPP_STEP(0x114, 0xf)                              // row_shr:4
-    CCL_DPP_STEP(0x118, 0xf)                              // row_shr:8
-    CCL_DPP_STEP(0x142, 0xa)                              // row_bcast:15 -> rows 1, 3
-    CCL_DPP_STEP(0x143, 0xc)                              // row_bcast:31 -> rows 2, 3
-#undef CCL_DPP_STEP
-    return x;
+    return extra;
 }
 
 struct CclGeom {
     int H, W, WW, CW, NC, items;
     u32 inv_nc;                                          // ceil(2^32 / NC): item / NC = umulhi(item, inv_nc); 0 when NC = 1
+    int R, vitems;                                       // spread order (CCL_ITEM_DECODE_SPREAD): R = ceil(H / 64) row groups
+    u32 inv_r;
     u32 node_cap;                                        // entries of the parent table
     u32 off_cbase, off_acc, off_tmp;                     // byte offsets into the dynamic LDS
     int stop;                                            // debug builds: leave after phase `stop` (0 = run everything)
@@ -199,6 +189,14 @@ __device__ __forceinline__ u32 ccl_pixel_cid(const u64* __restrict__ bits, const
 #define CCL_ITEM_DECODE                                                                            \
     const int y = geo.inv_nc ? (int)__umulhi((u32)it, geo.inv_nc) : it, c = it - y * NC;           \
     const int j0 = c * CW, j1 = min(j0 + CW, WW);
+// The same chunks in an order that puts rows 64 apart on neighbouring lanes: the lanes of a wave then work on
+// different components (a marker is < 64 rows tall), so their LDS atomics on per-component accumulators do not
+// collide on one address (raster order puts 16 rows of one marker in a wave: 16-way serialised atomics).
+#define CCL_ITEM_DECODE_SPREAD                                                                     \
+    const int yv = geo.inv_nc ? (int)__umulhi((u32)vt, geo.inv_nc) : vt, c = vt - yv * NC;         \
+    const int grp = geo.inv_r ? (int)__umulhi((u32)yv, geo.inv_r) : yv, y = (yv - grp * geo.R) * 64 + grp; \
+    if (y >= H) continue;                                                                          \
+    const int it = y * NC + c, j0 = c * CW, j1 = min(j0 + CW, WW);
 
 template <int MODE>                                      // 0: band mask, 4-connectivity; 1: opened mask, 8-connectivity
 __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_all, u32* __restrict__ ncomp_all,
@@ -209,7 +207,7 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned short* P = reinterpret_cast<unsigned short*>(smem);                         // [node_cap]
     unsigned short* cbase = reinterpret_cast<unsigned short*>(smem + geo.off_cbase);     // [items + 1]
-    unsigned char* accb = smem + geo.off_acc;                                            // band sums | open boxes
+    unsigned char* accb = smem + geo.off_acc;                                            // band sums | open moments + anchors
     u32* tmp = reinterpret_cast<u32*>(smem + geo.off_tmp);                               // [32]
     int* misc = reinterpret_cast<int*>(tmp + 32);                                        // [4]
     u8* lut = reinterpret_cast<u8*>(misc + 4);                                           // [256] (open)
@@ -249,11 +247,16 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
     if (geo.stop == 2) return;
 
     // ---- B: parents, pointer jumping, the remaining links --------------------------------------------------------
+    u64 extra_mask = 0;                                  // bit k: this thread's k-th chunk has links left for pass 1
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
+        int kk = -1;
         for (int it = tid; it < items; it += CCL_NT) {
+            ++kk;
             u32 bc = cbase[it];
             if (cbase[it + 1] == bc) continue;           // no run starts in this chunk (and none enters: cut at chunks)
+            if (pass == 1 && kk < 64 && !((extra_mask >> kk) & 1ull)) continue;
+            bool extra = false;
             CCL_ITEM_DECODE
             const u64* row = bits + (int64_t)y * WW;
             const u64* up = row - WW;
@@ -267,7 +270,7 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
                 const u64 B = row[j];
                 const u64 An = (hasu && j + 1 < WW) ? up[j + 1] : 0ull;
                 if (B) {
-                    if (pass == 0) ccl_link_word<MODE, 0>(P, B, A, pB, pA, aL, (u32)(An & 1ull), j + 1 < j1, left, bc, ba);
+                    if (pass == 0) extra |= ccl_link_word<MODE, 0>(P, B, A, pB, pA, aL, (u32)(An & 1ull), j + 1 < j1, left, bc, ba);
                     else ccl_link_word<MODE, 1>(P, B, A, pB, pA, aL, (u32)(An & 1ull), j + 1 < j1, left, bc, ba);
                 }
                 left = false;
@@ -277,6 +280,7 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
                 pA = aL = (u32)(A >> 63);
                 A = An;
             }
+            if (pass == 0 && (extra || kk >= 64)) extra_mask |= 1ull << (kk & 63);
         }
         __syncthreads();
         if (pass == 0) {
@@ -334,10 +338,10 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
         u64* asy = asx + maxm;                                                           // [maxm]
         for (u32 c = tid; c < ncomp; c += CCL_NT) { acnt[c] = 0; asx[c] = 0; asy[c] = 0; }
         __syncthreads();
-        for (int it = tid; it < items; it += CCL_NT) {
+        for (int vt = tid; vt < geo.vitems; vt += CCL_NT) {
+            CCL_ITEM_DECODE_SPREAD
             u32 bc = cbase[it];
             if (cbase[it + 1] == bc) continue;
-            CCL_ITEM_DECODE
             const u64* row = bits + (int64_t)y * WW;
             u32 ccid = NONE16, cnt = 0, sx = 0, pB = 0;
             for (int j = j0; j < j1; ++j) {
@@ -370,40 +374,30 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
         return;
     }
 
-    // ---- D (open) 0: per component: first pixel (= start of its root run, the moments' origin) and bounding box ----
-    u32* anchor = reinterpret_cast<u32*>(accb);          // [CCL_OPEN_COMPS] y * W + x of the first pixel
-    u32* bymax = anchor + CCL_OPEN_COMPS;                // last row
-    u32* bxmin = bymax + CCL_OPEN_COMPS;                 // first / last column
-    u32* bxmax = bxmin + CCL_OPEN_COMPS;
-    for (u32 c = tid; c < ncomp; c += CCL_NT) { bymax[c] = 0; bxmin[c] = 0xFFFFFFFFu; bxmax[c] = 0; }
+    // ---- D (open) 0: the component's first pixel = start of its root run (the moments' origin) ---------------------
+    u32* anchor = reinterpret_cast<u32*>(accb + CCL_MOM_COMPS * NMOM * 8);               // [CCL_OPEN_COMPS]
     __syncthreads();
     for (int it = tid; it < items; it += CCL_NT) {
         u32 bc = cbase[it];
         if (cbase[it + 1] == bc) continue;
         CCL_ITEM_DECODE
         const u64* row = bits + (int64_t)y * WW;
-        u32 pB = 0, ccid = NONE16, lo = 0, hi = 0;
+        u32 pB = 0;
         for (int j = j0; j < j1; ++j) {
-            const u64 B = row[j], stB = ccl_starts(B, pB);
-            u64 mB = B;
-            while (mB) {
-                const u64 lowbit = mB & (~mB + 1ull);
-                const u64 t = mB + lowbit;
-                const u64 g = mB & ~t;
-                mB &= t;
-                const u32 v = P[bc + (u32)__popcll(stB & ((lowbit << 1) - 1ull)) - 1u], cid = v & 0x7FFFu;
-                const u32 x0 = 64u * j + (u32)(__ffsll((long long)g) - 1), x1 = 64u * j + 63u - (u32)__clzll(g);
-                if ((v & 0x8000u) && (stB & lowbit)) { anchor[cid] = (u32)y * (u32)W + x0; first[cid] = (u32)y * (u32)W + x0; }
-                if (cid != ccid) {
-                    if (ccid != NONE16) { atomicMin(&bxmin[ccid], lo); atomicMax(&bxmax[ccid], hi); atomicMax(&bymax[ccid], (u32)y); }
-                    ccid = cid; lo = x0;
+            const u64 B = row[j];
+            u64 st = ccl_starts(B, pB);
+            while (st) {                                 // one new node per start bit, in order
+                const int k = __ffsll((long long)st) - 1;
+                st &= st - 1;
+                const u32 v = P[bc++];
+                if (v & 0x8000u) {
+                    const u32 pos = (u32)y * (u32)W + 64u * j + (u32)k;
+                    anchor[v & 0x7FFFu] = pos;
+                    first[v & 0x7FFFu] = pos;
                 }
-                hi = x1;
             }
-            bc += (u32)__popcll(stB);
             pB = (u32)(B >> 63);
         }
-        if (ccid != NONE16) { atomicMin(&bxmin[ccid], lo); atomicMax(&bxmax[ccid], hi); atomicMax(&bymax[ccid], (u32)y); }
     }
     // Euler number by bit quads (see k_label.hip): holes = components - E
     {
@@ -442,95 +436,107 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
     }
     if (geo.stop == 5) return;
 
-    // ---- D (open) 1: contour-vertex moments: one wave per component, lane = row of its bounding box -----------------
-    // A row contributes X_a = sum mult * dx^a (a = 0..4) over its vertices, dy is the row's own, so the 15 moments of
-    // the row are X_a * dy^b; they are summed over the wave by DPP and leave through lane 63 - no atomics.
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-        i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
-        for (u32 c = wave; c < ncomp; c += CCL_NT / 64) {
-            const u32 fp = anchor[c];
-            const int ay = (int)(fp / (u32)W), ax = (int)(fp - (u32)ay * (u32)W);
-            const int y1 = (int)bymax[c], jw0 = (int)(bxmin[c] >> 6), jw1 = (int)(bxmax[c] >> 6);
-            for (int yb = ay; yb <= y1; yb += 64) {
-                const int y = yb + lane;
-                i64 X0 = 0, X1 = 0, X2 = 0, X3 = 0, X4 = 0;
-                if (y <= y1) {
-                    const u64* rowm = bits + (int64_t)y * WW;
-                    const bool hasu = y > 0, hasd = y + 1 < H;
-                    for (int j = jw0; j <= jw1; ++j) {
-                        const u64 B = rowm[j];
-                        if (!B) continue;
-                        const int cc = j / CW, cj0 = cc * CW;
-                        u32 bcw = cbase[y * NC + cc], pB = 0;
-                        for (int jj = cj0; jj < j; ++jj) { const u64 ww = rowm[jj]; bcw += (u32)__popcll(ccl_starts(ww, pB)); pB = (u32)(ww >> 63); }
-                        const u64 stB = ccl_starts(B, pB);
-                        const u64 up = hasu ? rowm[j - WW] : 0ull, dn = hasd ? rowm[j + WW] : 0ull;
-                        u64 bl = 0, br = 0, upL = 0, upR = 0, dnL = 0, dnR = 0;
-                        if ((B & 1ull) && j > 0) {
-                            bl = rowm[j - 1] >> 63;
-                            upL = hasu ? rowm[j - 1 - WW] >> 63 : 0ull; dnL = hasd ? rowm[j - 1 + WW] >> 63 : 0ull;
-                        }
-                        if ((B >> 63) && j + 1 < WW) {
-                            br = rowm[j + 1] & 1ull;
-                            upR = hasu ? rowm[j + 1 - WW] & 1ull : 0ull; dnR = hasd ? rowm[j + 1 + WW] & 1ull : 0ull;
-                        }
-                        const u64 NE = (up >> 1) | (upR << 63), NWd = (up << 1) | upL;
-                        const u64 SE = (dn >> 1) | (dnR << 63), SW = (dn << 1) | dnL;
-                        const u64 E = (B >> 1) | (br << 63), Wd = (B << 1) | bl;
-                        // border pixels that can be contour vertices: not 4-interior, not inside a straight horizontal
-                        // edge (patterns 241 / 31 of the vertex table: multiplicity 0)
-                        u64 bgw = B & ~(up & dn & E & Wd);
-                        bgw &= ~(E & Wd & ((~up & ~NE & ~NWd & dn & SE & SW) | (up & NE & NWd & ~dn & ~SE & ~SW)));
-                        u64 mB = B;
-                        while (mB) {
-                            const u64 lowbit = mB & (~mB + 1ull);
-                            const u64 t = mB + lowbit;
-                            const u64 g = mB & ~t;
-                            mB &= t;
-                            u64 bg = bgw & g;
-                            if (!bg) continue;
-                            if ((P[bcw + (u32)__popcll(stB & ((lowbit << 1) - 1ull)) - 1u] & 0x7FFFu) != c) continue;
-                            while (bg) {
-                                const int k = __ffsll((long long)bg) - 1;
-                                bg &= bg - 1;
-                                const u32 pat = (u32)((E >> k) & 1ull) | ((u32)((NE >> k) & 1ull) << 1) |
-                                                ((u32)((up >> k) & 1ull) << 2) | ((u32)((NWd >> k) & 1ull) << 3) |
-                                                ((u32)((Wd >> k) & 1ull) << 4) | ((u32)((SW >> k) & 1ull) << 5) |
-                                                ((u32)((dn >> k) & 1ull) << 6) | ((u32)((SE >> k) & 1ull) << 7);
-                                const int mult = lut[pat];
-                                if (!mult) continue;
-                                const int dx = 64 * j + k - ax;
-                                X0 += mult;
-                                if (abs(dx) <= 150) {    // 4 * 150^4 < 2^31: products in 32 bits
-                                    const int x2 = dx * dx, mx = mult * dx;
-                                    X1 += mx; X2 += mx * dx; X3 += mx * x2; X4 += mult * x2 * x2;
-                                } else {
-                                    const i64 dl = dx, x2 = dl * dl, ml = mult;
-                                    X1 += ml * dl; X2 += ml * x2; X3 += ml * x2 * dl; X4 += ml * x2 * x2;
-                                }
+    // ---- D (open) 1: contour-vertex moments, CCL_MOM_COMPS components per pass, LDS atomics in the spread order ----
+    u64* acc = reinterpret_cast<u64*>(accb);
+    i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
+    for (u32 c0 = 0; c0 < ncomp; c0 += CCL_MOM_COMPS) {
+        const u32 nc = min((u32)CCL_MOM_COMPS, ncomp - c0);
+        for (u32 c = tid; c < nc * NMOM; c += CCL_NT) acc[c] = 0;
+        __syncthreads();
+        for (int vt = tid; vt < geo.vitems; vt += CCL_NT) {
+            CCL_ITEM_DECODE_SPREAD
+            u32 bc = cbase[it];
+            if (cbase[it + 1] == bc) continue;
+            const u64* rowm = bits + (int64_t)y * WW;
+            const bool hasu = y > 0, hasd = y + 1 < H;
+            u32 pB = 0;
+            for (int j = j0; j < j1; ++j) {
+                const u64 B = rowm[j];
+                const u64 stB = ccl_starts(B, pB);
+                const u32 bcw = bc;
+                bc += (u32)__popcll(stB);
+                pB = (u32)(B >> 63);
+                if (!B) continue;
+                const u64 up = hasu ? rowm[j - WW] : 0ull, dn = hasd ? rowm[j + WW] : 0ull;
+                u64 bl = 0, br = 0, upL = 0, upR = 0, dnL = 0, dnR = 0;
+                if ((B & 1ull) && j > 0) {
+                    bl = rowm[j - 1] >> 63;
+                    upL = hasu ? rowm[j - 1 - WW] >> 63 : 0ull; dnL = hasd ? rowm[j - 1 + WW] >> 63 : 0ull;
+                }
+                if ((B >> 63) && j + 1 < WW) {
+                    br = rowm[j + 1] & 1ull;
+                    upR = hasu ? rowm[j + 1 - WW] & 1ull : 0ull; dnR = hasd ? rowm[j + 1 + WW] & 1ull : 0ull;
+                }
+                const u64 NE = (up >> 1) | (upR << 63), NWd = (up << 1) | upL;
+                const u64 SE = (dn >> 1) | (dnR << 63), SW = (dn << 1) | dnL;
+                const u64 E = (B >> 1) | (br << 63), Wd = (B << 1) | bl;
+                // border pixels that can be contour vertices: not 4-interior, not inside a straight horizontal edge
+                // (patterns 241 / 31 of the vertex table: multiplicity 0)
+                u64 bgw = B & ~(up & dn & E & Wd);
+                bgw &= ~(E & Wd & ((~up & ~NE & ~NWd & dn & SE & SW) | (up & NE & NWd & ~dn & ~SE & ~SW)));
+                u64 mB = B;
+                while (mB) {
+                    const u64 lowbit = mB & (~mB + 1ull);
+                    const u64 t = mB + lowbit;
+                    const u64 g = mB & ~t;
+                    mB &= t;
+                    u64 bg = bgw & g;
+                    if (!bg) continue;
+                    const u32 cid = (P[bcw + (u32)__popcll(stB & ((lowbit << 1) - 1ull)) - 1u] & 0x7FFFu) - c0;
+                    if (cid >= nc) continue;
+                    const u32 fp = anchor[cid + c0];
+                    const int ay = (int)(fp / (u32)W), ax = (int)(fp - (u32)ay * (u32)W);
+                    u64* a = acc + cid * NMOM;
+                    while (bg) {
+                        const int k = __ffsll((long long)bg) - 1;
+                        bg &= bg - 1;
+                        const u32 pat = (u32)((E >> k) & 1ull) | ((u32)((NE >> k) & 1ull) << 1) |
+                                        ((u32)((up >> k) & 1ull) << 2) | ((u32)((NWd >> k) & 1ull) << 3) |
+                                        ((u32)((Wd >> k) & 1ull) << 4) | ((u32)((SW >> k) & 1ull) << 5) |
+                                        ((u32)((dn >> k) & 1ull) << 6) | ((u32)((SE >> k) & 1ull) << 7);
+                        const int mult = lut[pat];
+                        if (!mult) continue;
+                        const int dx = 64 * j + k - ax, dy = y - ay;
+                        atomicAdd(&a[0], (u64)mult);
+                        if (max(abs(dx), abs(dy)) <= 150) {          // 4 * 150^4 < 2^31: products in 32 bits
+                            const int x2 = dx * dx, y2 = dy * dy, mx = mult * dx, my = mult * dy;
+                            if (dx) {
+                                atomicAdd(&a[1], (u64)(i64)mx);
+                                atomicAdd(&a[3], (u64)(i64)(mx * dx));
+                                atomicAdd(&a[6], (u64)(i64)(mx * x2));
+                                atomicAdd(&a[10], (u64)(i64)(mult * x2 * x2));
                             }
+                            if (dy) {
+                                atomicAdd(&a[2], (u64)(i64)my);
+                                atomicAdd(&a[5], (u64)(i64)(my * dy));
+                                atomicAdd(&a[9], (u64)(i64)(my * y2));
+                                atomicAdd(&a[14], (u64)(i64)(mult * y2 * y2));
+                            }
+                            if (dx && dy) {
+                                atomicAdd(&a[4], (u64)(i64)(mx * dy));
+                                atomicAdd(&a[7], (u64)(i64)(my * x2));
+                                atomicAdd(&a[8], (u64)(i64)(mx * y2));
+                                atomicAdd(&a[11], (u64)(i64)(mx * x2 * dy));
+                                atomicAdd(&a[12], (u64)(i64)(mult * x2 * y2));
+                                atomicAdd(&a[13], (u64)(i64)(mx * dy * y2));
+                            }
+                        } else {
+                            const i64 ml = mult, dl = dx, el = dy, x2 = dl * dl, y2 = el * el;
+                            atomicAdd(&a[1], (u64)(ml * dl));            atomicAdd(&a[2], (u64)(ml * el));
+                            atomicAdd(&a[3], (u64)(ml * x2));            atomicAdd(&a[4], (u64)(ml * dl * el));
+                            atomicAdd(&a[5], (u64)(ml * y2));            atomicAdd(&a[6], (u64)(ml * x2 * dl));
+                            atomicAdd(&a[7], (u64)(ml * x2 * el));       atomicAdd(&a[8], (u64)(ml * dl * y2));
+                            atomicAdd(&a[9], (u64)(ml * y2 * el));       atomicAdd(&a[10], (u64)(ml * x2 * x2));
+                            atomicAdd(&a[11], (u64)(ml * x2 * dl * el)); atomicAdd(&a[12], (u64)(ml * x2 * y2));
+                            atomicAdd(&a[13], (u64)(ml * dl * el * y2)); atomicAdd(&a[14], (u64)(ml * y2 * y2));
                         }
                     }
                 }
-                // moment q = x^a y^b in the order (0,0) (1,0) (0,1) (2,0) (1,1) (0,2) (3,0) (2,1) (1,2) (0,3) (4,0) (3,1) (2,2) (1,3) (0,4);
-                // a component taller than 64 rows adds its further row blocks onto what lane 63 wrote before
-                const i64 d1 = (i64)(y - ay), d2 = d1 * d1;
-                i64* dst = as + c * VBS_AREA_SUMS;
-                const bool head = yb == ay;
-#define CCL_EMIT(q, expr)                                                                  \
-                {                                                                          \
-                    const i64 sum_ = ccl_wave_sum(expr);                                   \
-                    if (lane == 63) dst[q] = head ? sum_ : dst[q] + sum_;                  \
-                }
-                CCL_EMIT(0, X0)        CCL_EMIT(1, X1)        CCL_EMIT(2, X0 * d1)
-                CCL_EMIT(3, X2)        CCL_EMIT(4, X1 * d1)   CCL_EMIT(5, X0 * d2)
-                CCL_EMIT(6, X3)        CCL_EMIT(7, X2 * d1)   CCL_EMIT(8, X1 * d2)   CCL_EMIT(9, X0 * d2 * d1)
-                CCL_EMIT(10, X4)       CCL_EMIT(11, X3 * d1)  CCL_EMIT(12, X2 * d2)  CCL_EMIT(13, X1 * d2 * d1)
-                CCL_EMIT(14, X0 * d2 * d2)
-#undef CCL_EMIT
             }
         }
+        __syncthreads();
+        for (u32 c = tid; c < nc * NMOM; c += CCL_NT) as[(c0 + c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
+        __syncthreads();
     }
     if (geo.stop == 6) return;
 
@@ -563,10 +569,13 @@ static bool ccl_layout(const vbs_handle* h, int mode, CclGeom* g, size_t* lds_by
     g->NC = (h->WW + g->CW - 1) / g->CW;
     g->items = h->H * g->NC;
     g->inv_nc = g->NC == 1 ? 0u : (u32)((0x100000000ull + g->NC - 1) / g->NC);
+    g->R = (h->H + 63) / 64;
+    g->vitems = g->R * 64 * g->NC;
+    g->inv_r = g->R == 1 ? 0u : (u32)((0x100000000ull + g->R - 1) / g->R);
     g->stop = VBS_KNOB("VBS_CCL_STOP");
     const size_t cb = ((size_t)(g->items + 1) * 2 + 15) / 16 * 16;
     const size_t acc = mode == 0 ? ((size_t)(8 * ((h->maxm + 1) / 2)) + 16 * (size_t)h->maxm + 15) / 16 * 16     // band sums
-                                 : (size_t)CCL_OPEN_COMPS * 4 * 4;                                                // boxes
+                                 : (size_t)CCL_MOM_COMPS * NMOM * 8 + (size_t)CCL_OPEN_COMPS * 4;                  // moments, anchors
     const size_t misc = 32 * 4 + 16 + 256;
     const size_t fixed = cb + acc + misc;
     const size_t half = 80 * 1024, full = 160 * 1024;

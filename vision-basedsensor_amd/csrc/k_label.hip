@@ -14,6 +14,7 @@
 //                 contour vertices, classified per border pixel from its 8-neighbourhood by a LUT.
 //   k_finalize  : per frame: centroids, fitEllipse (:208) from the vertex moments via two normal-
 //                 equation solves in float64, then the sequential contour <-> centre matching (:203-243).
+#include <algorithm>
 #include <cstdlib>
 
 #include "common.h"
@@ -103,91 +104,113 @@ __device__ __forceinline__ u64 hmorph(u64 wl, u64 wc, u64 wr, int lo, int hi) {
     return ulo;                                          // bit i = AND / OR of pixels i + lo .. i + hi
 }
 
-// band = mask & ~erode_ns(mask) and open = dilate5(erode5(area)), separably, one workgroup per tile of MR rows:
-// horizontal passes once per row into LDS, vertical passes out of LDS (the first version recomputed the
-// horizontal erosion for every vertical offset: ~590 word ops per output word, now ~60).
+// ---- wave64 cross-lane primitives on DPP (gfx9: wave_shr/wave_shl/row_shr/row_bcast), a few cycles each;
+//      __shfl_* would go through ds_bpermute and its LDS-crossbar latency on every step of a row ----------
+__device__ __forceinline__ u32 dpp_shr1(u32 x) {        // lane i <- lane i-1, lane 0 <- 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u32 dpp_shl1(u32 x) {        // lane i <- lane i+1, lane 63 <- 0
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false);
+}
+__device__ __forceinline__ u64 dpp_shr1(u64 x) {
+    return ((u64)dpp_shr1((u32)(x >> 32)) << 32) | dpp_shr1((u32)x);
+}
+__device__ __forceinline__ u64 dpp_shl1(u64 x) {
+    return ((u64)dpp_shl1((u32)(x >> 32)) << 32) | dpp_shl1((u32)x);
+}
+// band = mask & ~erode_ns(mask) and open = dilate5(erode5(area)), separably, as a stream down the image:
+// a wave holds G = 64 / WW strips of rows side by side (lane = strip * WW + word column) and takes one image row per
+// step; the horizontal passes get their neighbour words by DPP lane shifts, the vertical passes are delay lines in
+// registers (the ns-row AND by doubling: 2, 4, 8, ns rows).  No LDS, no barrier; a strip re-reads only the ns - 1 rows
+// above / below it.  (The first version staged 32-row tiles in LDS behind four barriers: 0.31 us per 1280x1024 frame.)
 // Outside the image erosion sees 1s (pixels ignored), dilation sees 0s - scipy 'reflect' / cv2's default border.
-#define MR 32
+template <int NS14>                                      // ns = 14 (large frames) or 8 (small)
 __global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits, const u64* __restrict__ abits,
-                                               u64* __restrict__ band, u64* __restrict__ opn, int H, int W, int WW,
-                                               int ns) {
-    extern __shared__ u64 lds[];
-    const int lo14 = -(ns / 2), hi14 = ns / 2 - 1, span = hi14 - lo14;      // rows y+lo14 .. y+hi14
-    u64* he14 = lds;                                   // [MR + span][WW]   rows y0+lo14 ..
-    u64* he5 = he14 + (MR + span) * WW;                // [MR + 8][WW]      rows y0-4 ..
-    u64* ve5 = he5 + (MR + 8) * WW;                    // [MR + 4][WW]      rows y0-2 ..
-    u64* hd5 = ve5 + (MR + 4) * WW;                    // [MR + 4][WW]      rows y0-2 ..
-    const int y0 = blockIdx.x * MR, n = blockIdx.y, tid = threadIdx.x;
+                                               u64* __restrict__ band, u64* __restrict__ opn, int nb, int H, int W, int WW,
+                                               int G, int strips, int rows_per_strip, int waves_per_frame) {
+    const int lane = threadIdx.x & 63;
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = gw / waves_per_frame;
+    if (n >= nb) return;                                 // wave-uniform
+    const int sidx = (gw - n * waves_per_frame) * G + lane / WW, j = lane % WW;
+    const bool act = lane < G * WW && sidx < strips;
+    const int ra = min(sidx * rows_per_strip, H), rb = min(ra + rows_per_strip, H);
     const int64_t fo = (int64_t)n * H * WW;
     const u64* M = mbits + fo;
     const u64* A = abits + fo;
-    // 1: horizontal erosions (rows outside the image are stored as all-ones = neutral for the vertical AND)
-    for (int i = tid; i < (MR + span) * WW; i += 256) {
-        int r = i / WW, j = i - r * WW, y = y0 + lo14 + r;
-        u64 v = ~0ull;
-        if (y >= 0 && y < H) {
-            const u64* row = M + (int64_t)y * WW;
-            u64 wl = j > 0 ? row[j - 1] : ~0ull, wc = row[j] | ~valid_mask(j, W);
-            u64 wr = (j + 1 < WW) ? (row[j + 1] | ~valid_mask(j + 1, W)) : ~0ull;
-            v = hmorph<true>(wl, wc, wr, lo14, hi14);
+    const u64 vm = valid_mask(j, W);
+    const bool hasl = j > 0, hasr = j + 1 < WW;
+    constexpr int LO = -(NS14 / 2), HI = NS14 / 2 - 1;    // window rows / columns y + LO .. y + HI
+    // every lane runs the same number of steps (DPP moves need all lanes): the longest strip of the wave
+    // input rows ra + LO .. : the band row yb needs rows up to yb + HI, the opened row yo rows up to yo + 4
+    const int nsteps = rows_per_strip + (NS14 - 1 > 4 - LO ? NS14 - 1 : 4 - LO);
+    // delay lines (index 0 = newest)
+    u64 h1 = ~0ull, a2[2] = {~0ull, ~0ull}, a4[4] = {~0ull, ~0ull, ~0ull, ~0ull}, a8[6] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
+    u64 e5[4] = {~0ull, ~0ull, ~0ull, ~0ull}, d5[4] = {0, 0, 0, 0};
+    for (int k = 0; k < nsteps; ++k) {
+        const int t = ra + LO + k;                       // input row of this step
+        const bool tin = act && t >= 0 && t < H;
+        const u64 mw = tin ? M[(int64_t)t * WW + j] : 0ull, aw = tin ? A[(int64_t)t * WW + j] : 0ull;
+        const int yb = t - HI;                           // band row completed by this step (window yb + LO .. yb + HI = t)
+        const bool bout = act && yb >= ra && yb < rb;
+        const u64 mc = bout ? M[(int64_t)yb * WW + j] : 0ull;
+        // ---- horizontal erosions (neighbour words by lane shift; rows outside the image are all ones) ----
+        u64 hm, ha;
+        {
+            const u64 wc = tin ? (mw | ~vm) : ~0ull, wl_ = dpp_shr1(wc), wr_ = dpp_shl1(wc);
+            hm = hmorph<true>(hasl ? wl_ : ~0ull, wc, hasr ? wr_ : ~0ull, LO, HI);
+            const u64 ac = tin ? (aw | ~vm) : ~0ull, al_ = dpp_shr1(ac), ar_ = dpp_shl1(ac);
+            ha = hmorph<true>(hasl ? al_ : ~0ull, ac, hasr ? ar_ : ~0ull, -2, 2);
         }
-        he14[i] = v;
-    }
-    for (int i = tid; i < (MR + 8) * WW; i += 256) {
-        int r = i / WW, j = i - r * WW, y = y0 - 4 + r;
-        u64 v = ~0ull;
-        if (y >= 0 && y < H) {
-            const u64* row = A + (int64_t)y * WW;
-            u64 wl = j > 0 ? row[j - 1] : ~0ull, wc = row[j] | ~valid_mask(j, W);
-            u64 wr = (j + 1 < WW) ? (row[j + 1] | ~valid_mask(j + 1, W)) : ~0ull;
-            v = hmorph<true>(wl, wc, wr, -2, 2);
+        // ---- vertical erosion over NS14 rows by doubling: a2[t-1], a4[t-3], a8[t-7], then rows t-NS14+1 .. t ----
+        u64 e14;
+        {
+            const u64 n2 = h1 & hm;                      // rows t-1, t
+            const u64 n4 = a2[1] & n2;                   // rows t-3 .. t      (a2[1] = rows t-3, t-2)
+            if (NS14 == 14) {
+                const u64 n8 = a4[3] & n4;               // rows t-7 .. t      (a4[3] = rows t-7 .. t-4)
+                e14 = a8[5] & n8;                        // rows t-13 .. t     (a8[5] = rows t-13 .. t-6)
+                a8[5] = a8[4]; a8[4] = a8[3]; a8[3] = a8[2]; a8[2] = a8[1]; a8[1] = a8[0]; a8[0] = n8;
+            } else {
+                e14 = a4[3] & n4;                        // ns = 8: rows t-7 .. t
+            }
+            a4[3] = a4[2]; a4[2] = a4[1]; a4[1] = a4[0]; a4[0] = n4;
+            a2[1] = a2[0]; a2[0] = n2;
+            h1 = hm;
         }
-        he5[i] = v;
-    }
-    __syncthreads();
-    // 2: vertical erosions -> band (global) and the eroded area rows y0-2 .. y0+MR+1 (LDS; 0 outside the image,
-    //    which is what the dilation must see there)
-    for (int i = tid; i < MR * WW; i += 256) {
-        int r = i / WW, j = i - r * WW, y = y0 + r;
-        if (y >= H) continue;
-        u64 e = ~0ull;
-        for (int d = 0; d <= span; ++d) e &= he14[(r + d) * WW + j];
-        band[fo + (int64_t)y * WW + j] = M[(int64_t)y * WW + j] & ~e & valid_mask(j, W);
-    }
-    for (int i = tid; i < (MR + 4) * WW; i += 256) {
-        int r = i / WW, j = i - r * WW, y = y0 - 2 + r;
-        u64 e = 0ull;
-        if (y >= 0 && y < H) {
-            e = ~0ull;
-            for (int d = 0; d < 5; ++d) e &= he5[(r + d) * WW + j];
-            e &= valid_mask(j, W);
+        if (bout) band[fo + (int64_t)yb * WW + j] = mc & ~e14 & vm;
+        // ---- open: vertical erosion over 5 rows -> row t-2 (0 outside the image), horizontal dilation, vertical
+        //      dilation over 5 rows -> row t-4 ----
+        {
+            const int ye = t - 2;
+            u64 ve = ha & e5[0] & e5[1] & e5[2] & e5[3];
+            e5[3] = e5[2]; e5[2] = e5[1]; e5[1] = e5[0]; e5[0] = ha;
+            ve = (act && ye >= 0 && ye < H) ? (ve & vm) : 0ull;
+            const u64 vl_ = dpp_shr1(ve), vr_ = dpp_shl1(ve);
+            const u64 hd = hmorph<false>(hasl ? vl_ : 0ull, ve, hasr ? vr_ : 0ull, -2, 2);
+            const u64 o = hd | d5[0] | d5[1] | d5[2] | d5[3];
+            d5[3] = d5[2]; d5[2] = d5[1]; d5[1] = d5[0]; d5[0] = hd;
+            const int yo = t - 4;
+            if (act && yo >= ra && yo < rb) opn[fo + (int64_t)yo * WW + j] = o & vm;
         }
-        ve5[i] = e;
-    }
-    __syncthreads();
-    // 3: horizontal dilation of the eroded rows
-    for (int i = tid; i < (MR + 4) * WW; i += 256) {
-        int r = i / WW, j = i - r * WW;
-        const u64* row = ve5 + r * WW;
-        hd5[i] = hmorph<false>(j > 0 ? row[j - 1] : 0ull, row[j], (j + 1 < WW) ? row[j + 1] : 0ull, -2, 2);
-    }
-    __syncthreads();
-    // 4: vertical dilation -> open
-    for (int i = tid; i < MR * WW; i += 256) {
-        int r = i / WW, j = i - r * WW, y = y0 + r;
-        if (y >= H) continue;
-        u64 o = 0ull;
-        for (int d = 0; d < 5; ++d) o |= hd5[(r + d) * WW + j];
-        opn[fo + (int64_t)y * WW + j] = o & valid_mask(j, W);
     }
 }
 
 void launch_morph(vbs_handle* h, int nb, hipStream_t s) {
-    const int span = h->bp.ns - 1;
-    const size_t lds = (size_t)((MR + span) + (MR + 8) + 2 * (MR + 4)) * h->WW * sizeof(u64);
-    dim3 grid((h->H + MR - 1) / MR, nb);
-    VBS_LAUNCH(h, s, "k_morph", k_morph, grid, dim3(256), lds, s, h->mask_bits, h->area_bits, h->band_bits,
-               h->open_bits, h->H, h->W, h->WW, h->bp.ns);
+    const int G = 64 / h->WW;                            // strips per wave (WW <= 64)
+    // strips per frame: enough waves to fill the chip several times over, but strips much longer than the ns - 1 rows
+    // each re-reads
+    int wpf = (8192 + nb - 1) / nb;                      // waves per frame for ~8192 waves in flight
+    wpf = std::max(1, std::min(wpf, h->H / (4 * h->bp.ns) / G));
+    const int strips = wpf * G, rps = (h->H + strips - 1) / strips;
+    const int waves = nb * wpf;
+    dim3 grid((waves + 3) / 4);
+    if (h->bp.ns == 14)
+        VBS_LAUNCH(h, s, "k_morph", k_morph<14>, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits, h->open_bits,
+                   nb, h->H, h->W, h->WW, G, strips, rps, wpf);
+    else
+        VBS_LAUNCH(h, s, "k_morph", k_morph<8>, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits, h->open_bits,
+                   nb, h->H, h->W, h->WW, G, strips, rps, wpf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -310,20 +333,6 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* tmp, u32* total)
 // moment index of x^a y^b, a+b <= 4:  (0,0) (1,0) (0,1) (2,0) (1,1) (0,2) (3,0) (2,1) (1,2) (0,3) (4,0) (3,1) (2,2) (1,3) (0,4)
 #define NONE32 0xFFFFFFFFu
 
-// ---- wave64 cross-lane primitives on DPP (gfx9: wave_shr/wave_shl/row_shr/row_bcast), a few cycles each;
-//      __shfl_* would go through ds_bpermute and its LDS-crossbar latency on every step of a row ----------
-__device__ __forceinline__ u32 dpp_shr1(u32 x) {        // lane i <- lane i-1, lane 0 <- 0
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ u32 dpp_shl1(u32 x) {        // lane i <- lane i+1, lane 63 <- 0
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false);
-}
-__device__ __forceinline__ u64 dpp_shr1(u64 x) {
-    return ((u64)dpp_shr1((u32)(x >> 32)) << 32) | dpp_shr1((u32)x);
-}
-__device__ __forceinline__ u64 dpp_shl1(u64 x) {
-    return ((u64)dpp_shl1((u32)(x >> 32)) << 32) | dpp_shl1((u32)x);
-}
 __device__ __forceinline__ u32 wave_scan_incl(u32 x) {   // inclusive prefix sum over the 64 lanes
     x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);   // row_shr:1
     x += (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);   // row_shr:2
