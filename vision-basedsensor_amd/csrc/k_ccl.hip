@@ -4,35 +4,34 @@
 //
 // One workgroup per (frame, mask); nothing walks the image sequentially.  The image is cut into work items of CW
 // consecutive 64-px words of one row ("chunks"; lane l of a wave takes chunk l, so a wave reads consecutive bytes):
-//   A  runs of 1s per chunk (a run that crosses a chunk boundary is cut there) -> block prefix sum: the nodes are
-//      numbered in raster order, 16-bit, cbase[item] = index of the chunk's first node
+//   A  runs of 1s that START in the chunk -> block prefix sum: the runs (= nodes) are numbered in raster order, 15 bits,
+//      cbase[item] = nodes before the chunk (bit 15: the chunk holds any pixel).  A run that enters a chunk from the
+//      left is the node cbase - 1, so runs are never cut.  (Opened mask: the bit-quad Euler number rides along.)
 //   B  union-find over the nodes in LDS (uint16 parents, two per dword).  A component of a marker frame is a stack of
 //      runs, one or two per row, so hooking every run to the run above it with atomics builds chains as deep as the
 //      component is tall and every find walks them.  Instead: (1) every run takes as parent the FIRST run it touches
-//      in the row above (else the run it continues from the chunk to its left, else itself) - plain stores, a forest
-//      whose roots are smaller than their members; (2) pointer jumping, parent = parent[parent], until nothing moves
-//      (log2 of the tallest chain rounds); (3) only the remaining links (a run that touches a second run above, the
-//      continuation links not used in 1) go through the atomic union (compare-and-swap on the dword, towards the
-//      smaller index, path halving) - on trees that are flat by then
+//      in the row above (else itself) - plain stores, a forest whose roots are smaller than their members; (2) pointer
+//      jumping, parent = parent[parent], until nothing moves (log2 of the tallest chain rounds); (3) only the
+//      remaining links (a run that touches a second run above) go through the atomic union (compare-and-swap on the
+//      dword, towards the smaller index, path halving) - on trees that are flat by then, and only in the chunks that
+//      have such links
 //   C  flatten; roots ranked in raster order = ndimage.label's numbering (reversed: cv2's contour order); the parent
 //      table becomes the component id of every node (bit 15 marks the root = the component's first run)
 //   D  band: pixel count / sum x / sum y per component (center_of_mass :181)
-//      open: contour-vertex moments about the component's first pixel (see k_label.hip), LDS atomics; bit-quad Euler
-//            number (holes); and for every band centroid the component ids of the 2x2 pixel cell around it ("probes"):
-//            k_finalize's pointPolygonTest needs nothing else, so no label image or run table goes to HBM.
-//      The accumulating walks of D visit the chunks in an order that puts rows 64 apart on neighbouring lanes: in
-//      raster order 16 lanes of a wave sit on one marker and their atomics serialise on one address (measured: the
-//      moment pass 0.33 -> see profiles/README.md).
+//      open: contour-vertex moments about the component's first pixel (see k_label.hip), LDS atomics; and for every
+//            band centroid the component ids of the 2x2 pixel cell around it ("probes"): k_finalize's
+//            pointPolygonTest needs nothing else, so no label image or run table goes to HBM.
 // LDS is laid out per handle (ccl_layout): <= 80 KB and <= 64 VGPRs put two workgroups (32 waves) on a CU at
 // 1280x1024; larger frames take up to the whole 160 KB (one workgroup per CU).  Frames outside the fast path's limits
 // (more runs than the node table holds - at most 32767 -, more than 512 contours, holes in the opened mask) set their
-// slow flag and are redone by the general kernels of k_label.hip, which also own the capacity status.
+// slow flag and are redone by the general kernel of k_label.hip, which also owns the capacity status.
 #include "common.h"
 
 #define CCL_NT 1024
 #define CCL_NODE_MAX 32767         // node indices are 15-bit (bit 15 of a resolved entry marks the root)
 #define CCL_MOM_COMPS 256          // components per moment pass (15 x 8 B x 256 = 30 KB of accumulators)
 #define CCL_OPEN_COMPS 512         // contour components (k_finalize's limit)
+#define CCL_ROOT_LIST 1024         // runs without a run above them (root candidates) whose position is remembered
 #define NMOM 15
 #define NONE16 0xFFFFu
 
@@ -103,27 +102,35 @@ __device__ __forceinline__ u32 ccl_scan(u32 v, u32* tmp, u32* total) {
     return ex;
 }
 
-// runs of word B that start inside it: p = 1 when the word to its left IN THE SAME CHUNK ends with a 1 (a run that
-// continues from there is not a new node)
+// runs that START in word B: p = bit 63 of the word to its left (0 at the row start)
 __device__ __forceinline__ u64 ccl_starts(u64 B, u32 p) { return B & ~((B << 1) | (u64)p); }
 
-// links of word B (row y, word j of its chunk) to the word above (A) and its diagonal neighbours.  pB / pA: carry-in
-// bits of B / A (see ccl_starts); aL = bit 63 of the word above-left (any chunk), aR = bit 0 of the word above-right,
-// aR_same = that word belongs to the same chunk; left = B's bit-0 run continues the run that ends the chunk to its left.
-// bc / ba = nodes of row y / y-1 before word j.  The links of a run, in ascending node order: above-left diagonal, the
-// runs of A it touches, above-right diagonal, the run to its left.
-//   PASS 0: the parent of every run that STARTS in this word = its first link (itself if it has none)
-//   PASS 1: every other link (all links of a segment that continues a run from the previous word) -> ccl_union
-//   PASS 0 returns true when the word has such links (pass 1 skips the chunks that have none)
+struct CclGeom {
+    int H, W, WW, CW, NC, items;
+    u32 inv_nc;                                          // ceil(2^32 / NC): item / NC = umulhi(item, inv_nc); 0 when NC = 1
+    u32 node_cap;                                        // entries of the parent table
+    u32 off_cbase, off_acc, off_tmp;                     // byte offsets into the dynamic LDS
+    int stop;                                            // debug builds: leave after phase `stop` (0 = run everything)
+};
+
+// Links of word B (row y, word j) to the row above.  pB / pA = bit 63 of the word to the left of B / of A (the word
+// above B); aR = bit 0 of the word above-right.  bc / ba = nodes of row y / y - 1 before word j, so the node of the
+// run of B that holds bit k is bc + (starts of B at or below k) - 1, which is bc - 1 for a run that came in from the
+// left.  The links of a run, in ascending node order: above-left diagonal (8-connectivity), the runs of A it touches,
+// above-right diagonal.  A run that came in from the left skips its links at bit 0 when the run above came in from the
+// left too: the two touch one column earlier and were linked there.
+//   PASS 0: the parent of every run that STARTS in this word = its first link (itself if it has none); returns true
+//           when the word has further links; appends the runs without a link (root candidates) to the root list
+//   PASS 1: those further links -> ccl_union
 template <int M8, int PASS>
-__device__ __forceinline__ bool ccl_link_word(unsigned short* P, u64 B, u64 A, u32 pB, u32 pA, u32 aL, u32 aR,
-                                              bool aR_same, bool left, u32 bc, u32 ba) {
+__device__ __forceinline__ bool ccl_link_word(unsigned short* P, u64 B, u64 A, u32 pB, u32 pA, u32 aR, u32 bc, u32 ba,
+                                              u32 pos0, u32* rlist, int* rcount) {
     u64 adj = A;
-    if (M8) adj |= (A << 1) | (A >> 1) | (u64)aL | ((u64)aR << 63);
+    if (M8) adj |= (A << 1) | (A >> 1) | (u64)pA | ((u64)aR << 63);
     const u64 stB = ccl_starts(B, pB);
-    if (PASS == 1 && !(B & adj) && !left) return false;
-    bool extra = false;
+    if (PASS == 1 && !(B & adj)) return false;
     const u64 stA = ccl_starts(A, pA);
+    bool extra = false;
     u64 mB = B;
     while (mB) {
         const u64 lowbit = mB & (~mB + 1ull);
@@ -132,15 +139,14 @@ __device__ __forceinline__ bool ccl_link_word(unsigned short* P, u64 B, u64 A, u
         mB &= t;
         const bool starts = (stB & lowbit) != 0;
         const u32 node = bc + (u32)__popcll(stB & ((lowbit << 1) - 1ull)) - 1u;
-        bool have = !starts;                            // a continuing segment's parent was set by its first segment
+        bool have = !starts;                            // a run that came in from the left got its parent where it starts
         u32 par = node;
         if (g & adj) {
             u64 rm = g;
             if (M8) rm |= (g << 1) | (g >> 1);
-            if (M8 && (g & 1ull) && aL) {
-                if (!have) { par = ba - 1u; have = true; } else if (PASS == 1) ccl_union(P, node, ba - 1u); else extra = true;
-            }
+            if (M8 && starts && (g & 1ull) && pA) { par = ba - 1u; have = true; }       // (a run from the left: linked earlier)
             u64 mA = A & rm;
+            if (!starts && pA) mA &= ~(A & ~(A + 1ull));    // drop the run of A at bit 0: it came in from the left as well
             while (mA) {                                // the runs of A under it
                 const u64 lb = mA & (~mA + 1ull);
                 const u64 t2 = mA + lb;
@@ -149,27 +155,20 @@ __device__ __forceinline__ bool ccl_link_word(unsigned short* P, u64 B, u64 A, u
                 if (!have) { par = na; have = true; } else if (PASS == 1) ccl_union(P, node, na); else { extra = true; break; }
             }
             if (M8 && (g >> 63) && aR) {
-                const u32 na = ba + (u32)__popcll(stA) - (((A >> 63) && aR_same) ? 1u : 0u);
+                const u32 na = ba + (u32)__popcll(stA) - ((A >> 63) ? 1u : 0u);
                 if (!have) { par = na; have = true; } else if (PASS == 1) ccl_union(P, node, na); else extra = true;
             }
         }
-        if (left && (g & 1ull)) {                       // (only the chunk's first word passes left = true)
-            if (!have) { par = node - 1u; have = true; } else if (PASS == 1) ccl_union(P, node, node - 1u); else extra = true;
+        if (PASS == 0 && starts) {
+            P[node] = (unsigned short)par;
+            if (par == node && rlist) {                 // no run above: a root candidate, remember where it starts
+                const int k = atomicAdd(rcount, 1);
+                if (k < CCL_ROOT_LIST) { rlist[2 * k] = node; rlist[2 * k + 1] = pos0 + (u32)(__ffsll((long long)g) - 1); }
+            }
         }
-        if (PASS == 0 && starts) P[node] = (unsigned short)par;
     }
     return extra;
 }
-
-struct CclGeom {
-    int H, W, WW, CW, NC, items;
-    u32 inv_nc;                                          // ceil(2^32 / NC): item / NC = umulhi(item, inv_nc); 0 when NC = 1
-    int R, vitems;                                       // spread order (CCL_ITEM_DECODE_SPREAD): R = ceil(H / 64) row groups
-    u32 inv_r;
-    u32 node_cap;                                        // entries of the parent table
-    u32 off_cbase, off_acc, off_tmp;                     // byte offsets into the dynamic LDS
-    int stop;                                            // debug builds: leave after phase `stop` (0 = run everything)
-};
 
 // component id (or NONE16) of pixel (x, y) from the resolved parent table
 __device__ __forceinline__ u32 ccl_pixel_cid(const u64* __restrict__ bits, const unsigned short* P,
@@ -180,23 +179,22 @@ __device__ __forceinline__ u32 ccl_pixel_cid(const u64* __restrict__ bits, const
     const u64 w = row[jw];
     if (!((w >> k) & 1ull)) return NONE16;
     const int c = jw / g.CW, j0 = c * g.CW;
-    u32 base = cbase[y * g.NC + c], p = 0;
+    u32 base = cbase[y * g.NC + c] & 0x7FFFu, p = j0 ? (u32)(row[j0 - 1] >> 63) : 0u;
     for (int jj = j0; jj < jw; ++jj) { const u64 ww = row[jj]; base += (u32)__popcll(ccl_starts(ww, p)); p = (u32)(ww >> 63); }
     const u64 below = (k == 63) ? ~0ull : ((1ull << (k + 1)) - 1ull);
     return P[base + (u32)__popcll(ccl_starts(w, p) & below) - 1u] & 0x7FFFu;
 }
 
+// bits k-1, k, k+1 of the 66-bit string {l, X[0..63], r} (given as the dwords e0 = X[0..30] << 1 | l, e1 = X[31..62],
+// e2 = X[63] | r << 1) as a 3-bit number, k = 0..63
+__device__ __forceinline__ u32 ccl_win3(u32 e0, u32 e1, u32 e2, int k) {
+    const bool hi = k >= 32;
+    return __builtin_amdgcn_alignbit(hi ? e2 : e1, hi ? e1 : e0, (u32)k & 31u) & 7u;
+}
+
 #define CCL_ITEM_DECODE                                                                            \
     const int y = geo.inv_nc ? (int)__umulhi((u32)it, geo.inv_nc) : it, c = it - y * NC;           \
     const int j0 = c * CW, j1 = min(j0 + CW, WW);
-// The same chunks in an order that puts rows 64 apart on neighbouring lanes: the lanes of a wave then work on
-// different components (a marker is < 64 rows tall), so their LDS atomics on per-component accumulators do not
-// collide on one address (raster order puts 16 rows of one marker in a wave: 16-way serialised atomics).
-#define CCL_ITEM_DECODE_SPREAD                                                                     \
-    const int yv = geo.inv_nc ? (int)__umulhi((u32)vt, geo.inv_nc) : vt, c = vt - yv * NC;         \
-    const int grp = geo.inv_r ? (int)__umulhi((u32)yv, geo.inv_r) : yv, y = (yv - grp * geo.R) * 64 + grp; \
-    if (y >= H) continue;                                                                          \
-    const int it = y * NC + c, j0 = c * CW, j1 = min(j0 + CW, WW);
 
 template <int MODE>                                      // 0: band mask, 4-connectivity; 1: opened mask, 8-connectivity
 __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_all, u32* __restrict__ ncomp_all,
@@ -207,24 +205,62 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned short* P = reinterpret_cast<unsigned short*>(smem);                         // [node_cap]
     unsigned short* cbase = reinterpret_cast<unsigned short*>(smem + geo.off_cbase);     // [items + 1]
-    unsigned char* accb = smem + geo.off_acc;                                            // band sums | open moments + anchors
+    unsigned char* accb = smem + geo.off_acc;                                            // band sums | open moments, anchors, roots
     u32* tmp = reinterpret_cast<u32*>(smem + geo.off_tmp);                               // [32]
-    int* misc = reinterpret_cast<int*>(tmp + 32);                                        // [4]
-    u8* lut = reinterpret_cast<u8*>(misc + 4);                                           // [256] (open)
+    int* misc = reinterpret_cast<int*>(tmp + 32);                                        // [8]
+    u8* lut = reinterpret_cast<u8*>(misc + 8);                                           // [512] (open)
     const int n = blockIdx.x, tid = threadIdx.x;
     const int H = geo.H, W = geo.W, WW = geo.WW, CW = geo.CW, NC = geo.NC, items = geo.items;
     if (slow_flag[n]) return;                            // already handed to the general path
     const u64* bits = bits_all + (int64_t)n * H * WW;
-    if (MODE == 1 && tid < 256) lut[tid] = lut_g[tid];
-    if (tid < 4) misc[tid] = 0;                          // [0] Euler sum, [1..3] pointer-jumping flags
+    if (MODE == 1 && tid < 512) {
+        // vertex multiplicity by (3 bits above, 3 bits of the row, 3 bits below), bit 0 = left neighbour column:
+        // index of the 8-neighbour table (bit d = neighbour in chain direction d: 0 E, 1 NE, 2 N, 3 NW, 4 W, 5 SW, 6 S, 7 SE)
+        const u32 u = tid & 7, m = (tid >> 3) & 7, d = tid >> 6;
+        lut[tid] = lut_g[((m >> 2) & 1) | (((u >> 2) & 1) << 1) | (((u >> 1) & 1) << 2) | ((u & 1) << 3) | ((m & 1) << 4) |
+                         ((d & 1) << 5) | (((d >> 1) & 1) << 6) | (((d >> 2) & 1) << 7)];
+    }
+    if (tid < 8) misc[tid] = 0;                          // [0] Euler sum, [1..3] pointer-jumping flags, [4] root list length
 
-    // ---- A: runs per chunk, numbered in raster order ---------------------------------------------------------------
-    for (int it = tid; it < items; it += CCL_NT) {
-        CCL_ITEM_DECODE
-        const u64* row = bits + (int64_t)y * WW;
-        u32 cnt = 0, p = 0;
-        for (int j = j0; j < j1; ++j) { const u64 w = row[j]; cnt += (u32)__popcll(ccl_starts(w, p)); p = (u32)(w >> 63); }
-        cbase[it] = (unsigned short)cnt;
+    // ---- A: runs that start in each chunk, numbered in raster order (+ the Euler number of the opened mask) -------
+    {
+        int e4 = 0;
+        for (int it = tid; it < items; it += CCL_NT) {
+            CCL_ITEM_DECODE
+            const u64* row = bits + (int64_t)y * WW;
+            u32 cnt = 0, p = j0 ? (u32)(row[j0 - 1] >> 63) : 0u;
+            u64 any = 0;
+            for (int j = j0; j < j1; ++j) {
+                const u64 w = row[j];
+                cnt += (u32)__popcll(ccl_starts(w, p));
+                p = (u32)(w >> 63);
+                any |= w;
+                if (MODE == 1) {
+                    // bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the zero-padded
+                    // image; this word counts the windows whose top row is its row (row 0 also the padding row above)
+                    const bool hasd = y + 1 < H;
+                    const u64 dn = hasd ? row[j + WW] : 0ull;
+                    const u64 wn_ = j + 1 < WW ? row[j + 1] : 0ull;
+                    const u64 dn_ = (hasd && j + 1 < WW) ? row[j + 1 + WW] : 0ull;
+                    if (!(w | dn) && y != 0 && !((wn_ | dn_) & 1ull)) continue;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (q == 1 && y != 0) continue;
+                        const u64 a = q ? 0ull : w, an = q ? 0ull : wn_, bq = q ? w : dn, bn = q ? wn_ : dn_;
+                        if (a | bq | (an & 1ull) | (bn & 1ull)) {
+                            const u64 a1 = (a >> 1) | (an << 63), b1 = (bq >> 1) | (bn << 63);
+                            const u64 x2 = (a ^ a1) ^ (bq ^ b1);
+                            const u64 pairs = (a & a1) | (a & bq) | (a & b1) | (a1 & bq) | (a1 & b1) | (bq & b1);
+                            const u64 qd = (a & b1 & ~a1 & ~bq) | (a1 & bq & ~a & ~b1);
+                            e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
+                            if (j == 0) e4 += (int)((a ^ bq) & 1ull);               // window x = -1: only (0,y), (0,y+1)
+                        }
+                    }
+                }
+            }
+            cbase[it] = (unsigned short)(cnt | (any ? 0x8000u : 0u));
+        }
+        if (MODE == 1 && e4) atomicAdd(&misc[0], e4);
     }
     __syncthreads();
     if (geo.stop == 1) return;
@@ -233,51 +269,51 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
     {
         const int i0 = min(tid * K, items), i1 = min(i0 + K, items);
         u32 s = 0;
-        for (int i = i0; i < i1; ++i) s += cbase[i];
+        for (int i = i0; i < i1; ++i) s += cbase[i] & 0x7FFFu;
         u32 ex = ccl_scan(s, tmp, &total);
         if (total <= geo.node_cap)
-            for (int i = i0; i < i1; ++i) { const u32 c = cbase[i]; cbase[i] = (unsigned short)ex; ex += c; }
+            for (int i = i0; i < i1; ++i) { const u32 c = cbase[i]; cbase[i] = (unsigned short)(ex | (c & 0x8000u)); ex += c & 0x7FFFu; }
     }
     if (total > geo.node_cap) {                          // block-uniform
         if (tid == 0) slow_flag[n] = 1;
         return;
     }
-    if (tid == 0) cbase[items] = (unsigned short)total;
     __syncthreads();
     if (geo.stop == 2) return;
 
     // ---- B: parents, pointer jumping, the remaining links --------------------------------------------------------
+    u32* rlist = MODE == 1 ? reinterpret_cast<u32*>(accb + CCL_MOM_COMPS * NMOM * 8 + CCL_OPEN_COMPS * 4) : nullptr;
     u64 extra_mask = 0;                                  // bit k: this thread's k-th chunk has links left for pass 1
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
         int kk = -1;
         for (int it = tid; it < items; it += CCL_NT) {
             ++kk;
-            u32 bc = cbase[it];
-            if (cbase[it + 1] == bc) continue;           // no run starts in this chunk (and none enters: cut at chunks)
+            const u32 cb = cbase[it];
+            if (!(cb & 0x8000u)) continue;               // no pixel in this chunk
             if (pass == 1 && kk < 64 && !((extra_mask >> kk) & 1ull)) continue;
             bool extra = false;
+            u32 bc = cb & 0x7FFFu;
             CCL_ITEM_DECODE
             const u64* row = bits + (int64_t)y * WW;
             const u64* up = row - WW;
             const bool hasu = y > 0;
-            u32 ba = hasu ? (u32)cbase[it - NC] : 0u;
-            u32 aL = (hasu && j0) ? (u32)(up[j0 - 1] >> 63) : 0u;
+            u32 ba = hasu ? (u32)(cbase[it - NC] & 0x7FFFu) : 0u;
+            u32 pB = j0 ? (u32)(row[j0 - 1] >> 63) : 0u;
+            u32 pA = (hasu && j0) ? (u32)(up[j0 - 1] >> 63) : 0u;
             u64 A = hasu ? up[j0] : 0ull;
-            bool left = j0 && (row[j0 - 1] >> 63);      // the chunk's first run may continue the chunk to its left
-            u32 pB = 0, pA = 0;
             for (int j = j0; j < j1; ++j) {
                 const u64 B = row[j];
                 const u64 An = (hasu && j + 1 < WW) ? up[j + 1] : 0ull;
                 if (B) {
-                    if (pass == 0) extra |= ccl_link_word<MODE, 0>(P, B, A, pB, pA, aL, (u32)(An & 1ull), j + 1 < j1, left, bc, ba);
-                    else ccl_link_word<MODE, 1>(P, B, A, pB, pA, aL, (u32)(An & 1ull), j + 1 < j1, left, bc, ba);
+                    const u32 pos0 = (u32)y * (u32)W + 64u * (u32)j;
+                    if (pass == 0) extra |= ccl_link_word<MODE, 0>(P, B, A, pB, pA, (u32)(An & 1ull), bc, ba, pos0, rlist, &misc[4]);
+                    else ccl_link_word<MODE, 1>(P, B, A, pB, pA, (u32)(An & 1ull), bc, ba, pos0, nullptr, nullptr);
                 }
-                left = false;
                 bc += (u32)__popcll(ccl_starts(B, pB));
                 ba += (u32)__popcll(ccl_starts(A, pA));
                 pB = (u32)(B >> 63);
-                pA = aL = (u32)(A >> 63);
+                pA = (u32)(A >> 63);
                 A = An;
             }
             if (pass == 0 && (extra || kk >= 64)) extra_mask |= 1ull << (kk & 63);
@@ -317,7 +353,10 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
     for (u32 i = r0; i < r1; ++i) nroot += (P[i] == i);
     u32 ncomp;
     u32 cid0 = ccl_scan(nroot, tmp, &ncomp);
-    if (ncomp > (u32)maxm || ncomp > (MODE == 0 ? 1024u : (u32)CCL_OPEN_COMPS)) {       // block-uniform
+    if (ncomp > (u32)maxm || ncomp > (MODE == 0 ? 1024u : (u32)CCL_OPEN_COMPS) ||
+        (MODE == 1 && ((int)ncomp - misc[0] / 4 != 0 || misc[4] > CCL_ROOT_LIST))) {
+        // block-uniform.  (Open: holes - RETR_EXTERNAL needs the fill passes of the general path -, or more runs without
+        // a run above them than the root list remembers.)
         if (tid == 0) slow_flag[n] = 1;
         return;
     }
@@ -338,12 +377,13 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
         u64* asy = asx + maxm;                                                           // [maxm]
         for (u32 c = tid; c < ncomp; c += CCL_NT) { acnt[c] = 0; asx[c] = 0; asy[c] = 0; }
         __syncthreads();
-        for (int vt = tid; vt < geo.vitems; vt += CCL_NT) {
-            CCL_ITEM_DECODE_SPREAD
-            u32 bc = cbase[it];
-            if (cbase[it + 1] == bc) continue;
+        for (int it = tid; it < items; it += CCL_NT) {
+            const u32 cb = cbase[it];
+            if (!(cb & 0x8000u)) continue;
+            u32 bc = cb & 0x7FFFu;
+            CCL_ITEM_DECODE
             const u64* row = bits + (int64_t)y * WW;
-            u32 ccid = NONE16, cnt = 0, sx = 0, pB = 0;
+            u32 ccid = NONE16, cnt = 0, sx = 0, pB = j0 ? (u32)(row[j0 - 1] >> 63) : 0u;
             for (int j = j0; j < j1; ++j) {
                 const u64 B = row[j], stB = ccl_starts(B, pB);
                 u64 mB = B;
@@ -374,106 +414,62 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
         return;
     }
 
-    // ---- D (open) 0: the component's first pixel = start of its root run (the moments' origin) ---------------------
-    u32* anchor = reinterpret_cast<u32*>(accb + CCL_MOM_COMPS * NMOM * 8);               // [CCL_OPEN_COMPS]
+    // ---- D (open) 0: the component's first pixel = start of its root run (the moments' origin), from the root list ---
+    u32* anchor = reinterpret_cast<u32*>(accb + CCL_MOM_COMPS * NMOM * 8);               // [CCL_OPEN_COMPS]  (y << 16) | x
     __syncthreads();
-    for (int it = tid; it < items; it += CCL_NT) {
-        u32 bc = cbase[it];
-        if (cbase[it + 1] == bc) continue;
-        CCL_ITEM_DECODE
-        const u64* row = bits + (int64_t)y * WW;
-        u32 pB = 0;
-        for (int j = j0; j < j1; ++j) {
-            const u64 B = row[j];
-            u64 st = ccl_starts(B, pB);
-            while (st) {                                 // one new node per start bit, in order
-                const int k = __ffsll((long long)st) - 1;
-                st &= st - 1;
-                const u32 v = P[bc++];
-                if (v & 0x8000u) {
-                    const u32 pos = (u32)y * (u32)W + 64u * j + (u32)k;
-                    anchor[v & 0x7FFFu] = pos;
-                    first[v & 0x7FFFu] = pos;
-                }
-            }
-            pB = (u32)(B >> 63);
+    for (int i = tid; i < misc[4]; i += CCL_NT) {
+        const u32 v = P[rlist[2 * i]];
+        if (v & 0x8000u) {
+            const u32 pos = rlist[2 * i + 1], py = pos / (u32)W;
+            anchor[v & 0x7FFFu] = (py << 16) | (pos - py * (u32)W);
+            first[v & 0x7FFFu] = pos;
         }
-    }
-    // Euler number by bit quads (see k_label.hip): holes = components - E
-    {
-        const int NW = H * WW;
-        int e4 = 0;
-        for (int idx = tid; idx < NW; idx += CCL_NT) {
-            const int yr = idx / WW, jc = idx - yr * WW;
-            const u64 wv = bits[idx];
-            const u64 dn = yr + 1 < H ? bits[idx + WW] : 0ull;
-            if (!(wv | dn) && !(yr == 0)) {
-                if (jc + 1 >= WW) continue;
-                if (!((bits[idx + 1] | (yr + 1 < H ? bits[idx + 1 + WW] : 0ull)) & 1ull)) continue;
-            }
-            const u64 wn_ = jc + 1 < WW ? bits[idx + 1] : 0ull;
-            const u64 dn_ = (jc + 1 < WW && yr + 1 < H) ? bits[idx + 1 + WW] : 0ull;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (q == 1 && yr != 0) continue;
-                const u64 a = q ? 0ull : wv, an = q ? 0ull : wn_, bq = q ? wv : dn, bn = q ? wn_ : dn_;
-                if (a | bq | (an & 1ull) | (bn & 1ull)) {
-                    const u64 a1 = (a >> 1) | (an << 63), b1 = (bq >> 1) | (bn << 63);
-                    const u64 x2 = (a ^ a1) ^ (bq ^ b1);
-                    const u64 pairs = (a & a1) | (a & bq) | (a & b1) | (a1 & bq) | (a1 & b1) | (bq & b1);
-                    const u64 qd = (a & b1 & ~a1 & ~bq) | (a1 & bq & ~a & ~b1);
-                    e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
-                    if (jc == 0) e4 += (int)((a ^ bq) & 1ull);
-                }
-            }
-        }
-        if (e4) atomicAdd(&misc[0], e4);
-    }
-    __syncthreads();
-    if ((int)ncomp - misc[0] / 4 != 0) {                 // holes: RETR_EXTERNAL needs the fill passes of the general path
-        if (tid == 0) slow_flag[n] = 1;
-        return;
     }
     if (geo.stop == 5) return;
 
-    // ---- D (open) 1: contour-vertex moments, CCL_MOM_COMPS components per pass, LDS atomics in the spread order ----
+    // ---- D (open) 1: contour-vertex moments, CCL_MOM_COMPS components per pass, LDS atomics ---------------------
     u64* acc = reinterpret_cast<u64*>(accb);
     i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
     for (u32 c0 = 0; c0 < ncomp; c0 += CCL_MOM_COMPS) {
         const u32 nc = min((u32)CCL_MOM_COMPS, ncomp - c0);
         for (u32 c = tid; c < nc * NMOM; c += CCL_NT) acc[c] = 0;
         __syncthreads();
-        for (int vt = tid; vt < geo.vitems; vt += CCL_NT) {
-            CCL_ITEM_DECODE_SPREAD
-            u32 bc = cbase[it];
-            if (cbase[it + 1] == bc) continue;
+        for (int it = tid; it < items; it += CCL_NT) {
+            const u32 cb = cbase[it];
+            if (!(cb & 0x8000u)) continue;
+            u32 bc = cb & 0x7FFFu;
+            CCL_ITEM_DECODE
             const u64* rowm = bits + (int64_t)y * WW;
             const bool hasu = y > 0, hasd = y + 1 < H;
-            u32 pB = 0;
+            u32 pB = j0 ? (u32)(rowm[j0 - 1] >> 63) : 0u;
             for (int j = j0; j < j1; ++j) {
                 const u64 B = rowm[j];
                 const u64 stB = ccl_starts(B, pB);
-                const u32 bcw = bc;
+                const u32 bcw = bc, bl = pB;
                 bc += (u32)__popcll(stB);
                 pB = (u32)(B >> 63);
                 if (!B) continue;
                 const u64 up = hasu ? rowm[j - WW] : 0ull, dn = hasd ? rowm[j + WW] : 0ull;
-                u64 bl = 0, br = 0, upL = 0, upR = 0, dnL = 0, dnR = 0;
-                if ((B & 1ull) && j > 0) {
-                    bl = rowm[j - 1] >> 63;
-                    upL = hasu ? rowm[j - 1 - WW] >> 63 : 0ull; dnL = hasd ? rowm[j - 1 + WW] >> 63 : 0ull;
-                }
-                if ((B >> 63) && j + 1 < WW) {
-                    br = rowm[j + 1] & 1ull;
-                    upR = hasu ? rowm[j + 1 - WW] & 1ull : 0ull; dnR = hasd ? rowm[j + 1 + WW] & 1ull : 0ull;
-                }
-                const u64 NE = (up >> 1) | (upR << 63), NWd = (up << 1) | upL;
-                const u64 SE = (dn >> 1) | (dnR << 63), SW = (dn << 1) | dnL;
-                const u64 E = (B >> 1) | (br << 63), Wd = (B << 1) | bl;
-                // border pixels that can be contour vertices: not 4-interior, not inside a straight horizontal edge
-                // (patterns 241 / 31 of the vertex table: multiplicity 0)
+                // border pixels: not 4-interior (the neighbour words matter only at bits 0 / 63)
+                u32 br = 0;
+                if ((B >> 63) && j + 1 < WW) br = (u32)(rowm[j + 1] & 1ull);
+                const u64 E = (B >> 1) | ((u64)br << 63), Wd = (B << 1) | (u64)bl;
                 u64 bgw = B & ~(up & dn & E & Wd);
-                bgw &= ~(E & Wd & ((~up & ~NE & ~NWd & dn & SE & SW) | (up & NE & NWd & ~dn & ~SE & ~SW)));
+                if (!bgw) continue;
+                u32 upL = 0, upR = 0, dnL = 0, dnR = 0;
+                if (j > 0) { upL = hasu ? (u32)(rowm[j - 1 - WW] >> 63) : 0u; dnL = hasd ? (u32)(rowm[j - 1 + WW] >> 63) : 0u; }
+                if (j + 1 < WW) { upR = hasu ? (u32)(rowm[j + 1 - WW] & 1ull) : 0u; dnR = hasd ? (u32)(rowm[j + 1 + WW] & 1ull) : 0u; }
+                {   // pixels inside a straight horizontal edge (no vertex): E and W set, the three above all clear and the
+                    // three below all set, or the other way round
+                    const u64 upr = (up >> 1) | ((u64)upR << 63), upl = (up << 1) | (u64)upL;
+                    const u64 dnr = (dn >> 1) | ((u64)dnR << 63), dnl = (dn << 1) | (u64)dnL;
+                    bgw &= ~(E & Wd & ((~(up | upr | upl) & dn & dnr & dnl) | (up & upr & upl & ~(dn | dnr | dnl))));
+                    if (!bgw) continue;
+                }
+                // the three rows as 66-bit strings {left bit, word, right bit} in dwords, for the 3x3 window of a pixel
+                const u32 u0 = ((u32)up << 1) | upL, u1 = (u32)(up >> 31), u2 = (u32)(up >> 63) | (upR << 1);
+                const u32 m0 = ((u32)B << 1) | bl, m1 = (u32)(B >> 31), m2 = (u32)(B >> 63) | (br << 1);
+                const u32 d0 = ((u32)dn << 1) | dnL, d1 = (u32)(dn >> 31), d2 = (u32)(dn >> 63) | (dnR << 1);
                 u64 mB = B;
                 while (mB) {
                     const u64 lowbit = mB & (~mB + 1ull);
@@ -485,40 +481,37 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
                     const u32 cid = (P[bcw + (u32)__popcll(stB & ((lowbit << 1) - 1ull)) - 1u] & 0x7FFFu) - c0;
                     if (cid >= nc) continue;
                     const u32 fp = anchor[cid + c0];
-                    const int ay = (int)(fp / (u32)W), ax = (int)(fp - (u32)ay * (u32)W);
+                    const int ay = (int)(fp >> 16), ax = (int)(fp & 0xFFFFu);
                     u64* a = acc + cid * NMOM;
+                    const int dy = y - ay;
                     while (bg) {
                         const int k = __ffsll((long long)bg) - 1;
                         bg &= bg - 1;
-                        const u32 pat = (u32)((E >> k) & 1ull) | ((u32)((NE >> k) & 1ull) << 1) |
-                                        ((u32)((up >> k) & 1ull) << 2) | ((u32)((NWd >> k) & 1ull) << 3) |
-                                        ((u32)((Wd >> k) & 1ull) << 4) | ((u32)((SW >> k) & 1ull) << 5) |
-                                        ((u32)((dn >> k) & 1ull) << 6) | ((u32)((SE >> k) & 1ull) << 7);
-                        const int mult = lut[pat];
+                        const int mult = lut[ccl_win3(u0, u1, u2, k) | (ccl_win3(m0, m1, m2, k) << 3) | (ccl_win3(d0, d1, d2, k) << 6)];
                         if (!mult) continue;
-                        const int dx = 64 * j + k - ax, dy = y - ay;
+                        const int dx = 64 * j + k - ax;
                         atomicAdd(&a[0], (u64)mult);
-                        if (max(abs(dx), abs(dy)) <= 150) {          // 4 * 150^4 < 2^31: products in 32 bits
-                            const int x2 = dx * dx, y2 = dy * dy, mx = mult * dx, my = mult * dy;
+                        if (max(abs(dx), abs(dy)) <= 150) {          // 4 * 150^4 < 2^31 and every factor < 2^23: 24-bit multiplies
+                            const int x2 = __mul24(dx, dx), y2 = __mul24(dy, dy), mx = __mul24(mult, dx), my = __mul24(mult, dy);
                             if (dx) {
                                 atomicAdd(&a[1], (u64)(i64)mx);
-                                atomicAdd(&a[3], (u64)(i64)(mx * dx));
-                                atomicAdd(&a[6], (u64)(i64)(mx * x2));
-                                atomicAdd(&a[10], (u64)(i64)(mult * x2 * x2));
+                                atomicAdd(&a[3], (u64)(i64)__mul24(mx, dx));
+                                atomicAdd(&a[6], (u64)(i64)__mul24(mx, x2));
+                                atomicAdd(&a[10], (u64)(i64)__mul24(__mul24(mult, x2), x2));
                             }
                             if (dy) {
                                 atomicAdd(&a[2], (u64)(i64)my);
-                                atomicAdd(&a[5], (u64)(i64)(my * dy));
-                                atomicAdd(&a[9], (u64)(i64)(my * y2));
-                                atomicAdd(&a[14], (u64)(i64)(mult * y2 * y2));
+                                atomicAdd(&a[5], (u64)(i64)__mul24(my, dy));
+                                atomicAdd(&a[9], (u64)(i64)__mul24(my, y2));
+                                atomicAdd(&a[14], (u64)(i64)__mul24(__mul24(mult, y2), y2));
                             }
                             if (dx && dy) {
-                                atomicAdd(&a[4], (u64)(i64)(mx * dy));
-                                atomicAdd(&a[7], (u64)(i64)(my * x2));
-                                atomicAdd(&a[8], (u64)(i64)(mx * y2));
-                                atomicAdd(&a[11], (u64)(i64)(mx * x2 * dy));
-                                atomicAdd(&a[12], (u64)(i64)(mult * x2 * y2));
-                                atomicAdd(&a[13], (u64)(i64)(mx * dy * y2));
+                                atomicAdd(&a[4], (u64)(i64)__mul24(mx, dy));
+                                atomicAdd(&a[7], (u64)(i64)__mul24(my, x2));
+                                atomicAdd(&a[8], (u64)(i64)__mul24(mx, y2));
+                                atomicAdd(&a[11], (u64)(i64)__mul24(__mul24(mx, x2), dy));
+                                atomicAdd(&a[12], (u64)(i64)__mul24(__mul24(mult, x2), y2));
+                                atomicAdd(&a[13], (u64)(i64)__mul24(__mul24(mx, dy), y2));
                             }
                         } else {
                             const i64 ml = mult, dl = dx, el = dy, x2 = dl * dl, y2 = el * el;
@@ -560,27 +553,24 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
     if (tid == 0) { ncomp_all[n * 2 + 1] = ncomp; fstat[n * 8 + 6] = ncomp; fstat[n * 8 + 4] = 0; }
 }
 
-// LDS layout of k_ccl<mode> for this handle: [parents u16 x node_cap][chunk bases u16 x (items + 1)][accumulators]
-// [anchors][scan scratch + lut].  Two workgroups per CU (<= 80 KB each) when the expected number of runs fits the
-// node table that leaves, else one workgroup with the whole 160 KB.
+// LDS layout of k_ccl<mode> for this handle: [parents u16 x node_cap][chunk bases u16 x (items + 1)]
+// [band sums | open moment accumulators + anchors + root list][scan scratch + lut].  Two workgroups per CU (<= 80 KB
+// each) when the expected number of runs fits the node table that leaves, else one workgroup with the whole 160 KB.
 static bool ccl_layout(const vbs_handle* h, int mode, CclGeom* g, size_t* lds_bytes) {
     g->H = h->H; g->W = h->W; g->WW = h->WW;
     g->CW = h->WW < 5 ? h->WW : 5;
     g->NC = (h->WW + g->CW - 1) / g->CW;
     g->items = h->H * g->NC;
     g->inv_nc = g->NC == 1 ? 0u : (u32)((0x100000000ull + g->NC - 1) / g->NC);
-    g->R = (h->H + 63) / 64;
-    g->vitems = g->R * 64 * g->NC;
-    g->inv_r = g->R == 1 ? 0u : (u32)((0x100000000ull + g->R - 1) / g->R);
     g->stop = VBS_KNOB("VBS_CCL_STOP");
     const size_t cb = ((size_t)(g->items + 1) * 2 + 15) / 16 * 16;
     const size_t acc = mode == 0 ? ((size_t)(8 * ((h->maxm + 1) / 2)) + 16 * (size_t)h->maxm + 15) / 16 * 16     // band sums
-                                 : (size_t)CCL_MOM_COMPS * NMOM * 8 + (size_t)CCL_OPEN_COMPS * 4;                  // moments, anchors
-    const size_t misc = 32 * 4 + 16 + 256;
+                                 : (size_t)CCL_MOM_COMPS * NMOM * 8 + (size_t)CCL_OPEN_COMPS * 4 + (size_t)CCL_ROOT_LIST * 8;
+    const size_t misc = 32 * 4 + 32 + 512;
     const size_t fixed = cb + acc + misc;
     const size_t half = 80 * 1024, full = 160 * 1024;
     if (fixed + 2 * 1024 > full) return false;
-    // expected runs on marker frames (measured: 1280x1024 band 14.3 k / open 8 k; 1920x1200 band 29 k / open 16 k)
+    // expected runs on marker frames (measured: 1280x1024 band 13.9 k / open 7.6 k; 1920x1200 band 27.9 k / open 15.1 k)
     const size_t expect = (size_t)h->H * h->W / (mode == 0 ? 72 : 130);
     size_t cap = fixed < half ? (half - fixed) / 2 : 0;
     if (cap < expect) cap = (full - fixed) / 2;
@@ -591,7 +581,7 @@ static bool ccl_layout(const vbs_handle* h, int mode, CclGeom* g, size_t* lds_by
     g->off_acc = (u32)(g->off_cbase + cb);
     g->off_tmp = (u32)(g->off_acc + acc);
     *lds_bytes = g->off_tmp + misc;
-    return g->items < 65535 && cap >= 1024;
+    return g->items < 65535 && h->W < 65536 && h->H < 65536 && cap >= 1024;
 }
 
 bool launch_ccl(vbs_handle* h, int nb, hipStream_t s) {

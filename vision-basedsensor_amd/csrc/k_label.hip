@@ -147,13 +147,23 @@ __global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits, co
     // delay lines (index 0 = newest)
     u64 h1 = ~0ull, a2[2] = {~0ull, ~0ull}, a4[4] = {~0ull, ~0ull, ~0ull, ~0ull}, a8[6] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
     u64 e5[4] = {~0ull, ~0ull, ~0ull, ~0ull}, d5[4] = {0, 0, 0, 0};
+    // rows are loaded three steps ahead of their use (nothing else hides the load latency: there is no other work between
+    // two steps of a wave)
+    auto ld = [&](const u64* src, int row, bool ok) { return (ok && row >= 0 && row < H) ? src[(int64_t)row * WW + j] : 0ull; };
+    auto ldc = [&](int row) { return (act && row >= ra && row < rb) ? M[(int64_t)row * WW + j] : 0ull; };
+    const int tb = ra + LO;
+    u64 mq0 = ld(M, tb, act), mq1 = ld(M, tb + 1, act), mq2 = ld(M, tb + 2, act);
+    u64 aq0 = ld(A, tb, act), aq1 = ld(A, tb + 1, act), aq2 = ld(A, tb + 2, act);
+    u64 cq0 = ldc(tb - HI), cq1 = ldc(tb + 1 - HI), cq2 = ldc(tb + 2 - HI);
     for (int k = 0; k < nsteps; ++k) {
-        const int t = ra + LO + k;                       // input row of this step
+        const int t = tb + k;                            // input row of this step
         const bool tin = act && t >= 0 && t < H;
-        const u64 mw = tin ? M[(int64_t)t * WW + j] : 0ull, aw = tin ? A[(int64_t)t * WW + j] : 0ull;
+        const u64 mw = mq0, aw = aq0, mc = cq0;
+        mq0 = mq1; mq1 = mq2; mq2 = ld(M, t + 3, act);
+        aq0 = aq1; aq1 = aq2; aq2 = ld(A, t + 3, act);
+        cq0 = cq1; cq1 = cq2; cq2 = ldc(t + 3 - HI);
         const int yb = t - HI;                           // band row completed by this step (window yb + LO .. yb + HI = t)
         const bool bout = act && yb >= ra && yb < rb;
-        const u64 mc = bout ? M[(int64_t)yb * WW + j] : 0ull;
         // ---- horizontal erosions (neighbour words by lane shift; rows outside the image are all ones) ----
         u64 hm, ha;
         {
