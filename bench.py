@@ -228,9 +228,10 @@ def main():
     ids, xy = D.broadcast_reference(ids, xy, dev)
     assert len(ids) == M, f"frame 0 gave {len(ids)} IDs, expected {M}"
 
+    from vbs_amd.pipeline import track_and_gather
+
     def step(fr):
-        table, _, counts = eng.track_to_3d(fr, xy, 20.0, cam, 5.0)
-        table = D.gather_tables(table, n_total)
+        _, counts, table = track_and_gather(eng, fr, n_total, xy, 20.0, cam, 5.0)     # all-gather per internal pass
         disp = eng.displacement(table, 0, 5.0, 50.0, frame_range=(a, b))    # this rank's frames of the gathered table
         if args.workload == "c5":
             eng.plane_fit(table[a:b])

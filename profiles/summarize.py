@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
 """Turn the raw rocprofv3 output merged back under gpurun_out/ into the small files kept in profiles/:
-   <tag>_rocprofv3_kernel_stats.csv  rows of this repo's kernels from `--kernel-trace --stats`
-   <tag>_pmc_traffic.json            HBM traffic per launch of the threshold+CCL stage from the FETCH_SIZE / WRITE_SIZE passes
-usage: python profiles/summarize.py <tag> [frames_per_launch=256]"""
+   <tag>_rocprofv3_kernel_stats.csv     rows of this repo's kernels from `--kernel-trace --stats`
+   <tag>_pmc_traffic_<workload>.json    HBM traffic per launch of the threshold+CCL stage of the FUSED path from the
+                                        FETCH_SIZE / WRITE_SIZE passes (profiles/collect.sh), workload c3 / c5
+   <tag>_sq_counters.json               SQ counters of the matrix-core kernels
+usage: python profiles/summarize.py <tag> [frames_per_launch=512]"""
 import csv, glob, json, os, sys, collections
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
-frames = int(sys.argv[2]) if len(sys.argv) > 2 else 256
+frames = int(sys.argv[2]) if len(sys.argv) > 2 else 512
 G = os.path.join(ROOT, "gpurun_out")
 
-def one(pattern):
+
+def one(pattern, required=True):
     f = sorted(glob.glob(os.path.join(G, pattern), recursive=True))
     if not f:
-        raise SystemExit(f"missing {pattern}")
+        if required:
+            raise SystemExit(f"missing {pattern}")
+        return None
     return f[-1]
+
+
+def kname(s):
+    k = s.split("(")[0].replace("void ", "")
+    if k.startswith("k_ccl<"):
+        return "k_ccl_band" if k.startswith("k_ccl<0") else "k_ccl_open"
+    return k.split("<")[0]
+
 
 rows = list(csv.reader(open(one(f"prof_{tag}/**/*kernel_stats.csv"))))
 with open(os.path.join(ROOT, "profiles", f"{tag}_rocprofv3_kernel_stats.csv"), "w", newline="") as f:
@@ -24,36 +37,41 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_rocprofv3_kernel_stats.csv"), "
         if r[0].startswith(("void k_", "k_")):
             w.writerow(r)
 
+
 def counter(pattern):
     agg = collections.defaultdict(list)
-    for r in csv.DictReader(open(one(pattern))):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").split("<")[0]
+    p = one(pattern, required=False)
+    if p is None:
+        return None
+    for r in csv.DictReader(open(p)):
+        k = kname(r["Kernel_Name"])
         if k.startswith("k_"):
             agg[k].append(float(r["Counter_Value"]))
     return agg
 
-fetch, write = counter(f"pmc_fetch_{tag}/**/*counter_collection.csv"), counter(f"pmc_write_{tag}/**/*counter_collection.csv")
-stage = ("k_threshold", "k_morph", "k_label", "k_finalize")
-per_kernel = {}
-total = 0.0
-for k in stage:
-    n_launch = max(1, len(fetch[k]) // max(1, len(fetch["k_threshold"])))   # launches per stage call (k_morph 2,
-                                                     # k_label 3 since the hole-fill / relabel modes were added)
-    # steady-state launches only (the script runs the stage 4x after one find_markers pass): take the last ones
-    fk = sum(fetch[k][-n_launch:]) * 1024.0          # FETCH_SIZE / WRITE_SIZE are in KiB
-    wk = sum(write[k][-n_launch:]) * 1024.0
-    corr = 2.0 if k == "k_threshold" else 1.0         # gfx950: FETCH_SIZE counts 128-B requests as 64 B for wide
-    per_kernel[k] = {"fetch_bytes_raw": fk, "fetch_correction": corr, "write_bytes": wk,
-                     "bytes": fk * corr + wk}         # (16 B/lane) streaming loads; calibrated for k_threshold only
-    total += fk * corr + wk
-out = {"tag": tag, "frames_per_launch": frames, "stage": "+".join(stage),
-       "traffic_bytes_per_launch": total, "traffic_bytes_per_frame": total / frames,
-       "per_kernel": per_kernel,
-       "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE); k_threshold's FETCH_SIZE doubled per MI355X_MICROARCH.md "
-               "(verified: 2 x raw == 2*H*W*frames exactly); the other kernels' narrow / LDS-staged accesses are uncalibrated and "
-               "taken at face value"}
-json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(out)[:400])
+
+alg = {"c3": 1280 * 1024 + 24 * 169, "c5": 1920 * 1200 + 24 * 441}
+for wl in ("c3", "c5"):
+    fetch, write = counter(f"pmc_fetch_{tag}_{wl}/**/*counter_collection.csv"), counter(f"pmc_write_{tag}_{wl}/**/*counter_collection.csv")
+    if not fetch or not write:
+        continue
+    per_kernel, total = {}, 0.0
+    for k in sorted(fetch):
+        # the program runs the fused path twice over `frames` frames in ONE internal pass: the last launch of every kernel
+        fk = fetch[k][-1] * 1024.0                      # FETCH_SIZE / WRITE_SIZE are in KiB
+        wk = write[k][-1] * 1024.0
+        per_kernel[k] = {"fetch_bytes": fk, "write_bytes": wk, "bytes": fk + wk}
+        total += fk + wk
+    out = {"tag": tag, "workload": wl, "frames_per_launch": frames, "stage": "+".join(sorted(per_kernel)),
+           "traffic_bytes_per_launch": total, "traffic_bytes_per_frame": total / frames,
+           "algorithmic_bytes_per_frame": alg[wl], "traffic_over_algorithmic": round(total / frames / alg[wl], 3),
+           "per_kernel": per_kernel,
+           "note": "separate --pmc passes (FETCH_SIZE, WRITE_SIZE) over the fused path, stage kernels only. gfx950 counts a wide "
+                   "(16 B / lane) streaming read at half its bytes (MI355X_MICROARCH.md); these kernels read the bit images "
+                   "with 8-byte loads, an access width the guide leaves uncalibrated: the counters are taken at face value, "
+                   "and doubling every FETCH_SIZE gives the upper bound"}
+    json.dump(out, open(os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{wl}.json"), "w"), indent=1)
+    print(wl, "traffic/frame", round(total / frames), "=", out["traffic_over_algorithmic"], "x algorithmic")
 
 # SQ counters of the matrix-core kernels (optional passes of collect.sh): last launch of each kernel
 sq = {}

@@ -788,6 +788,31 @@ def test_real_sensor_frame(golden_dir, tmp_path):
             assert Counter(df[df.frameno == 0].row.tolist()) == {0: 1, 1: 6, 2: 12, 3: 18, 4: 24, 5: 4}
 
 
+def test_bgr_frames_large_branch_fused_and_fallback():
+    """a3 + a4 on coloured 1280x1024 BGR frames (large branch): the blur kernel converts inside its loader when the rows
+    are 16-byte aligned (LDS-DMA), and through a gray plane otherwise (a crop view at an odd offset); both equal the
+    oracle, under both coefficient sets."""
+    rng = np.random.default_rng(12)
+    spec = S.config2()
+    g = S.make_frames(spec, [0, 3], seed=5)
+    tint = rng.integers(-12, 13, (2, 1, 1, 3))
+    frames = np.clip(g[..., None].astype(int) + tint + rng.integers(-3, 4, g.shape + (3,)), 0, 255).astype(np.uint8)
+    frames[0, :40, :300] = rng.integers(0, 256, (40, 300, 3), dtype=np.uint8)          # coloured clutter at the border
+    frames[1, 500:560, 1200:] = rng.integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    pad = np.pad(frames, ((0, 0), (5, 3), (7, 9), (0, 0)))
+    for bits in (15, 14):
+        eng = engine(spec.height, spec.width, max_batch=2)
+        eng.set_option(L.OPT_GRAY_COEFFS, bits)
+        want = [O.find_markers(f, gray_bits=bits) for f in frames]
+        for ft in (torch.from_numpy(frames).cuda(), torch.from_numpy(pad).cuda()[:, 5:5 + spec.height, 7:7 + spec.width]):
+            mask, area = eng.find_markers(ft)
+            for i in range(2):
+                assert np.array_equal(area[i].cpu().numpy(), want[i][1]), (bits, i)
+                assert np.array_equal(mask[i].cpu().numpy(), want[i][0]), (bits, i)
+        eng.close()
+    assert not np.array_equal(O.bgr2gray(frames[0], 15), O.bgr2gray(frames[0], 14))
+
+
 def test_bgr2gray_both_coefficient_sets():
     """a3 on coloured pixels, where the 15-bit (OpenCV 4) and 14-bit sets differ; also through `find_markers`."""
     rng = np.random.default_rng(9)

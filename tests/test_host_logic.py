@@ -333,7 +333,13 @@ def _gloo_worker(rank, world, port, n_total, out_dir):
             xy = np.linspace(0, 1, 14).reshape(7, 2) * 1e3 + 0.123456789
         ids, xy = D.broadcast_reference(ids, xy, torch.device("cpu"))
         gathered = D.gather_tables(full[a:b].clone(), n_total)
-        ok = torch.equal(gathered, full) and ids.shape == (7, 2) and ids[5].tolist() == [2, 2] \
+        # the pass-by-pass gather (chunk 3: several passes, the last one ragged when the shards differ)
+        g = D.TableGather(n_total, m, 10, torch.device("cpu"), 3)
+        local = full[a:b].clone()
+        for off in range(0, g.n_max, 3):
+            g.push(off, local[off:off + 3])
+        piped = g.finish()
+        ok = torch.equal(gathered, full) and torch.equal(piped, full) and ids.shape == (7, 2) and ids[5].tolist() == [2, 2] \
             and abs(xy[6, 1] - (1e3 + 0.123456789)) < 1e-12
         open(os.path.join(out_dir, f"rank{rank}.txt"), "w").write("ok" if ok else "bad")
     finally:

@@ -21,7 +21,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "child":
 else:
     n = sys.argv[1] if len(sys.argv) > 1 else "512"
     w = sys.argv[2] if len(sys.argv) > 2 else "c3"
-    for stop in (2, 7, 8, 3, 4, 5, 6, 0):    # counts+scan | parents | pointer jumping | other links | ids | boxes+Euler | moments | all
+    for stop in (2, 7, 8, 3, 4, 5, 9, 6, 0):    # counts+scan | parents | jumping | other links | ids | anchors | border-pixel list | moments | all
         env = dict(os.environ, VBS_CCL_STOP=str(stop))
         r = subprocess.run([sys.executable, __file__, n, w, "child"], env=env, capture_output=True, text=True, timeout=300)
         print("stop", stop, r.stdout.strip(), r.stderr.strip()[-300:] if r.returncode else "", flush=True)

@@ -210,7 +210,9 @@ static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, in
         launch_blur(h, h->gray, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
     } else if (channels == 1) {
         launch_blur(h, frames, stride_n, stride_row, nb, area_u8, s);
-    } else {
+    } else if (blur_bgr_direct(h, frames, stride_n, stride_row)) {
+        launch_blur(h, frames, stride_n, stride_row, nb, area_u8, s, true);      // cvtColor inside the blur's loader
+    } else {                                            // rows not 16-byte aligned (odd crops): gray plane first
         launch_gray(h, frames, nb, channels, stride_n, stride_row, s);
         launch_blur(h, h->gray, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
     }

@@ -116,7 +116,8 @@ void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t 
 void launch_gray_dense(vbs_handle* h, const u8* frames, int nb, int64_t stride_n, int64_t stride_row, u8* out,
                        hipStream_t s);
 void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,
-                 u8* area_u8, hipStream_t s);
+                 u8* area_u8, hipStream_t s, bool bgr = false);
+bool blur_bgr_direct(const vbs_handle* h, const u8* frames, int64_t stride_n, int64_t stride_row);
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s);
 void launch_points(int which, const double* in, int n, const vbs_camera& cam, double* out, int32_t* ok,
                    hipStream_t s);

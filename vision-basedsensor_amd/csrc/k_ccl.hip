@@ -18,9 +18,10 @@
 //   C  flatten; roots ranked in raster order = ndimage.label's numbering (reversed: cv2's contour order); the parent
 //      table becomes the component id of every node (bit 15 marks the root = the component's first run)
 //   D  band: pixel count / sum x / sum y per component (center_of_mass :181)
-//      open: contour-vertex moments about the component's first pixel (see k_label.hip), LDS atomics; and for every
-//            band centroid the component ids of the 2x2 pixel cell around it ("probes"): k_finalize's
-//            pointPolygonTest needs nothing else, so no label image or run table goes to HBM.
+//      open: contour-vertex moments about the component's first pixel (see k_label.hip): the border pixels are listed
+//            and then classified / accumulated one per thread (LDS atomics); and for every band centroid the
+//            component ids of the 2x2 pixel cell around it ("probes"): k_finalize's pointPolygonTest needs nothing
+//            else, so no label image or run table goes to HBM.
 // LDS is laid out per handle (ccl_layout): <= 80 KB and <= 64 VGPRs put two workgroups (32 waves) on a CU at
 // 1280x1024; larger frames take up to the whole 160 KB (one workgroup per CU).  Frames outside the fast path's limits
 // (more runs than the node table holds - at most 32767 -, more than 512 contours, holes in the opened mask) set their
@@ -110,6 +111,8 @@ struct CclGeom {
     u32 inv_nc;                                          // ceil(2^32 / NC): item / NC = umulhi(item, inv_nc); 0 when NC = 1
     u32 node_cap;                                        // entries of the parent table
     u32 off_cbase, off_acc, off_tmp;                     // byte offsets into the dynamic LDS
+    u32 pair_cap;                                        // entries of the extra-link list (it borrows the accumulator area)
+    u32 cand_cap;                                        // border-pixel records per frame (global scratch)
     int stop;                                            // debug builds: leave after phase `stop` (0 = run everything)
 };
 
@@ -119,18 +122,30 @@ struct CclGeom {
 // left.  The links of a run, in ascending node order: above-left diagonal (8-connectivity), the runs of A it touches,
 // above-right diagonal.  A run that came in from the left skips its links at bit 0 when the run above came in from the
 // left too: the two touch one column earlier and were linked there.
-//   PASS 0: the parent of every run that STARTS in this word = its first link (itself if it has none); returns true
-//           when the word has further links; appends the runs without a link (root candidates) to the root list
-//   PASS 1: those further links -> ccl_union
+//   PASS 0: the parent of every run that STARTS in this word = its first link (itself if it has none); every further
+//           link goes to the pair list (node << 16 | other node) for the dense union pass; when the list is full the
+//           word is flagged instead (returns true) and PASS 1 walks it again; runs without a link (root candidates)
+//           go to the root list
+//   PASS 1: the further links -> ccl_union (only for chunks flagged in pass 0)
+struct CclLists {
+    u32* pairs; int* npairs; int pair_cap;               // extra links
+    u32* roots; int* nroots;                             // root candidates (node, position), opened mask only
+};
+
 template <int M8, int PASS>
 __device__ __forceinline__ bool ccl_link_word(unsigned short* P, u64 B, u64 A, u32 pB, u32 pA, u32 aR, u32 bc, u32 ba,
-                                              u32 pos0, u32* rlist, int* rcount) {
+                                              u32 pos0, const CclLists& L) {
     u64 adj = A;
     if (M8) adj |= (A << 1) | (A >> 1) | (u64)pA | ((u64)aR << 63);
     const u64 stB = ccl_starts(B, pB);
     if (PASS == 1 && !(B & adj)) return false;
     const u64 stA = ccl_starts(A, pA);
-    bool extra = false;
+    bool overflow = false;
+    auto further = [&](u32 node, u32 other) {            // a link beyond the first
+        if (PASS == 1) { ccl_union(P, node, other); return; }
+        const int k = atomicAdd(L.npairs, 1);
+        if (k < L.pair_cap) L.pairs[k] = (node << 16) | other; else overflow = true;
+    };
     u64 mB = B;
     while (mB) {
         const u64 lowbit = mB & (~mB + 1ull);
@@ -152,22 +167,22 @@ __device__ __forceinline__ bool ccl_link_word(unsigned short* P, u64 B, u64 A, u
                 const u64 t2 = mA + lb;
                 mA &= t2;
                 const u32 na = ba + (u32)__popcll(stA & ((lb << 1) - 1ull)) - 1u;
-                if (!have) { par = na; have = true; } else if (PASS == 1) ccl_union(P, node, na); else { extra = true; break; }
+                if (!have) { par = na; have = true; } else further(node, na);
             }
             if (M8 && (g >> 63) && aR) {
                 const u32 na = ba + (u32)__popcll(stA) - ((A >> 63) ? 1u : 0u);
-                if (!have) { par = na; have = true; } else if (PASS == 1) ccl_union(P, node, na); else extra = true;
+                if (!have) { par = na; have = true; } else further(node, na);
             }
         }
         if (PASS == 0 && starts) {
             P[node] = (unsigned short)par;
-            if (par == node && rlist) {                 // no run above: a root candidate, remember where it starts
-                const int k = atomicAdd(rcount, 1);
-                if (k < CCL_ROOT_LIST) { rlist[2 * k] = node; rlist[2 * k + 1] = pos0 + (u32)(__ffsll((long long)g) - 1); }
+            if (par == node && L.roots) {               // no run above: a root candidate, remember where it starts
+                const int k = atomicAdd(L.nroots, 1);
+                if (k < CCL_ROOT_LIST) { L.roots[2 * k] = node; L.roots[2 * k + 1] = pos0 + (u32)(__ffsll((long long)g) - 1); }
             }
         }
     }
-    return extra;
+    return overflow;
 }
 
 // component id (or NONE16) of pixel (x, y) from the resolved parent table
@@ -201,7 +216,8 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
                                                    u32* __restrict__ first_all, u64* __restrict__ band_sums,
                                                    i64* __restrict__ area_sums, unsigned short* __restrict__ probe_all,
                                                    u32* __restrict__ fstat, u32* __restrict__ slow_flag,
-                                                   const u8* __restrict__ lut_g, CclGeom geo, int maxm) {
+                                                   u32* __restrict__ cand_all, const u8* __restrict__ lut_g, CclGeom geo,
+                                                   int maxm) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned short* P = reinterpret_cast<unsigned short*>(smem);                         // [node_cap]
     unsigned short* cbase = reinterpret_cast<unsigned short*>(smem + geo.off_cbase);     // [items + 1]
@@ -220,7 +236,7 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
         lut[tid] = lut_g[((m >> 2) & 1) | (((u >> 2) & 1) << 1) | (((u >> 1) & 1) << 2) | ((u & 1) << 3) | ((m & 1) << 4) |
                          ((d & 1) << 5) | (((d >> 1) & 1) << 6) | (((d >> 2) & 1) << 7)];
     }
-    if (tid < 8) misc[tid] = 0;                          // [0] Euler sum, [1..3] pointer-jumping flags, [4] root list length
+    if (tid < 8) misc[tid] = 0;                          // [0] Euler sum, [1..3] pointer-jumping flags, [4] roots, [5] pairs
 
     // ---- A: runs that start in each chunk, numbered in raster order (+ the Euler number of the opened mask) -------
     {
@@ -282,10 +298,17 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
     if (geo.stop == 2) return;
 
     // ---- B: parents, pointer jumping, the remaining links --------------------------------------------------------
-    u32* rlist = MODE == 1 ? reinterpret_cast<u32*>(accb + CCL_MOM_COMPS * NMOM * 8 + CCL_OPEN_COMPS * 4) : nullptr;
-    u64 extra_mask = 0;                                  // bit k: this thread's k-th chunk has links left for pass 1
+    // (the pair list lives in the accumulator area, which nothing uses before phase D)
+    CclLists L;
+    L.pairs = reinterpret_cast<u32*>(accb);
+    L.npairs = &misc[5];
+    L.pair_cap = (int)geo.pair_cap;
+    L.roots = MODE == 1 ? reinterpret_cast<u32*>(accb + CCL_MOM_COMPS * NMOM * 8 + CCL_OPEN_COMPS * 4) : nullptr;
+    L.nroots = &misc[4];
+    u64 extra_mask = 0;                                  // bit k: this thread's k-th chunk overflowed the pair list
 #pragma unroll 1
     for (int pass = 0; pass < 2; ++pass) {
+        if (pass == 1 && misc[5] <= L.pair_cap) break;   // block-uniform: every further link is in the pair list
         int kk = -1;
         for (int it = tid; it < items; it += CCL_NT) {
             ++kk;
@@ -307,8 +330,8 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
                 const u64 An = (hasu && j + 1 < WW) ? up[j + 1] : 0ull;
                 if (B) {
                     const u32 pos0 = (u32)y * (u32)W + 64u * (u32)j;
-                    if (pass == 0) extra |= ccl_link_word<MODE, 0>(P, B, A, pB, pA, (u32)(An & 1ull), bc, ba, pos0, rlist, &misc[4]);
-                    else ccl_link_word<MODE, 1>(P, B, A, pB, pA, (u32)(An & 1ull), bc, ba, pos0, nullptr, nullptr);
+                    if (pass == 0) extra |= ccl_link_word<MODE, 0>(P, B, A, pB, pA, (u32)(An & 1ull), bc, ba, pos0, L);
+                    else ccl_link_word<MODE, 1>(P, B, A, pB, pA, (u32)(An & 1ull), bc, ba, pos0, L);
                 }
                 bc += (u32)__popcll(ccl_starts(B, pB));
                 ba += (u32)__popcll(ccl_starts(A, pA));
@@ -336,6 +359,10 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
                 if (!misc[1 + f]) break;
             }
             if (geo.stop == 8) return;
+            // the further links, densely: one pair per thread
+            const int np = min(misc[5], L.pair_cap);
+            for (int i = tid; i < np; i += CCL_NT) { const u32 pr = L.pairs[i]; ccl_union(P, pr >> 16, pr & 0xFFFFu); }
+            __syncthreads();
         }
     }
     if (geo.stop == 3) return;
@@ -418,113 +445,164 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
     u32* anchor = reinterpret_cast<u32*>(accb + CCL_MOM_COMPS * NMOM * 8);               // [CCL_OPEN_COMPS]  (y << 16) | x
     __syncthreads();
     for (int i = tid; i < misc[4]; i += CCL_NT) {
-        const u32 v = P[rlist[2 * i]];
+        const u32 v = P[L.roots[2 * i]];
         if (v & 0x8000u) {
-            const u32 pos = rlist[2 * i + 1], py = pos / (u32)W;
+            const u32 pos = L.roots[2 * i + 1], py = pos / (u32)W;
             anchor[v & 0x7FFFu] = (py << 16) | (pos - py * (u32)W);
             first[v & 0x7FFFu] = pos;
         }
     }
     if (geo.stop == 5) return;
 
-    // ---- D (open) 1: contour-vertex moments, CCL_MOM_COMPS components per pass, LDS atomics ---------------------
+    // ---- D (open) 1: contour-vertex moments ------------------------------------------------------------------------
+    // (i) the chunk walk only LISTS the border pixels (component id, y, x in one dword, in this frame's slice of the
+    //     general path's run table, idle on the fast path); (ii) the vertex classification, the moment terms and the
+    //     LDS atomics run one listed pixel per thread.  Done inside the walk's three nested data-dependent loops
+    //     (words, runs, pixels) every wave pays the longest trip count of its 64 lanes at every level: 0.31 us per
+    //     frame against 0.1 this way.
+    u32* cand = cand_all + (int64_t)n * geo.cand_cap;
+    for (int itb = tid & ~63; itb < items; itb += CCL_NT) {          // (whole waves: the slot allocation scans the wave)
+        const int it = itb + (tid & 63);
+        const u32 cb = it < items ? (u32)cbase[it] : 0u;
+        const bool occ = (cb & 0x8000u) != 0;
+        u32 bc = cb & 0x7FFFu;
+        const int yv = it < items ? it : 0;
+        const int y = geo.inv_nc ? (int)__umulhi((u32)yv, geo.inv_nc) : yv, c = yv - y * NC;
+        const int j0 = c * CW, j1 = min(j0 + CW, WW);
+        const u64* rowm = bits + (int64_t)y * WW;
+        const bool hasu = y > 0, hasd = y + 1 < H;
+        // border pixels (not 4-interior) of the chunk's words, and how many
+        u64 bgv[5] = {0, 0, 0, 0, 0};
+        u32 cnt = 0;
+        if (occ) {
+            u32 bl = j0 ? (u32)(rowm[j0 - 1] >> 63) : 0u;
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int j = j0 + q;
+                if (j < j1) {
+                    const u64 B = rowm[j];
+                    if (B) {
+                        const u64 up = hasu ? rowm[j - WW] : 0ull, dn = hasd ? rowm[j + WW] : 0ull;
+                        u32 br = 0;
+                        if ((B >> 63) && j + 1 < WW) br = (u32)(rowm[j + 1] & 1ull);
+                        bgv[q] = B & ~(up & dn & ((B >> 1) | ((u64)br << 63)) & ((B << 1) | (u64)bl));
+                        cnt += (u32)__popcll(bgv[q]);
+                    }
+                    bl = (u32)(B >> 63);
+                }
+            }
+        }
+        // list slots for the wave's pixels: one atomic per wave
+        u32 slot;
+        {
+            u32 inc = cnt;
+            inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, false);   // row_shr:1
+            inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, false);   // row_shr:2
+            inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, false);   // row_shr:4
+            inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, false);   // row_shr:8
+            inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x142, 0xa, 0xf, false);   // row_bcast:15
+            inc += (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x143, 0xc, 0xf, false);   // row_bcast:31
+            const u32 wtot = (u32)__builtin_amdgcn_readlane((int)inc, 63);
+            u32 wbase_ = 0;
+            if ((tid & 63) == 0 && wtot) wbase_ = (u32)atomicAdd(&misc[6], (int)wtot);
+            slot = (u32)__builtin_amdgcn_readfirstlane((int)wbase_) + inc - cnt;
+        }
+        if (!cnt) continue;
+        u32 pB = j0 ? (u32)(rowm[j0 - 1] >> 63) : 0u;
+#pragma unroll
+        for (int q = 0; q < 5; ++q) {
+            const int j = j0 + q;
+            if (j >= j1) continue;
+            const u64 B = rowm[j];
+            const u64 stB = ccl_starts(B, pB);
+            const u32 bcw = bc;
+            bc += (u32)__popcll(stB);
+            pB = (u32)(B >> 63);
+            u64 mB = bgv[q] ? B : 0ull;
+            while (mB) {
+                const u64 lowbit = mB & (~mB + 1ull);
+                const u64 t = mB + lowbit;
+                const u64 g = mB & ~t;
+                mB &= t;
+                u64 bg = bgv[q] & g;
+                if (!bg) continue;
+                const u32 cid = P[bcw + (u32)__popcll(stB & ((lowbit << 1) - 1ull)) - 1u] & 0x7FFFu;
+                const u32 rec = (cid << 23) | ((u32)y << 12) | (64u * (u32)j);
+                while (bg) {
+                    const u32 k = (u32)(__ffsll((long long)bg) - 1);
+                    bg &= bg - 1;
+                    if (slot < geo.cand_cap) cand[slot] = rec | k;
+                    ++slot;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if ((u32)misc[6] > geo.cand_cap) {                   // block-uniform: more border pixels than the list holds
+        if (tid == 0) slow_flag[n] = 1;
+        return;
+    }
+    __threadfence_block();
+    if (geo.stop == 9) return;
     u64* acc = reinterpret_cast<u64*>(accb);
     i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
+    const u32 nrec = (u32)misc[6];
     for (u32 c0 = 0; c0 < ncomp; c0 += CCL_MOM_COMPS) {
         const u32 nc = min((u32)CCL_MOM_COMPS, ncomp - c0);
         for (u32 c = tid; c < nc * NMOM; c += CCL_NT) acc[c] = 0;
         __syncthreads();
-        for (int it = tid; it < items; it += CCL_NT) {
-            const u32 cb = cbase[it];
-            if (!(cb & 0x8000u)) continue;
-            u32 bc = cb & 0x7FFFu;
-            CCL_ITEM_DECODE
-            const u64* rowm = bits + (int64_t)y * WW;
-            const bool hasu = y > 0, hasd = y + 1 < H;
-            u32 pB = j0 ? (u32)(rowm[j0 - 1] >> 63) : 0u;
-            for (int j = j0; j < j1; ++j) {
-                const u64 B = rowm[j];
-                const u64 stB = ccl_starts(B, pB);
-                const u32 bcw = bc, bl = pB;
-                bc += (u32)__popcll(stB);
-                pB = (u32)(B >> 63);
-                if (!B) continue;
-                const u64 up = hasu ? rowm[j - WW] : 0ull, dn = hasd ? rowm[j + WW] : 0ull;
-                // border pixels: not 4-interior (the neighbour words matter only at bits 0 / 63)
-                u32 br = 0;
-                if ((B >> 63) && j + 1 < WW) br = (u32)(rowm[j + 1] & 1ull);
-                const u64 E = (B >> 1) | ((u64)br << 63), Wd = (B << 1) | (u64)bl;
-                u64 bgw = B & ~(up & dn & E & Wd);
-                if (!bgw) continue;
-                u32 upL = 0, upR = 0, dnL = 0, dnR = 0;
-                if (j > 0) { upL = hasu ? (u32)(rowm[j - 1 - WW] >> 63) : 0u; dnL = hasd ? (u32)(rowm[j - 1 + WW] >> 63) : 0u; }
-                if (j + 1 < WW) { upR = hasu ? (u32)(rowm[j + 1 - WW] & 1ull) : 0u; dnR = hasd ? (u32)(rowm[j + 1 + WW] & 1ull) : 0u; }
-                {   // pixels inside a straight horizontal edge (no vertex): E and W set, the three above all clear and the
-                    // three below all set, or the other way round
-                    const u64 upr = (up >> 1) | ((u64)upR << 63), upl = (up << 1) | (u64)upL;
-                    const u64 dnr = (dn >> 1) | ((u64)dnR << 63), dnl = (dn << 1) | (u64)dnL;
-                    bgw &= ~(E & Wd & ((~(up | upr | upl) & dn & dnr & dnl) | (up & upr & upl & ~(dn | dnr | dnl))));
-                    if (!bgw) continue;
+        for (u32 i = tid; i < nrec; i += CCL_NT) {
+            const u32 rec = cand[i];
+            const u32 cid = (rec >> 23) - c0;
+            if (cid >= nc) continue;
+            const int y = (int)((rec >> 12) & 0x7FFu), x = (int)(rec & 0xFFFu), j = x >> 6, k = x & 63;
+            const u64* rowm = bits + (int64_t)y * WW + j;
+            const bool hasu = y > 0, hasd = y + 1 < H, el = k == 0 && j > 0, er = k == 63 && j + 1 < WW;
+            const u64 md = rowm[0], up = hasu ? rowm[-WW] : 0ull, dn = hasd ? rowm[WW] : 0ull;
+            u32 ml = 0, mr = 0, ul = 0, ur = 0, dl = 0, dr = 0;      // neighbour words matter only at bits 0 / 63
+            if (el) { ml = (u32)(rowm[-1] >> 63); ul = hasu ? (u32)(rowm[-1 - WW] >> 63) : 0u; dl = hasd ? (u32)(rowm[-1 + WW] >> 63) : 0u; }
+            if (er) { mr = (u32)(rowm[1] & 1ull); ur = hasu ? (u32)(rowm[1 - WW] & 1ull) : 0u; dr = hasd ? (u32)(rowm[1 + WW] & 1ull) : 0u; }
+            auto win3 = [&](u64 w, u32 l, u32 r) {       // pixels k-1, k, k+1 of the row as bits 0, 1, 2
+                u32 v = k ? (u32)(w >> (k - 1)) & 7u : (((u32)w << 1) & 6u) | l;
+                return k == 63 ? (v & 3u) | (r << 2) : v;
+            };
+            const int mult = lut[win3(up, ul, ur) | (win3(md, ml, mr) << 3) | (win3(dn, dl, dr) << 6)];
+            if (!mult) continue;
+            const u32 fp = anchor[cid + c0];
+            const int dy = y - (int)(fp >> 16), dx = x - (int)(fp & 0xFFFFu);
+            u64* a = acc + cid * NMOM;
+            atomicAdd(&a[0], (u64)mult);
+            if (max(abs(dx), abs(dy)) <= 150) {          // 4 * 150^4 < 2^31 and every factor < 2^24: 24-bit multiplies
+                const int x2 = __mul24(dx, dx), y2 = __mul24(dy, dy), mx = __mul24(mult, dx), my = __mul24(mult, dy);
+                if (dx) {
+                    atomicAdd(&a[1], (u64)(i64)mx);
+                    atomicAdd(&a[3], (u64)(i64)__mul24(mx, dx));
+                    atomicAdd(&a[6], (u64)(i64)__mul24(mx, x2));
+                    atomicAdd(&a[10], (u64)(i64)__mul24(__mul24(mult, x2), x2));
                 }
-                // the three rows as 66-bit strings {left bit, word, right bit} in dwords, for the 3x3 window of a pixel
-                const u32 u0 = ((u32)up << 1) | upL, u1 = (u32)(up >> 31), u2 = (u32)(up >> 63) | (upR << 1);
-                const u32 m0 = ((u32)B << 1) | bl, m1 = (u32)(B >> 31), m2 = (u32)(B >> 63) | (br << 1);
-                const u32 d0 = ((u32)dn << 1) | dnL, d1 = (u32)(dn >> 31), d2 = (u32)(dn >> 63) | (dnR << 1);
-                u64 mB = B;
-                while (mB) {
-                    const u64 lowbit = mB & (~mB + 1ull);
-                    const u64 t = mB + lowbit;
-                    const u64 g = mB & ~t;
-                    mB &= t;
-                    u64 bg = bgw & g;
-                    if (!bg) continue;
-                    const u32 cid = (P[bcw + (u32)__popcll(stB & ((lowbit << 1) - 1ull)) - 1u] & 0x7FFFu) - c0;
-                    if (cid >= nc) continue;
-                    const u32 fp = anchor[cid + c0];
-                    const int ay = (int)(fp >> 16), ax = (int)(fp & 0xFFFFu);
-                    u64* a = acc + cid * NMOM;
-                    const int dy = y - ay;
-                    while (bg) {
-                        const int k = __ffsll((long long)bg) - 1;
-                        bg &= bg - 1;
-                        const int mult = lut[ccl_win3(u0, u1, u2, k) | (ccl_win3(m0, m1, m2, k) << 3) | (ccl_win3(d0, d1, d2, k) << 6)];
-                        if (!mult) continue;
-                        const int dx = 64 * j + k - ax;
-                        atomicAdd(&a[0], (u64)mult);
-                        if (max(abs(dx), abs(dy)) <= 150) {          // 4 * 150^4 < 2^31 and every factor < 2^23: 24-bit multiplies
-                            const int x2 = __mul24(dx, dx), y2 = __mul24(dy, dy), mx = __mul24(mult, dx), my = __mul24(mult, dy);
-                            if (dx) {
-                                atomicAdd(&a[1], (u64)(i64)mx);
-                                atomicAdd(&a[3], (u64)(i64)__mul24(mx, dx));
-                                atomicAdd(&a[6], (u64)(i64)__mul24(mx, x2));
-                                atomicAdd(&a[10], (u64)(i64)__mul24(__mul24(mult, x2), x2));
-                            }
-                            if (dy) {
-                                atomicAdd(&a[2], (u64)(i64)my);
-                                atomicAdd(&a[5], (u64)(i64)__mul24(my, dy));
-                                atomicAdd(&a[9], (u64)(i64)__mul24(my, y2));
-                                atomicAdd(&a[14], (u64)(i64)__mul24(__mul24(mult, y2), y2));
-                            }
-                            if (dx && dy) {
-                                atomicAdd(&a[4], (u64)(i64)__mul24(mx, dy));
-                                atomicAdd(&a[7], (u64)(i64)__mul24(my, x2));
-                                atomicAdd(&a[8], (u64)(i64)__mul24(mx, y2));
-                                atomicAdd(&a[11], (u64)(i64)__mul24(__mul24(mx, x2), dy));
-                                atomicAdd(&a[12], (u64)(i64)__mul24(__mul24(mult, x2), y2));
-                                atomicAdd(&a[13], (u64)(i64)__mul24(__mul24(mx, dy), y2));
-                            }
-                        } else {
-                            const i64 ml = mult, dl = dx, el = dy, x2 = dl * dl, y2 = el * el;
-                            atomicAdd(&a[1], (u64)(ml * dl));            atomicAdd(&a[2], (u64)(ml * el));
-                            atomicAdd(&a[3], (u64)(ml * x2));            atomicAdd(&a[4], (u64)(ml * dl * el));
-                            atomicAdd(&a[5], (u64)(ml * y2));            atomicAdd(&a[6], (u64)(ml * x2 * dl));
-                            atomicAdd(&a[7], (u64)(ml * x2 * el));       atomicAdd(&a[8], (u64)(ml * dl * y2));
-                            atomicAdd(&a[9], (u64)(ml * y2 * el));       atomicAdd(&a[10], (u64)(ml * x2 * x2));
-                            atomicAdd(&a[11], (u64)(ml * x2 * dl * el)); atomicAdd(&a[12], (u64)(ml * x2 * y2));
-                            atomicAdd(&a[13], (u64)(ml * dl * el * y2)); atomicAdd(&a[14], (u64)(ml * y2 * y2));
-                        }
-                    }
+                if (dy) {
+                    atomicAdd(&a[2], (u64)(i64)my);
+                    atomicAdd(&a[5], (u64)(i64)__mul24(my, dy));
+                    atomicAdd(&a[9], (u64)(i64)__mul24(my, y2));
+                    atomicAdd(&a[14], (u64)(i64)__mul24(__mul24(mult, y2), y2));
                 }
+                if (dx && dy) {
+                    atomicAdd(&a[4], (u64)(i64)__mul24(mx, dy));
+                    atomicAdd(&a[7], (u64)(i64)__mul24(my, x2));
+                    atomicAdd(&a[8], (u64)(i64)__mul24(mx, y2));
+                    atomicAdd(&a[11], (u64)(i64)__mul24(__mul24(mx, x2), dy));
+                    atomicAdd(&a[12], (u64)(i64)__mul24(__mul24(mult, x2), y2));
+                    atomicAdd(&a[13], (u64)(i64)__mul24(__mul24(mx, dy), y2));
+                }
+            } else {
+                const i64 ml_ = mult, dl_ = dx, el_ = dy, x2 = dl_ * dl_, y2 = el_ * el_;
+                atomicAdd(&a[1], (u64)(ml_ * dl_));             atomicAdd(&a[2], (u64)(ml_ * el_));
+                atomicAdd(&a[3], (u64)(ml_ * x2));              atomicAdd(&a[4], (u64)(ml_ * dl_ * el_));
+                atomicAdd(&a[5], (u64)(ml_ * y2));              atomicAdd(&a[6], (u64)(ml_ * x2 * dl_));
+                atomicAdd(&a[7], (u64)(ml_ * x2 * el_));        atomicAdd(&a[8], (u64)(ml_ * dl_ * y2));
+                atomicAdd(&a[9], (u64)(ml_ * y2 * el_));        atomicAdd(&a[10], (u64)(ml_ * x2 * x2));
+                atomicAdd(&a[11], (u64)(ml_ * x2 * dl_ * el_)); atomicAdd(&a[12], (u64)(ml_ * x2 * y2));
+                atomicAdd(&a[13], (u64)(ml_ * dl_ * el_ * y2)); atomicAdd(&a[14], (u64)(ml_ * y2 * y2));
             }
         }
         __syncthreads();
@@ -580,8 +658,10 @@ static bool ccl_layout(const vbs_handle* h, int mode, CclGeom* g, size_t* lds_by
     g->off_cbase = (u32)(2 * cap);
     g->off_acc = (u32)(g->off_cbase + cb);
     g->off_tmp = (u32)(g->off_acc + acc);
+    g->pair_cap = (u32)((mode == 0 ? acc : (size_t)CCL_MOM_COMPS * NMOM * 8) / 4);
+    g->cand_cap = 2u * (u32)h->H * (u32)h->WW;           // the frame's slice of wbase (general path only)
     *lds_bytes = g->off_tmp + misc;
-    return g->items < 65535 && h->W < 65536 && h->H < 65536 && cap >= 1024;
+    return g->items < 65535 && h->W <= 4096 && h->H <= 2048 && cap >= 1024;     // (record: 9 + 11 + 12 bits)
 }
 
 bool launch_ccl(vbs_handle* h, int nb, hipStream_t s) {
@@ -594,9 +674,9 @@ bool launch_ccl(vbs_handle* h, int nb, hipStream_t s) {
         if (l0 > set0) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccl<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l0); set0 = l0; }
         if (l1 > set1) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_ccl<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l1); set1 = l1; }
         VBS_LAUNCH(h, s, "k_ccl_band", k_ccl<0>, dim3(nb), dim3(CCL_NT), l0, s, h->band_bits, h->ncomp, h->band_first,
-                   h->band_sums, h->area_sums, h->probe, h->fstat, h->slow_flag, h->lut, g0, h->maxm);
+                   h->band_sums, h->area_sums, h->probe, h->fstat, h->slow_flag, h->wbase, h->lut, g0, h->maxm);
         VBS_LAUNCH(h, s, "k_ccl_open", k_ccl<1>, dim3(nb), dim3(CCL_NT), l1, s, h->open_bits, h->ncomp, h->area_first,
-                   h->band_sums, h->area_sums, h->probe, h->fstat, h->slow_flag, h->lut, g1, h->maxm);
+                   h->band_sums, h->area_sums, h->probe, h->fstat, h->slow_flag, h->wbase, h->lut, g1, h->maxm);
     }
     return fast;                                         // false: every frame takes the general kernel
 }

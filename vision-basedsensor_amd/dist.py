@@ -70,3 +70,70 @@ def gather_tables(local: torch.Tensor, n_total: int) -> torch.Tensor:
     if all(b - a == nmax for a, b in per):
         return out
     return torch.cat([out[r * nmax:r * nmax + (b - a)] for r, (a, b) in enumerate(per)], dim=0)
+
+
+class TableGather:
+    """All-gather of the per-frame tables issued PASS BY PASS, so that the exchange of one internal pass overlaps the
+    kernels of the next one (RCCL runs on its own stream; `async_op=True` only orders it after the pass that produced
+    the chunk).  Every rank's chunk lands directly in its frames' rows of the final [n_total, M, C] tensor - no
+    re-concatenation, also for ragged shards (a rank that has run out of frames contributes an empty-padded chunk).
+
+        g = TableGather(n_total, M, C, device, chunk)
+        for off in range(0, g.n_max, chunk):
+            g.push(off, local_rows_of_this_pass)        # [<= chunk, M, C], may be empty on a short rank
+        table = g.finish()
+    """
+
+    def __init__(self, n_total: int, m: int, cols: int, device, chunk: int, dtype=torch.float32):
+        self.rank, self.ws = world()
+        self.n_total, self.chunk = int(n_total), int(chunk)
+        self.spans = [shard_bounds(n_total, self.ws, r) for r in range(self.ws)]
+        self.n_max = max(b - a for a, b in self.spans)
+        self.out = torch.empty((n_total, m, cols), dtype=dtype, device=device)
+        self.works = []
+        self._keep = []
+        self.host = self.ws > 1 and td.get_backend() == "gloo" and torch.device(device).type == "cuda"
+
+    def push(self, off: int, local: torch.Tensor):
+        a, b = self.spans[self.rank]
+        if self.ws == 1:
+            self.out[a + off:a + off + local.shape[0]] = local
+            return
+        # rows of this pass per rank (ranks with shorter shards have fewer / none in the last pass)
+        cnt = [max(0, min(self.chunk, (rb - ra) - off)) for ra, rb in self.spans]
+        width = max(cnt)
+        if width == 0:
+            return
+        even = all(c == width for c in cnt)
+        src = local
+        if local.shape[0] != width:                     # ragged end: pad to the pass width
+            src = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+            src[:local.shape[0]] = local
+        if self.host:                                   # gloo rehearsal with device tensors: through the host, synchronous
+            parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(self.ws)]
+            td.all_gather(parts, src.cpu().contiguous())
+            for r, (ra, _) in enumerate(self.spans):
+                if cnt[r]:
+                    self.out[ra + off:ra + off + cnt[r]] = parts[r][:cnt[r]].to(self.out.device)
+            return
+        if even:
+            outs = [self.out[ra + off:ra + off + width] for ra, _ in self.spans]        # contiguous row blocks of the result
+            self.works.append(td.all_gather(outs, src.contiguous(), async_op=True))
+            self._keep.append(src)
+        else:
+            tmp = [torch.empty_like(src) for _ in range(self.ws)]
+            w = td.all_gather(tmp, src.contiguous(), async_op=True)
+            self.works.append(w)
+            self._keep.append((src, tmp, off, cnt))
+
+    def finish(self) -> torch.Tensor:
+        for w in self.works:
+            w.wait()
+        for k in self._keep:
+            if isinstance(k, tuple):
+                _, tmp, off, cnt = k
+                for r, (ra, _) in enumerate(self.spans):
+                    if cnt[r]:
+                        self.out[ra + off:ra + off + cnt[r]] = tmp[r][:cnt[r]]
+        self.works, self._keep = [], []
+        return self.out

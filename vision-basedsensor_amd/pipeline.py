@@ -44,6 +44,32 @@ def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mo
     return _ids.reference_arrays(table)
 
 
+def track_and_gather(eng: Engine, frames_local: torch.Tensor, n_total: int, xy, min_dist=20.0, cam=None,
+                     min_marker_size_px=5.0):
+    """This rank's frames through the fused path, one internal pass (`eng.max_batch` frames) at a time, the all-gather of
+    each pass's rows issued as soon as the pass is enqueued (`dist.TableGather`): the exchange overlaps the next pass.
+    Returns (local table [n_local, M, 10], counts [n_local], gathered table [n_total, M, 10])."""
+    rank, ws = D.world()
+    m = int(np.asarray(xy).reshape(-1, 2).shape[0])
+    n_local = int(frames_local.shape[0])
+    if ws == 1:
+        local, _, counts = eng.track_to_3d(frames_local, xy, min_dist, cam, min_marker_size_px)
+        return local, counts, local
+    g = D.TableGather(n_total, m, L.TABLE_COLS, eng.device, eng.max_batch)
+    a, _ = D.shard_bounds(n_total, ws, rank)
+    counts = torch.zeros((n_local,), dtype=torch.int32, device=eng.device)
+    for off in range(0, g.n_max, eng.max_batch):
+        part = frames_local[off:off + eng.max_batch]
+        if part.shape[0]:
+            t, _, c = eng.track_to_3d(part, xy, min_dist, cam, min_marker_size_px)
+            counts[off:off + part.shape[0]] = c
+        else:                                           # a shorter shard has run out of frames: still joins the collective
+            t = torch.zeros((0, m, L.TABLE_COLS), dtype=torch.float32, device=eng.device)
+        g.push(off, t)
+    table = g.finish()
+    return table[a:a + n_local], counts, table
+
+
 def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None, cam: L.Camera = None,
                 min_dist=20.0, min_marker_size_px=5.0, warmup_frames=0, max_displacement=50.0,
                 num_layers=5, id_mode="full", kmeans="optimal", with_plane=True) -> TrackResult:
@@ -57,8 +83,7 @@ def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None,
         ids, xy = D.broadcast_reference(ids, xy, eng.device)
     else:
         ids, xy = ref
-    local, _, counts = eng.track_to_3d(frames_local, xy, min_dist, cam, min_marker_size_px)
-    table = D.gather_tables(local, n_total)
+    local, counts, table = track_and_gather(eng, frames_local, n_total, xy, min_dist, cam, min_marker_size_px)
     bad = torch.nonzero(counts < 0)            # (after the collective, so a failing rank cannot leave the others waiting in it)
     if bad.numel():
         f = int(bad[0].item())
