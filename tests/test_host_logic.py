@@ -304,6 +304,25 @@ def test_xlsx_parameter_sheets_and_result_sheet(tmp_path):
     assert X.read_rows(tmp_path / "s.xlsx") == [["k"], ["a<b & c"], ["  padded "], [None], [True]]
 
 
+def test_csv_writer_equals_pandas(tmp_path):
+    """`_save_results` writes the batches' columns with its own writer: byte for byte what `df.to_csv(index=False)`
+    (`marker_detection.py:464-468`) writes, including integral floats, exponents, NaN, inf and the empty table."""
+    import pandas as pd
+    from vbs_amd.marker_detection import _write_csv_columns, CSV_COLUMNS
+    rng = np.random.default_rng(1)
+    n = 2000
+    cols = {"frameno": rng.integers(0, 50, n), "row": rng.integers(0, 6, n), "col": rng.integers(0, 24, n)}
+    for c in CSV_COLUMNS[3:]:
+        cols[c] = rng.random(n) * 10.0 ** rng.integers(-8, 8, n)
+    cols["Ox"][0] = 100.0; cols["Oy"][1] = np.nan; cols["Cx"][2] = 1e22; cols["Cy"][3] = np.inf; cols["angle"][4] = -0.0
+    _write_csv_columns(tmp_path / "a.csv", cols)
+    pd.DataFrame(cols, columns=CSV_COLUMNS).to_csv(tmp_path / "b.csv", index=False)
+    assert (tmp_path / "a.csv").read_bytes() == (tmp_path / "b.csv").read_bytes()
+    _write_csv_columns(tmp_path / "e.csv", {c: np.zeros(0) for c in CSV_COLUMNS})
+    pd.DataFrame({c: [] for c in CSV_COLUMNS}, columns=CSV_COLUMNS).to_csv(tmp_path / "f.csv", index=False)
+    assert (tmp_path / "e.csv").read_bytes() == (tmp_path / "f.csv").read_bytes()
+
+
 def test_shard_bounds():
     from vbs_amd.dist import shard_bounds
     for n, w in ((32768, 8), (10, 4), (7, 8), (0, 2)):

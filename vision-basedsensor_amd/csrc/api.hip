@@ -107,6 +107,9 @@ extern "C" int vbs_destroy(vbs_handle* h) {
     if (!h) return VBS_EINVAL;
     (void)hipSetDevice(h->device);
     for (void* p : h->allocs) (void)hipFree(p);
+    if (h->side) (void)hipStreamDestroy(h->side);
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    for (int i = 0; i < 2; ++i) { if (h->ev_gray[i]) (void)hipEventDestroy(h->ev_gray[i]); if (h->ev_free[i]) (void)hipEventDestroy(h->ev_free[i]); }
     delete h;
     return VBS_OK;
 }
@@ -149,7 +152,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     const size_t B = (size_t)max_batch, HW = (size_t)height * h->WW, HP = (size_t)height * h->P;
     int rc;
 #define ALLOC(field, count) if ((rc = dev_alloc(h, &h->field, (count))) != VBS_OK) return rc
-    ALLOC(gray, B * HP);
+    ALLOC(gray, B * HP); ALLOC(gray2, B * HP);
     ALLOC(area_bits, B * HW); ALLOC(mask_bits, B * HW); ALLOC(band_bits, B * HW);
     ALLOC(open_bits, B * HW);
     ALLOC(ncc_rx, (size_t)width); ALLOC(ncc_ry, (size_t)height);
@@ -192,6 +195,12 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
         HIPCHK(h, hipMemcpy(h->uwtab, wt.data(), 4096 * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     HIPCHK(h, hipMemset(h->ncc_tot, 0, 4 * sizeof(u64)));
+    HIPCHK(h, hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking));
+    HIPCHK(h, hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+    for (int i = 0; i < 2; ++i) {
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_gray[i], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->ev_free[i], hipEventDisableTiming));
+    }
     HIPCHK(h, hipDeviceSynchronize());
     return VBS_OK;
 }
@@ -202,24 +211,64 @@ static int check_launch(vbs_handle* h) {
     return VBS_OK;
 }
 
+// One internal pass of the detection stage.  `pre` = gray plane already converted for this pass (vbs_detect_loop's
+// side-stream pipeline), else the conversion runs here on `s`.
 static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
-                       int64_t stride_row, u8* mask_u8, u8* area_u8, double* ncc_out, hipStream_t s) {
+                       int64_t stride_row, u8* mask_u8, u8* area_u8, double* ncc_out, hipStream_t s, const u8* pre = nullptr) {
     HIPCHK(h, hipMemsetAsync(h->fstat, 0, (size_t)nb * 8 * sizeof(u32), s));
-    if (h->undist) {                                    // marker_detection.py:88-89: undistort, then cvtColor
+    if (pre) {
+        launch_blur(h, pre, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
+    } else if (h->undist) {                             // marker_detection.py:88-89: undistort, then cvtColor
         launch_remap(h, frames, nb, channels, stride_n, stride_row, h->gray, 1, s);
         launch_blur(h, h->gray, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
     } else if (channels == 1) {
         launch_blur(h, frames, stride_n, stride_row, nb, area_u8, s);
-    } else if (blur_bgr_direct(h, frames, stride_n, stride_row)) {
-        launch_blur(h, frames, stride_n, stride_row, nb, area_u8, s, true);      // cvtColor inside the blur's loader
-    } else {                                            // rows not 16-byte aligned (odd crops): gray plane first
-        launch_gray(h, frames, nb, channels, stride_n, stride_row, s);
+    } else {
+        launch_gray(h, frames, nb, channels, stride_n, stride_row, h->gray, s);
         launch_blur(h, h->gray, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
     }
     launch_ncc(h, nb, mask_u8, ncc_out, s);
     launch_stat_accum(h, nb, s);
     return check_launch(h);
 }
+
+// BGR frames over several internal passes: cvtColor of pass k + 1 runs on the handle's side stream while pass k's
+// kernels run on `s` (two gray planes; fork / join by events, so a caller may capture the whole call in a graph).
+struct GrayPipe {
+    vbs_handle* h; const u8* frames; int n, channels; int64_t stride_n, stride_row; hipStream_t s;
+    bool on;
+    int start() {
+        on = !h->undist && channels == 3 && n > h->maxb;
+        if (!on) return VBS_OK;
+        HIPCHK(h, hipEventRecord(h->ev_fork, s));
+        HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
+        return convert(0);
+    }
+    int convert(int k) {                                // pass k -> plane k & 1, on the side stream
+        const int off = k * h->maxb, nb = std::min(h->maxb, n - off);
+        launch_gray(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, k & 1 ? h->gray2 : h->gray, h->side);
+        HIPCHK(h, hipEventRecord(h->ev_gray[k & 1], h->side));
+        return VBS_OK;
+    }
+    // before pass k's blur: its plane is ready; the next pass's conversion may start once ITS plane is free again
+    int acquire(int k, const u8** plane) {
+        *plane = nullptr;
+        if (!on) return VBS_OK;
+        HIPCHK(h, hipStreamWaitEvent(s, h->ev_gray[k & 1], 0));
+        if ((k + 1) * h->maxb < n) {
+            if (k >= 1) HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_free[(k + 1) & 1], 0));
+            int rc = convert(k + 1);
+            if (rc != VBS_OK) return rc;
+        }
+        *plane = k & 1 ? h->gray2 : h->gray;
+        return VBS_OK;
+    }
+    int release(int k) {                                // after pass k's blur has been enqueued
+        if (!on) return VBS_OK;
+        HIPCHK(h, hipEventRecord(h->ev_free[k & 1], s));
+        return VBS_OK;
+    }
+};
 
 extern "C" int vbs_find_markers(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
                                 int64_t stride_row, uint8_t* mask, uint8_t* area_mask, void* stream) {
@@ -231,12 +280,17 @@ extern "C" int vbs_find_markers(vbs_handle* h, const uint8_t* frames, int n, int
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t hw = (size_t)h->H * h->W;
-    for (int off = 0; off < n; off += h->maxb) {
+    GrayPipe gp{h, frames, n, channels, stride_n, stride_row, s, false};
+    int rc = gp.start();
+    if (rc != VBS_OK) return rc;
+    for (int off = 0, k = 0; off < n; off += h->maxb, ++k) {
         int nb = std::min(h->maxb, n - off);
-        int rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row,
-                             mask ? mask + off * hw : nullptr, area_mask ? area_mask + off * hw : nullptr,
-                             nullptr, s);
+        const u8* plane;
+        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return rc;
+        rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row,
+                         mask ? mask + off * hw : nullptr, area_mask ? area_mask + off * hw : nullptr, nullptr, s, plane);
         if (rc != VBS_OK) return rc;
+        if ((rc = gp.release(k)) != VBS_OK) return rc;
     }
     return VBS_OK;
 }
@@ -260,11 +314,17 @@ extern "C" int vbs_ncc_map(vbs_handle* h, const uint8_t* frames, int n, int chan
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(h, hipSetDevice(h->device));
     const size_t hw = (size_t)h->H * h->W;
-    for (int off = 0; off < n; off += h->maxb) {
+    GrayPipe gp{h, frames, n, channels, stride_n, stride_row, s, false};
+    int rc = gp.start();
+    if (rc != VBS_OK) return rc;
+    for (int off = 0, k = 0; off < n; off += h->maxb, ++k) {
         int nb = std::min(h->maxb, n - off);
-        int rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr,
-                             nullptr, ncc + off * hw, s);
+        const u8* plane;
+        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return rc;
+        rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr, nullptr,
+                         ncc + off * hw, s, plane);
         if (rc != VBS_OK) return rc;
+        if ((rc = gp.release(k)) != VBS_OK) return rc;
     }
     return VBS_OK;
 }
@@ -466,11 +526,17 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
     if (cam) { int rc = check_cam(h, cam); if (rc != VBS_OK) return rc; }
     hipStream_t s = (hipStream_t)stream;
     HIPCHK(h, hipSetDevice(h->device));
-    for (int off = 0; off < n; off += h->maxb) {
+    GrayPipe gp{h, frames, n, channels, stride_n, stride_row, s, false};
+    int rc = gp.start();
+    if (rc != VBS_OK) return rc;
+    for (int off = 0, k = 0; off < n; off += h->maxb, ++k) {
         int nb = std::min(h->maxb, n - off);
-        int rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr,
-                             nullptr, nullptr, s);
+        const u8* plane;
+        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return rc;
+        rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr, nullptr, nullptr,
+                         s, plane);
         if (rc != VBS_OK) return rc;
+        if ((rc = gp.release(k)) != VBS_OK) return rc;
         launch_morph(h, nb, s);
         launch_label(h, nb, s);
         launch_finalize(h, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr,

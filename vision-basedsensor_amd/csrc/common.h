@@ -55,7 +55,10 @@ struct vbs_handle {
     NccConst ncc;
     std::string err;
     // ---- device workspace (per internal pass of maxb frames) ----
-    u8* gray;          // [maxb][H][P]
+    u8* gray;          // [maxb][H][P]   gray plane of 3-channel / undistorted input
+    u8* gray2;         // second plane: the conversion of pass k + 1 runs on `side` while pass k computes
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_gray[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     uint4* blur_frags; // Toeplitz operand fragments of k_blur_mfma (blur_mfma_fragments)
     u64* area_bits;    // [maxb][H][WW]
     u64* mask_bits;    // [maxb][H][WW]
@@ -112,12 +115,11 @@ struct vbs_handle {
 
 // ---- launchers (each enqueues on `s`; nb = frames in this pass) --------------------------------
 void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
-                 int64_t stride_row, hipStream_t s);
+                 int64_t stride_row, u8* gray, hipStream_t s);
 void launch_gray_dense(vbs_handle* h, const u8* frames, int nb, int64_t stride_n, int64_t stride_row, u8* out,
                        hipStream_t s);
 void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,
-                 u8* area_u8, hipStream_t s, bool bgr = false);
-bool blur_bgr_direct(const vbs_handle* h, const u8* frames, int64_t stride_n, int64_t stride_row);
+                 u8* area_u8, hipStream_t s);
 void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t s);
 void launch_points(int which, const double* in, int n, const vbs_camera& cam, double* out, int32_t* ok,
                    hipStream_t s);

@@ -16,15 +16,39 @@ __device__ __forceinline__ int reflect101(int i, int n) {
     return min(max(i, 0), n - 1);
 }
 
-__global__ void k_gray(const u8* __restrict__ frames, int channels, int64_t stride_n,
-                       int64_t stride_row, u8* __restrict__ gray, int H, int W, int P, GrayCoef gc) {
-    int x4 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-    int y = blockIdx.y, n = blockIdx.z;
-    if (x4 >= P) return;
+// gray pixels of 4 consecutive BGR pixels (12 bytes as 3 dwords): cv2's fixed-point weights (common.h gray_coef)
+__device__ __forceinline__ u32 bgr4_to_gray(u32 a, u32 b, u32 c, const GrayCoef& gc) {
+    const u32 g0 = (gc.cb * (a & 255u) + gc.cg * ((a >> 8) & 255u) + gc.cr * ((a >> 16) & 255u) + gc.half) >> gc.shift;
+    const u32 g1 = (gc.cb * (a >> 24) + gc.cg * (b & 255u) + gc.cr * ((b >> 8) & 255u) + gc.half) >> gc.shift;
+    const u32 g2 = (gc.cb * ((b >> 16) & 255u) + gc.cg * (b >> 24) + gc.cr * (c & 255u) + gc.half) >> gc.shift;
+    const u32 g3 = (gc.cb * ((c >> 8) & 255u) + gc.cg * ((c >> 16) & 255u) + gc.cr * (c >> 24) + gc.half) >> gc.shift;
+    return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
+}
+
+// cvtColor(BGR2GRAY) (or a plain copy for 1 channel) into the pitched gray plane the blur reads: a streaming kernel,
+// 16 pixels per thread (three 16-byte loads, one 16-byte store) when the rows are 16-byte aligned.  The product path
+// runs it on the handle's side stream one internal pass ahead of the matrix-core kernels (api.hip), which leave the
+// HBM idle: a BGR frame then costs its 3 H W bytes of read, hidden behind the blur / NCC of the previous pass.
+// (Converting inside the blur's own loader was built and measured: LDS-DMA staging of the raw bytes kept the matrix
+//  operands in registers only at the price of 50 spilled VGPRs - 5 us per frame against 1.45.)
+__global__ __launch_bounds__(256) void k_gray(const u8* __restrict__ frames, int channels, int64_t stride_n,
+                                              int64_t stride_row, u8* __restrict__ gray, int H, int W, int P, GrayCoef gc,
+                                              int vec_ok) {
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 16;
+    const int y = blockIdx.y, n = blockIdx.z;
+    if (x0 >= P) return;
     const u8* src = frames + (int64_t)n * stride_n + (int64_t)y * stride_row;
-    u32 out = 0;
-    for (int k = 0; k < 4; ++k) {
-        int x = x4 + k;
+    u8* dst = gray + ((int64_t)n * H + y) * P + x0;
+    if (vec_ok && channels == 3 && x0 + 16 <= W) {
+        const uint4* s4 = reinterpret_cast<const uint4*>(src + (int64_t)x0 * 3);
+        const uint4 r0 = s4[0], r1 = s4[1], r2 = s4[2];
+        *reinterpret_cast<uint4*>(dst) = make_uint4(bgr4_to_gray(r0.x, r0.y, r0.z, gc), bgr4_to_gray(r0.w, r1.x, r1.y, gc),
+                                                    bgr4_to_gray(r1.z, r1.w, r2.x, gc), bgr4_to_gray(r2.y, r2.z, r2.w, gc));
+        return;
+    }
+    u32 out[4] = {0, 0, 0, 0};
+    for (int k = 0; k < 16; ++k) {
+        const int x = x0 + k;
         u32 v = 0;
         if (x < W) {
             if (channels == 1) {
@@ -34,9 +58,9 @@ __global__ void k_gray(const u8* __restrict__ frames, int channels, int64_t stri
                 v = (gc.cb * p[0] + gc.cg * p[1] + gc.cr * p[2] + gc.half) >> gc.shift;
             }
         }
-        out |= v << (8 * k);
+        out[k >> 2] |= v << (8 * (k & 3));
     }
-    *reinterpret_cast<u32*>(gray + ((int64_t)n * H + y) * P + x4) = out;
+    *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 // the cvtColor stage on its own (vbs_bgr2gray): dense [n,H,W] output, one pixel per thread
@@ -98,37 +122,18 @@ __device__ __forceinline__ uint4 fetch_chunk_slow(const u8* src, int px, int W) 
     return make_uint4(w[0], w[1], w[2], w[3]);
 }
 
-// gray pixels of 4 consecutive BGR pixels (12 bytes as 3 dwords): cv2's fixed-point weights (common.h gray_coef)
-__device__ __forceinline__ u32 bgr4_to_gray(const u32* d, const GrayCoef& gc) {
-    const u32 a = d[0], b = d[1], c = d[2];
-    const u32 g0 = (gc.cb * (a & 255u) + gc.cg * ((a >> 8) & 255u) + gc.cr * ((a >> 16) & 255u) + gc.half) >> gc.shift;
-    const u32 g1 = (gc.cb * (a >> 24) + gc.cg * (b & 255u) + gc.cr * ((b >> 8) & 255u) + gc.half) >> gc.shift;
-    const u32 g2 = (gc.cb * ((b >> 16) & 255u) + gc.cg * (b >> 24) + gc.cr * (c & 255u) + gc.half) >> gc.shift;
-    const u32 g3 = (gc.cb * ((c >> 8) & 255u) + gc.cg * ((c >> 16) & 255u) + gc.cr * (c >> 24) + gc.half) >> gc.shift;
-    return g0 | (g1 << 8) | (g2 << 16) | (g3 << 24);
-}
-
-// CH3: the frames are 3-channel BGR and cvtColor (marker_detection.py:114) happens in the loader: every wave brings the
-// raw bytes of its own 8 rows of the next tile into LDS by LDS-DMA (global_load_lds, no registers held across the
-// matrix work), waits for its own DMA only, converts them and writes the gray tile the A operands are read from.  No
-// gray plane in HBM: a BGR frame is read once (3 H W bytes) instead of 3 H W + 2 H W.  Needs 16-byte aligned rows
-// (launch_blur falls back to k_gray + the gray kernel otherwise).
-template <int NK, int SA0, int NKA, bool U8OUT, bool CH3>
+template <int NK, int SA0, int NKA, bool U8OUT>
 __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gray, int64_t gstride_n,
                                                       int64_t gstride_row, const uint4* __restrict__ frags,
                                                       u64* __restrict__ bits, u8* __restrict__ area_u8,
                                                       u32* __restrict__ fstat, int H, int W, int WW,
-                                                      int tiles_per_seg, int k3, int k8, int span_i, GrayCoef gc) {
+                                                      int tiles_per_seg, int k3, int k8, int span_i) {
     constexpr int LEFT = 32 * ((NK - 1) / 2);
     constexpr int ROWB = 128 + 32 * (NK - 1);          // bytes staged per image row
     constexpr int CH = ROWB / 16;
     constexpr int STRIDE = ROWB + 16;                  // 68 (52) dwords: 16 consecutive rows hit all banks
     constexpr int NIT = (32 * CH + 255) / 256;
-    constexpr int RAWROW = 3 * ROWB;                   // raw BGR bytes per staged row
-    constexpr int NPIECE = 8 * RAWROW / 16;            // 16-byte pieces of a wave's 8 raw rows
-    constexpr int NDMA = CH3 ? (NPIECE + 63) / 64 : 0; // LDS-DMA instructions (<= 1 KB each) per wave and tile
     __shared__ __align__(16) u8 tile[2][32 * STRIDE];
-    __shared__ __align__(16) u8 raw[CH3 ? 32 * RAWROW : 16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hh = lane >> 5, m = lane & 31;
     const int X0 = blockIdx.x * 128, n = blockIdx.z;
@@ -160,37 +165,18 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         int c = tid + 256 * it;
-        if (CH3) c = 8 * CH * wave + lane + 64 * it;    // the chunks of this wave's own rows 8 wave .. 8 wave + 7
-        c_on[it] = CH3 ? (lane + 64 * it < 8 * CH) : (c < 32 * CH);
+        c_on[it] = c < 32 * CH;
         c_row[it] = c / CH;
         int ch = c - c_row[it] * CH;
         c_px[it] = X0 - LEFT + 16 * ch;
         c_lds[it] = c_row[it] * STRIDE + 16 * ch;
         c_fast[it] = aligned && c_px[it] >= 0 && c_px[it] + 16 <= W;
     }
-    static_assert(!CH3 || NIT * 64 >= 8 * CH, "a wave's 8 rows must fit its lanes' chunks");
     // plain chunks are loaded a step ahead into registers and written to LDS at the end of the step; border chunks
     // (few, only in the first / last workgroup of a row) are gathered byte by byte at commit time
     uint4 stage[NIT];
     auto row_of = [&](int t, int it) { return g + (int64_t)reflect101(Y0 - LEFT + 32 * t + c_row[it], H) * gstride_row; };
     auto fetch = [&](int t) {
-        if (CH3) {
-            // raw bytes of rows 8 wave .. 8 wave + 7 of tile t: piece p (16 bytes) of the wave = row p / (RAWROW / 16),
-            // byte offset 16 (p % (RAWROW / 16)); source columns outside the image are clamped (those chunks are
-            // gathered with reflection at commit time and never read from `raw`)
-#pragma unroll
-            for (int q = 0; q < NDMA; ++q) {
-                const int p = 64 * q + lane, r = p / (RAWROW / 16), o = 16 * (p - r * (RAWROW / 16));
-                if (NPIECE % 64 != 0 && p >= NPIECE) continue;      // (the last instruction may be partial)
-                const int64_t col = (int64_t)(X0 - LEFT) * 3 + o;
-                const int64_t colc = col < 0 ? 0 : (col + 16 > (int64_t)W * 3 ? (int64_t)W * 3 - 16 : col);
-                const u8* src = g + (int64_t)reflect101(Y0 - LEFT + 32 * t + 8 * wave + r, H) * gstride_row + colc;
-                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) u32*)src,
-                                                 (__attribute__((address_space(3))) u32*)(&raw[(8 * wave) * RAWROW + 1024 * q]),
-                                                 16, 0, 0);
-            }
-            return;
-        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
             if (c_on[it] && c_fast[it]) {
@@ -199,42 +185,9 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
             }
     };
     auto commit = [&](int t, int buf) {
-        if (CH3) __builtin_amdgcn_s_waitcnt(0x0F70);       // vmcnt(0): this wave's DMA of tile t has landed
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             if (!c_on[it]) continue;
-            if (CH3) {
-                uint4 v;
-                if (c_fast[it]) {
-                    // 4 pixels (12 raw bytes) at a time, so that few registers are live next to the matrix operands
-                    const u32* r32 = reinterpret_cast<const u32*>(&raw[c_row[it] * RAWROW + 3 * (c_lds[it] - c_row[it] * STRIDE)]);
-                    u32 o4[4];
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const u32 d3[3] = {r32[3 * q], r32[3 * q + 1], r32[3 * q + 2]};
-                        o4[q] = bgr4_to_gray(d3, gc);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    v = make_uint4(o4[0], o4[1], o4[2], o4[3]);
-                } else {                                   // image border: byte gather with reflect-101
-                    const u8* rp = row_of(t, it);
-                    u32 w4[4];
-#pragma unroll
-                    for (int dd = 0; dd < 4; ++dd) {
-                        u32 acc4 = 0;
-#pragma unroll
-                        for (int b = 0; b < 4; ++b) {
-                            const u8* px = rp + (int64_t)reflect101(c_px[it] + 4 * dd + b, W) * 3;
-                            acc4 |= ((gc.cb * px[0] + gc.cg * px[1] + gc.cr * px[2] + gc.half) >> gc.shift) << (8 * b);
-                        }
-                        w4[dd] = acc4;
-                    }
-                    v = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-                }
-                v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
-                *reinterpret_cast<uint4*>(&tile[buf][c_lds[it]]) = v;
-                continue;
-            }
             if (c_fast[it]) {
                 uint4 v = stage[it];
                 v.x ^= 0x80808080u; v.y ^= 0x80808080u; v.z ^= 0x80808080u; v.w ^= 0x80808080u;
@@ -371,36 +324,26 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 
 
 void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
-                 int64_t stride_row, hipStream_t s) {
-    dim3 grid((h->P / 4 + 255) / 256, h->H, nb);
-    VBS_LAUNCH(h, s, "k_gray", k_gray, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row, h->gray,
-                       h->H, h->W, h->P, gray_coef(h->gray_bits));
+                 int64_t stride_row, u8* gray, hipStream_t s) {
+    dim3 grid((h->P / 16 + 255) / 256, h->H, nb);
+    const int vec_ok = (reinterpret_cast<uintptr_t>(frames) % 16 == 0) && (stride_n % 16 == 0) && (stride_row % 16 == 0);
+    VBS_LAUNCH(h, s, "k_gray", k_gray, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row, gray,
+                       h->H, h->W, h->P, gray_coef(h->gray_bits), vec_ok);
 }
 
 void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,
-                 u8* area_u8, hipStream_t s, bool bgr) {
+                 u8* area_u8, hipStream_t s) {
     const int gx = (h->P + 127) / 128, tilesY = (h->H + 31) / 32;
     int nseg = std::min(tilesY, std::max(1, (1024 + gx * nb - 1) / (gx * nb)));     // few frames: split columns
     const int tps = (tilesY + nseg - 1) / nseg;
     nseg = (tilesY + tps - 1) / tps;
     dim3 grid(gx, nseg, nb);
     const int k3 = 256 * (128 + 32768) + 32768, k8 = k3 + (15 - h->bp.thresh) * 65536;
-    const GrayCoef gc = gray_coef(h->gray_bits);
-#define BLUR_GO(NK, SA0, NKA, U8, C3)                                                                            \
-    VBS_LAUNCH(h, s, C3 ? "k_blur_mfma_bgr" : "k_blur_mfma", (k_blur_mfma<NK, SA0, NKA, U8, C3>), grid, dim3(256), 0, s, gray, \
-               gstride_n, gstride_row, h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, \
-               h->bp.hi - h->bp.thresh, gc)
-    if (bgr) {
-        if (!h->bp.small) { if (area_u8) BLUR_GO(5, 1, 3, true, true); else BLUR_GO(5, 1, 3, false, true); }
-        else { if (area_u8) BLUR_GO(3, 0, 3, true, true); else BLUR_GO(3, 0, 3, false, true); }
-    } else {
-        if (!h->bp.small) { if (area_u8) BLUR_GO(5, 1, 3, true, false); else BLUR_GO(5, 1, 3, false, false); }
-        else { if (area_u8) BLUR_GO(3, 0, 3, true, false); else BLUR_GO(3, 0, 3, false, false); }
-    }
+#define BLUR_GO(NK, SA0, NKA, U8)                                                                            \
+    VBS_LAUNCH(h, s, "k_blur_mfma", (k_blur_mfma<NK, SA0, NKA, U8>), grid, dim3(256), 0, s, gray, gstride_n, \
+               gstride_row, h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8,  \
+               h->bp.hi - h->bp.thresh)
+    if (!h->bp.small) { if (area_u8) BLUR_GO(5, 1, 3, true); else BLUR_GO(5, 1, 3, false); }
+    else { if (area_u8) BLUR_GO(3, 0, 3, true); else BLUR_GO(3, 0, 3, false); }
 #undef BLUR_GO
-}
-
-// can the blur kernel read these BGR frames itself (LDS-DMA of 16-byte pieces)?
-bool blur_bgr_direct(const vbs_handle* h, const u8* frames, int64_t stride_n, int64_t stride_row) {
-    return (reinterpret_cast<uintptr_t>(frames) % 16 == 0) && (stride_n % 16 == 0) && (stride_row % 16 == 0) && h->W * 3 >= 16;
 }

@@ -71,6 +71,23 @@ def _det_to_markers(det, count):
              "angle": float(r[4])} for r in det[:count]]
 
 
+def _write_csv_columns(path, cols):
+    """`DataFrame(cols).to_csv(path, index=False)`, byte for byte (shortest round-trip floats via repr, empty cell for
+    NaN), several times faster than pandas' writer on the ~170 rows per frame this path produces."""
+    text = []
+    for c in CSV_COLUMNS:
+        v = np.asarray(cols[c])
+        if v.dtype.kind == "f":
+            text.append(["" if x != x else repr(x) for x in v.tolist()])
+        else:
+            text.append(list(map(str, v.tolist())))
+    with open(path, "w", newline="") as f:
+        f.write(",".join(CSV_COLUMNS) + "\n")
+        f.write("\n".join(map(",".join, zip(*text))))
+        if len(text[0]):
+            f.write("\n")
+
+
 class _RowBlock:
     """The CSV rows of one device batch as columns (NumPy arrays); iterates / indexes as the reference's row dicts."""
 
@@ -349,10 +366,10 @@ class MarkerTracker:
         if isinstance(data, _Rows):
             data = data.blocks
         if data and all(isinstance(b, _RowBlock) for b in data):
-            df = pd.DataFrame({c: np.concatenate([b.cols[c] for b in data]) for c in CSV_COLUMNS}, columns=CSV_COLUMNS)
+            _write_csv_columns(self.output_csv, {c: np.concatenate([b.cols[c] for b in data]) for c in CSV_COLUMNS})
         else:
             df = pd.DataFrame(list(data), columns=CSV_COLUMNS if not data else None)
-        df.to_csv(self.output_csv, index=False)
+            df.to_csv(self.output_csv, index=False)
         print(f"Saved tracking data to {self.output_csv}")
 
     def _cleanup(self):
