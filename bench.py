@@ -139,8 +139,10 @@ def host_path_fps(spec, n, seed, batch):
     import tempfile
     import vbs_amd.synth as S
     from vbs_amd.marker_detection import MarkerTracker
+    import contextlib
     frames = S.make_frames(spec, range(n), seed=seed)
-    with tempfile.TemporaryDirectory() as td_:
+    # (the drop-in prints progress lines like the reference does: keep stdout for the ONE JSON line)
+    with tempfile.TemporaryDirectory() as td_, contextlib.redirect_stdout(sys.stderr):
         clip = os.path.join(td_, "clip.npy")
         open(clip, "wb").close()                           # `video_path` must exist; frames are passed in memory
         out = {}
@@ -294,7 +296,7 @@ def main():
 
     # ---- the same workload on BGR frames (the reference's input format; gray stays the headline) ----------------------
     if args.channels == 1 and not args.no_extras:
-        nb_ = min(n_local, 1024)
+        nb_ = min(n_local, 2048)
         fb = as_bgr(gray[:nb_])
         n_keep = n_total
         # (single-rank side measurement on rank 0's device; the other ranks wait at the barrier below)

@@ -33,9 +33,32 @@ __device__ __forceinline__ u32 bgr4_to_gray(u32 a, u32 b, u32 c, const GrayCoef&
 //  operands in registers only at the price of 50 spilled VGPRs - 5 us per frame against 1.45.)
 __global__ __launch_bounds__(256) void k_gray(const u8* __restrict__ frames, int channels, int64_t stride_n,
                                               int64_t stride_row, u8* __restrict__ gray, int H, int W, int P, GrayCoef gc,
-                                              int vec_ok) {
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 16;
-    const int y = blockIdx.y, n = blockIdx.z;
+                                              int vec_ok, int flat) {
+    __shared__ __align__(16) uint4 raw[3 * 256];        // 12 KB: the 48 bytes of each thread's 16 pixels, loaded coalesced
+    const int n = blockIdx.z;
+    if (flat) {
+        // dense BGR frame (row stride 3 W, gray pitch W): one run of H W pixels, 4096 per block, loaded as consecutive
+        // 16-byte pieces by consecutive lanes and handed to their owners through LDS
+        const int64_t npx = (int64_t)H * W, pb = (int64_t)blockIdx.x * 4096, p0 = pb + threadIdx.x * 16;
+        const u8* src = frames + (int64_t)n * stride_n;
+        u8* dst = gray + (int64_t)n * H * P + p0;
+        uint4 r0, r1, r2;
+        if (pb + 4096 <= npx) {                          // block-uniform
+            const uint4* s4 = reinterpret_cast<const uint4*>(src + pb * 3);
+#pragma unroll
+            for (int q = 0; q < 3; ++q) raw[q * 256 + threadIdx.x] = s4[q * 256 + threadIdx.x];
+            __syncthreads();
+            r0 = raw[3 * threadIdx.x]; r1 = raw[3 * threadIdx.x + 1]; r2 = raw[3 * threadIdx.x + 2];
+        } else {
+            if (p0 >= npx) return;                       // (H W is a multiple of 16 in flat mode)
+            const uint4* s4 = reinterpret_cast<const uint4*>(src + p0 * 3);
+            r0 = s4[0]; r1 = s4[1]; r2 = s4[2];
+        }
+        *reinterpret_cast<uint4*>(dst) = make_uint4(bgr4_to_gray(r0.x, r0.y, r0.z, gc), bgr4_to_gray(r0.w, r1.x, r1.y, gc),
+                                                    bgr4_to_gray(r1.z, r1.w, r2.x, gc), bgr4_to_gray(r2.y, r2.z, r2.w, gc));
+        return;
+    }
+    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 16, y = blockIdx.y;
     if (x0 >= P) return;
     const u8* src = frames + (int64_t)n * stride_n + (int64_t)y * stride_row;
     u8* dst = gray + ((int64_t)n * H + y) * P + x0;
@@ -325,10 +348,11 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 
 void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
                  int64_t stride_row, u8* gray, hipStream_t s) {
-    dim3 grid((h->P / 16 + 255) / 256, h->H, nb);
     const int vec_ok = (reinterpret_cast<uintptr_t>(frames) % 16 == 0) && (stride_n % 16 == 0) && (stride_row % 16 == 0);
+    const int flat = vec_ok && channels == 3 && stride_row == (int64_t)h->W * 3 && h->P == h->W && ((int64_t)h->H * h->W) % 16 == 0;
+    dim3 grid = flat ? dim3((unsigned)(((int64_t)h->H * h->W + 4095) / 4096), 1, nb) : dim3((h->P / 16 + 255) / 256, h->H, nb);
     VBS_LAUNCH(h, s, "k_gray", k_gray, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row, gray,
-                       h->H, h->W, h->P, gray_coef(h->gray_bits), vec_ok);
+                       h->H, h->W, h->P, gray_coef(h->gray_bits), vec_ok, flat);
 }
 
 void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,

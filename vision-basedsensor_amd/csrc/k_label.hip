@@ -211,7 +211,7 @@ void launch_morph(vbs_handle* h, int nb, hipStream_t s) {
     // strips per frame: enough waves to fill the chip several times over, but strips much longer than the ns - 1 rows
     // each re-reads
     int wpf = (8192 + nb - 1) / nb;                      // waves per frame for ~8192 waves in flight
-    wpf = std::max(1, std::min(wpf, h->H / (4 * h->bp.ns) / G));
+    wpf = std::max(1, std::min(wpf, h->H / (2 * h->bp.ns) / G));      // strips of at least 2 ns rows
     const int strips = wpf * G, rps = (h->H + strips - 1) / strips;
     const int waves = nb * wpf;
     dim3 grid((waves + 3) / 4);

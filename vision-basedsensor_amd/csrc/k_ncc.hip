@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
                                                      u64* __restrict__ mbits, u8* __restrict__ mask_u8,
                                                      u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
-                                                     NccConst nc) {
+                                                     int dbg, NccConst nc) {
     constexpr int HI = L - 1 + LO;
     constexpr int NT = (16 + L - 1 + 15) / 16;          // horizontal tiles under one output tile
     constexpr int NKS = (16 * NT + 31) / 32;            // k-steps of 32
@@ -374,11 +374,13 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
             ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, one[s], ac, 0, 0, 0);
         }
         {
+            // hi = the float32 cut to float16's 10 mantissa bits (exact in float16: 0.25 <= h <= 1024), lo = the rest
             h4 vh, vl, vc;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                vh[r] = (_Float16)ah[r];
-                vl[r] = (_Float16)(ah[r] - (float)vh[r]);
+                const float hi_f = __uint_as_float(__float_as_uint(ah[r]) & 0xFFFFE000u);
+                vh[r] = (_Float16)hi_f;
+                vl[r] = (_Float16)(ah[r] - hi_f);
                 vc[r] = (_Float16)ac[r];
             }
             const int ro = 16 * (t % NT) + 4 * g;
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
             *reinterpret_cast<h4*>(rlo + ro) = vl;
             *reinterpret_cast<h4*>(rct + ro) = vc;
         }
-        if (t < NT - 1) continue;
+        if (t < NT - 1 || dbg == 3) continue;            // (dbg: tools/ phase timing, always 0 in the product library)
         // ---- vertical: output tile rows yo .. yo + 15 from ring tiles t-NT+1 .. t ----
         const int yo = Y0 + 16 * (t - (NT - 1));
         const int base = 16 * ((t - (NT - 1)) % NT);
@@ -406,6 +408,7 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
             G = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[s], bh, G, 0, 0, 0);
             C = __builtin_amdgcn_mfma_f32_16x16x32_f16(one[s], bc, C, 0, 0, 0);
         }
+        if (dbg == 2) { asm volatile("" :: "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(C[0]), "v"(C[1]), "v"(C[2]), "v"(C[3])); continue; }
         // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
         const int x = xw + q;
         const bool interior = (yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
@@ -438,24 +441,25 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
             }
         }
         const bool allvalid = (yo + 15 < H) && (xw + 15 < W);   // uniform
-        u64 pw[4], uw[4], any = 0;
+        // pw[r]: 64-bit masks (wave-uniform, kept in scalar registers) of the pixels decided foreground, bit = lane
+        u64 pw[4];
+        u32 ubits = 0;                                   // bit r: this lane's pixel r is neither above theta (1 + e) nor below theta (1 - e)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const float m = __builtin_fmaf(fabsf(th[r]), rel, abs_), d = G[r] - th[r];
-            const u64 pb = __ballot(d > m), fb = __ballot(d < -m);
-            const u64 vm = allvalid ? ~0ull : __ballot((yo + 4 * g + r < H) && (x < W));
-            pw[r] = pb & vm;
-            uw[r] = ~pb & ~fb & vm;                      // neither above theta (1 + e) nor below theta (1 - e)
-            any |= uw[r];
+            const bool v = allvalid || ((yo + 4 * g + r < H) && (x < W));
+            pw[r] = __ballot((d > m) && v);
+            ubits |= (!(d > m) && !(d < -m) && v) ? (1u << r) : 0u;
         }
-        if (any) {
+        if (__ballot(ubits != 0)) {
             // Rare (a handful of pixels per frame): exact float64 G straight from the bits, one pixel at a time by the
             // whole wave: lane i sums rows i and i + 64 of the window from their runs, then the L products are added
-            // in ascending row order exactly as ncc_exact_G does.
-#pragma unroll 1
+            // in ascending row order exactly as ncc_exact_G does.  Every lane computes the same numbers; the decision is
+            // made wave-uniform explicitly so that the masks stay in scalar registers.
+#pragma unroll
             for (int r = 0; r < 4; ++r) {
-                u64 ur = r == 0 ? uw[0] : r == 1 ? uw[1] : r == 2 ? uw[2] : uw[3];
-                const float crl = r == 0 ? C[0] : r == 1 ? C[1] : r == 2 ? C[2] : C[3];
+                u64 ur = __ballot((ubits >> r) & 1u);
+                const float crl = C[r];
                 u64 add = 0;
                 while (ur) {
                     const int l = __ffsll((long long)ur) - 1;
@@ -480,16 +484,13 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
                     double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
                     double var = s2 - s1 * s1 * nc.inv_l2;
                     double rhs = nc.thr2 * var * nc.T2;
-                    if (var > 0.0) {                     // wave-uniform
-                        double num = 255.0 * Ge + rest;
-                        if ((num > 0.0) && (num * num > rhs)) add |= 1ull << l;
-                        if (lane == 0) {
-                            if (var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) amb++;
-                            nexact++;
-                        }
-                    }
+                    double num = 255.0 * Ge + rest;
+                    const int flags = __builtin_amdgcn_readfirstlane((var > 0.0 ? 1 : 0) | ((var > 0.0 && num > 0.0 && num * num > rhs) ? 2 : 0) |
+                                                                     ((var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) ? 4 : 0));
+                    if (flags & 2) add |= 1ull << l;
+                    if (flags & 1) { nexact++; if (flags & 4) amb++; }
                 }
-                pw[0] |= r == 0 ? add : 0ull; pw[1] |= r == 1 ? add : 0ull; pw[2] |= r == 2 ? add : 0ull; pw[3] |= r == 3 ? add : 0ull;
+                pw[r] |= add;
             }
         }
         if (mask_u8) {
@@ -499,16 +500,21 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
                 if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)((pw[r] >> lane) & 1ull);
             }
         }
+        if (dbg == 1) { asm volatile("" :: "s"(pw[0]), "s"(pw[1]), "s"(pw[2]), "s"(pw[3])); continue; }
+        // (Combining the four strips' quarters of a word through LDS into 8-byte stores was measured: the barrier it needs
+        //  per step costs more than the 2-byte stores - 3.5 us per frame against 3.2.)
         if (lane < 16) {                                 // lane = row of the tile: 16 mask bits of this strip
             const int y = yo + lane;
-            u64 wsel = (lane & 3) == 0 ? pw[0] : (lane & 3) == 1 ? pw[1] : (lane & 3) == 2 ? pw[2] : pw[3];
+            const u64 wsel = (lane & 3) == 0 ? pw[0] : (lane & 3) == 1 ? pw[1] : (lane & 3) == 2 ? pw[2] : pw[3];
             if (y < H)
                 reinterpret_cast<unsigned short*>(mbits)[(((int64_t)n * H + y) * WW + blockIdx.x) * 4 + wave] =
                     (unsigned short)(wsel >> (16 * (lane >> 2)));
         }
     }
-    if (amb) atomicAdd(&fstat[n * 8 + 1], amb);
-    if (nexact) atomicAdd(&fstat[n * 8 + 3], nexact);
+    if (lane == 0) {                                     // (wave-uniform counters)
+        if (amb) atomicAdd(&fstat[n * 8 + 1], amb);
+        if (nexact) atomicAdd(&fstat[n * 8 + 3], nexact);
+    }
 }
 
 // Toeplitz fragments of k_ncc_mfma in the lane layout of v_mfma_f32_16x16x32_f16 (lane = 16 g + column, element j
@@ -657,11 +663,11 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         if (!h->bp.small)
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
                        h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
-                       h->ncc);
+                       VBS_KNOB("VBS_NCC_DBG"), h->ncc);
         else
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
                        h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
-                       h->ncc);
+                       VBS_KNOB("VBS_NCC_DBG"), h->ncc);
         return;
     }
     dim3 grid(h->WW, (h->H + 63) / 64, nb);
