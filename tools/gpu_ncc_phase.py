@@ -20,7 +20,7 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
     print(json.dumps({k: round(1e3 * v[1] / v[0] / n, 4) for k, v in p.items() if "ncc" in k or "blur" in k}))
 else:
     n = sys.argv[1] if len(sys.argv) > 1 else "512"
-    for dbg in (3, 2, 1, 0):
+    for dbg in [int(x) for x in os.environ.get("PHASES", "3,2,1,0").split(",")]:
         env = dict(os.environ, VBS_NCC_DBG=str(dbg))
         r = subprocess.run([sys.executable, __file__, n, "child"], env=env, capture_output=True, text=True, timeout=300)
         print("dbg", dbg, r.stdout.strip(), r.stderr.strip()[-300:] if r.returncode else "", flush=True)

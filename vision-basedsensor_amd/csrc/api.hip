@@ -169,6 +169,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(blur_frags, frags.size() / 4);
     std::vector<u32> nfrags = ncc_mfma_fragments(h->ncc, bp.ncc_l);
     ALLOC(ncc_frags, nfrags.size() / 4);
+    ALLOC(ncc_tab, (size_t)2 * VBS_NCC_MAXL + 1);
     ALLOC(umap1, (size_t)height * width * 2); ALLOC(umap2, (size_t)height * width); ALLOC(uwtab, 4096);
 #undef ALLOC
     std::vector<double> rx(width), ry(height);
@@ -189,6 +190,8 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     HIPCHK(h, hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->blur_frags, frags.data(), frags.size() * sizeof(u32), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->ncc_frags, nfrags.data(), nfrags.size() * sizeof(u32), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->ncc_tab, h->ncc.g, VBS_NCC_MAXL * sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->ncc_tab + VBS_NCC_MAXL, h->ncc.cg, (VBS_NCC_MAXL + 1) * sizeof(double), hipMemcpyHostToDevice));
     {
         std::vector<int32_t> wt(4096);
         bilinear_weights_i16(wt.data());
@@ -238,14 +241,18 @@ struct GrayPipe {
     vbs_handle* h; const u8* frames; int n, channels; int64_t stride_n, stride_row; hipStream_t s;
     bool on;
     int start() {
-        on = !h->undist && channels == 3 && n > h->maxb;
+        on = h->gray_side && !h->undist && channels == 3 && n > h->maxb;
         if (!on) return VBS_OK;
         HIPCHK(h, hipEventRecord(h->ev_fork, s));
         HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
         return convert(0);
     }
+    // pass schedule: with the conversion pipelined, a short first pass keeps the only exposed conversion small
+    int lead() const { return on ? std::min(h->maxb, std::max(64, h->maxb / 8)) : h->maxb; }
+    int pass_off(int k) const { return k == 0 ? 0 : lead() + (k - 1) * h->maxb; }
+    int pass_len(int k) const { return std::min(k == 0 ? lead() : h->maxb, n - pass_off(k)); }
     int convert(int k) {                                // pass k -> plane k & 1, on the side stream
-        const int off = k * h->maxb, nb = std::min(h->maxb, n - off);
+        const int off = pass_off(k), nb = pass_len(k);
         launch_gray(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, k & 1 ? h->gray2 : h->gray, h->side);
         HIPCHK(h, hipEventRecord(h->ev_gray[k & 1], h->side));
         return VBS_OK;
@@ -255,7 +262,7 @@ struct GrayPipe {
         *plane = nullptr;
         if (!on) return VBS_OK;
         HIPCHK(h, hipStreamWaitEvent(s, h->ev_gray[k & 1], 0));
-        if ((k + 1) * h->maxb < n) {
+        if (pass_off(k + 1) < n) {
             if (k >= 1) HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_free[(k + 1) & 1], 0));
             int rc = convert(k + 1);
             if (rc != VBS_OK) return rc;
@@ -283,8 +290,8 @@ extern "C" int vbs_find_markers(vbs_handle* h, const uint8_t* frames, int n, int
     GrayPipe gp{h, frames, n, channels, stride_n, stride_row, s, false};
     int rc = gp.start();
     if (rc != VBS_OK) return rc;
-    for (int off = 0, k = 0; off < n; off += h->maxb, ++k) {
-        int nb = std::min(h->maxb, n - off);
+    for (int k = 0; gp.pass_off(k) < n; ++k) {
+        const int off = gp.pass_off(k), nb = gp.pass_len(k);
         const u8* plane;
         if ((rc = gp.acquire(k, &plane)) != VBS_OK) return rc;
         rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row,
@@ -317,8 +324,8 @@ extern "C" int vbs_ncc_map(vbs_handle* h, const uint8_t* frames, int n, int chan
     GrayPipe gp{h, frames, n, channels, stride_n, stride_row, s, false};
     int rc = gp.start();
     if (rc != VBS_OK) return rc;
-    for (int off = 0, k = 0; off < n; off += h->maxb, ++k) {
-        int nb = std::min(h->maxb, n - off);
+    for (int k = 0; gp.pass_off(k) < n; ++k) {
+        const int off = gp.pass_off(k), nb = gp.pass_len(k);
         const u8* plane;
         if ((rc = gp.acquire(k, &plane)) != VBS_OK) return rc;
         rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr, nullptr,
@@ -352,6 +359,7 @@ extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
     if (!h) return VBS_EINVAL;
     switch (option) {
         case VBS_OPT_FORCE_SEQ_MATCH: h->force_seq_match = value != 0; return VBS_OK;
+        case VBS_OPT_GRAY_SIDE_STREAM: h->gray_side = value != 0; return VBS_OK;
         case VBS_OPT_GRAY_COEFFS:
             if (value != 14 && value != 15) break;
             h->gray_bits = value;
@@ -529,8 +537,8 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
     GrayPipe gp{h, frames, n, channels, stride_n, stride_row, s, false};
     int rc = gp.start();
     if (rc != VBS_OK) return rc;
-    for (int off = 0, k = 0; off < n; off += h->maxb, ++k) {
-        int nb = std::min(h->maxb, n - off);
+    for (int k = 0; gp.pass_off(k) < n; ++k) {
+        const int off = gp.pass_off(k), nb = gp.pass_len(k);
         const u8* plane;
         if ((rc = gp.acquire(k, &plane)) != VBS_OK) return rc;
         rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr, nullptr, nullptr,

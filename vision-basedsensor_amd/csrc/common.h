@@ -67,6 +67,7 @@ struct vbs_handle {
     double* ncc_rx;    // [W]  sum of g over the in-image part of the window (columns)
     double* ncc_ry;    // [H]
     uint4* ncc_frags;  // Toeplitz operand fragments of k_ncc_mfma (ncc_mfma_fragments)
+    double* ncc_tab;   // [VBS_NCC_MAXL] g, then [VBS_NCC_MAXL + 1] cg: the exact path of k_ncc_mfma reads them from memory
     u32* fstat;        // [maxb][8]  0: area popcount, 1: ambiguous ncc pixels, 2: status
     u32* wbase;        // [maxb][2][H*WW]   first node index of each word
     u32* node_pos;     // [maxb][2][RUN_CAP]  y*W + x0 of each run
@@ -84,6 +85,7 @@ struct vbs_handle {
     u32* slow_flag;    // [maxb]  1 = the fast labelling path handed the frame on
     int gray_bits = 15;             // BGR2GRAY fixed-point coefficient set: 15 (OpenCV 4) | 14 (OpenCV <= 3.4.1)
     bool force_seq_match = false;   // vbs_set_option(VBS_OPT_FORCE_SEQ_MATCH)
+    bool gray_side = true;          // vbs_set_option(VBS_OPT_GRAY_SIDE_STREAM)
     u8* lut;           // [256] contour vertex table
     short* umap1;      // [H][W][2] int16 undistortion source pixel (CV_16SC2)
     unsigned short* umap2;   // [H][W] fractional index into the bilinear weight table

@@ -232,9 +232,12 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
 //   horizontal  h[y][x]  = sum_k b[y][xw+k] * w[k - x]          A = image bits expanded to 0.0 / 1.0 (exact),
 //               ch[y][x] = sum_k b[y][xw+k] * 1[k - x]          B = Toeplitz of w = 1024 g, split w = whi + wlo
 //   vertical    G[y][x]  = sum_k w[k - y] * h[yw+k][x]           A = the same Toeplitz fragments, B = h split into
-//               c[y][x]  = sum_k 1[k - y] * ch[yw+k][x]          float16 hi + lo (products hi*hi, hi*lo, lo*hi)
+//                                                                float16 hi + lo (products hi*hi, hi*lo, lo*hi)
+//               c[y][x]  = sum_k 1[k - y] * ch[yw+k][x]          int8 (v_mfma_i32_16x16x64_i8): ch <= l fits a byte
 // One wave owns a 16-column strip and slides down it 16 rows per step; horizontal tiles go through a per-wave
-// LDS ring stored column-major, so a vertical B operand is one 16-byte read.  The result is a FILTER exactly as
+// LDS ring stored column-major (h as float16 hi / lo, ch as bytes), so a vertical B operand is one 16-byte read.
+// The ring is what bounds the waves per CU, and the kernel's time goes with 1 / waves (measured 4.4 / 3.2 / 3.0 us per
+// frame at 2 / 3 / 4 waves per SIMD): the byte count ring and keeping the exact path's tables out of LDS make it four.  The result is a FILTER exactly as
 // before: the relative error of G stays below 2^-16 (dropped lo*lo, float16 lo roundings, float32 accumulation of
 // <= 300 positive terms), the decision is taken against theta (1 +- 2e-5) and the undecided pixels recompute G in
 // float64 from the bits, so every decision equals the float64 one.
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(256) void k_ncc(const u64* __restrict__ bits, const
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
 typedef float f4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
 #define NCC_WSCALE 1024.0                               // weights are scaled so that every wlo is a normal float16
 #define NCC_REL 2e-5f
 #define NCC_NEVER 3e38                                  // "no G reaches this" (finite, so G - theta stays ordered)
@@ -265,24 +269,28 @@ __device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, d
     return (sqrt(rhs) - rest) * (NCC_WSCALE * NCC_WSCALE / 255.0);
 }
 
+typedef int i4 __attribute__((ext_vector_type(4)));
+
 template <int L, int LO>
-__global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
+__global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
-                                                     u64* __restrict__ mbits, u8* __restrict__ mask_u8,
-                                                     u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
-                                                     int dbg, NccConst nc) {
+                                                     const double* __restrict__ tab, u64* __restrict__ mbits,
+                                                     u8* __restrict__ mask_u8, u32* __restrict__ fstat, int H, int W,
+                                                     int WW, int tiles_per_seg, int dbg, NccConst nc) {
     constexpr int HI = L - 1 + LO;
     constexpr int NT = (16 + L - 1 + 15) / 16;          // horizontal tiles under one output tile
-    constexpr int NKS = (16 * NT + 31) / 32;            // k-steps of 32
+    constexpr int NKS = (16 * NT + 31) / 32;            // k-steps of 32 (float16 products)
+    constexpr int NK8 = (16 * NT + 63) / 64;            // k-steps of 64 (int8 count product)
     constexpr int RING = 16 * NT;
     constexpr int RSTR = RING + 8;                      // halves per ring column (+16 B: conflict-free 16-byte reads)
+    constexpr int CSTR = RING + 16;                     // bytes per count-ring column (conflict-free as well)
     constexpr int L2 = L * L;
+    // 37.9 KB for l = 80: four workgroups (16 waves) per CU; the time of this kernel goes with 1 / waves per SIMD
     __shared__ __align__(16) uint4 lut[256];
-    __shared__ __align__(16) _Float16 ring[4][3][16 * RSTR];
-    __shared__ double cg[L + 1];
-    __shared__ double gsh[L];
-    __shared__ double hrow_s[4][L];                     // exact path: one window's row sums
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __align__(16) _Float16 ring[4][2][16 * RSTR];
+    __shared__ __align__(16) u8 ringc[4][16 * CSTR];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, and known to the compiler to be
     const int g = lane >> 4, q = lane & 15;
     const int n = blockIdx.z;
     const int tilesY = (H + 15) / 16;
@@ -298,9 +306,8 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
         for (int d = 0; d < 4; ++d) w[d] = (((u32)tid >> (2 * d)) & 1u ? 0x3C00u : 0u) | (((u32)tid >> (2 * d + 1)) & 1u ? 0x3C000000u : 0u);
         lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    for (int i = tid; i <= L; i += 256) cg[i] = nc.cg[i];
-    for (int i = tid; i < L; i += 256) gsh[i] = nc.g[i];
-    for (int i = lane; i < 3 * 16 * RSTR / 8; i += 64) reinterpret_cast<uint4*>(&ring[wave][0][0])[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < 2 * 16 * RSTR / 8; i += 64) reinterpret_cast<uint4*>(&ring[wave][0][0])[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < 16 * CSTR / 16; i += 64) reinterpret_cast<uint4*>(&ringc[wave][0])[i] = make_uint4(0, 0, 0, 0);
     h8 whi[NKS], wlo[NKS], one[NKS];
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
@@ -309,24 +316,44 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
         wlo[s] = __builtin_bit_cast(h8, b);
         one[s] = __builtin_bit_cast(h8, c);
     }
+    // int8 Toeplitz of ones (A operand of the vertical count product): lane (g, row q), byte j <-> k = 64 s + 16 g + j
+    i4 one8[NK8];
+#pragma unroll
+    for (int s = 0; s < NK8; ++s)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+            u32 w = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int idx = 64 * s + 16 * g + 4 * d + j - q;
+                w |= (idx >= 0 && idx < L) ? (1u << (8 * j)) : 0u;
+            }
+            one8[s][d] = (int)w;
+        }
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // operand fragments landed (see k_blur_mfma)
     __syncthreads();
 
     const double mu = (double)(255ull * (u64)fstat[n * 8 + 0]) / (double)((int64_t)H * W);
     const double full_t = ry[min(max(-LO, 0), H - 1)] * rx[min(max(-LO, 0), W - 1)];
-    // theta(c) = ks sqrt(c (l^2 - c)) + kc c + k0 on 2^20 G; th0 decides the empty window
+    // theta(c) = ks sqrt(c (l^2 - c)) + kc c + k0 on 2^20 G; th0 decides the empty window.  (Uniform values are made so
+    // explicitly: they then live in scalar registers.)
+    // (as inline assembly: the builtin is folded away for a value the compiler already knows to be uniform, and the
+    //  value then stays in the vector register its float64 -> float32 conversion produced)
+    auto uni = [](float v) { float o; asm("s_nop 4\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(o) : "v"(v)); return o; };   // (s_nop: the hazards the
+    // compiler pads for v_readfirstlane after a VALU write, and before a read of the scalar, are ours inside an asm)
     const float ks = (float)(sqrt(nc.thr2 * nc.T2) / (double)L * (NCC_WSCALE * NCC_WSCALE));
-    const float kc = (float)(nc.tbar * (NCC_WSCALE * NCC_WSCALE));
+    const float kc = uni((float)(nc.tbar * (NCC_WSCALE * NCC_WSCALE)));
     const float k0 = (float)(mu * (full_t - nc.l2 * nc.tbar) / 255.0 * (NCC_WSCALE * NCC_WSCALE));
     const float th0 = (float)ncc_theta(0.0, nc.l2, full_t, mu, nc);
-    // per-lane constants of the border tiles' threshold (the column is fixed for the whole strip)
-    const int xq = min(xw + q, W - 1);
-    const float nxf = (float)(min(xq + HI, W - 1) - max(xq + LO, 0) + 1), rxf = (float)rx[xq];
-    const float muf = (float)mu, tbarf = (float)nc.tbar, ktf = (float)(nc.tbar * 255.0), il2f = (float)nc.inv_l2;
-    const float krf = (float)(nc.thr2 * nc.T2);
+    const float k0e = uni(fmaxf(k0, 0.01f));
+    const float ks2 = uni(ks * ks);
+    const bool th0pos = __builtin_amdgcn_readfirstlane(th0 > 0.0f ? 1 : 0) != 0;
+    // constants of the border tiles' threshold
+    const float muf = uni((float)mu), tbarf = uni((float)nc.tbar), ktf = uni((float)(nc.tbar * 255.0)), il2f = uni((float)nc.inv_l2);
+    const float krf = uni((float)(nc.thr2 * nc.T2));
     _Float16* rhi = &ring[wave][0][q * RSTR];
     _Float16* rlo = &ring[wave][1][q * RSTR];
-    _Float16* rct = &ring[wave][2][q * RSTR];
+    u8* rct = &ringc[wave][q * CSTR];
     u32 amb = 0, nexact = 0;
     // Row bits of a horizontal tile: lane (g, q) takes row q's window [xw + LO, xw + LO + 32 NKS) as dwords.  Strips
     // whose window lies inside the row load them with one branch-free 16-byte load (issued a step ahead); the
@@ -374,25 +401,28 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
             ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, one[s], ac, 0, 0, 0);
         }
         {
-            // hi = the float32 cut to float16's 10 mantissa bits (exact in float16: 0.25 <= h <= 1024), lo = the rest
-            h4 vh, vl, vc;
+            // hi = the float32 cut to float16's 10 mantissa bits (exact in float16: 0.25 <= h <= 1024), lo = the rest;
+            // the count (an integer <= l) goes to the ring as a byte
+            h4 vh, vl;
+            u32 vc = 0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const float hi_f = __uint_as_float(__float_as_uint(ah[r]) & 0xFFFFE000u);
                 vh[r] = (_Float16)hi_f;
                 vl[r] = (_Float16)(ah[r] - hi_f);
-                vc[r] = (_Float16)ac[r];
+                vc = __builtin_amdgcn_cvt_pk_u8_f32(ac[r], r, vc);
             }
             const int ro = 16 * (t % NT) + 4 * g;
             *reinterpret_cast<h4*>(rhi + ro) = vh;
             *reinterpret_cast<h4*>(rlo + ro) = vl;
-            *reinterpret_cast<h4*>(rct + ro) = vc;
+            *reinterpret_cast<u32*>(rct + ro) = vc;
         }
         if (t < NT - 1 || dbg == 3) continue;            // (dbg: tools/ phase timing, always 0 in the product library)
         // ---- vertical: output tile rows yo .. yo + 15 from ring tiles t-NT+1 .. t ----
         const int yo = Y0 + 16 * (t - (NT - 1));
         const int base = 16 * ((t - (NT - 1)) % NT);
-        f4 G = {0, 0, 0, 0}, C = {0, 0, 0, 0};
+        f4 G = {0, 0, 0, 0};
+        i4 C = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < NKS; ++s) {
             int ub = base + 32 * s;                      // uniform part of the ring offset, wraps at RING
@@ -402,79 +432,140 @@ __global__ __launch_bounds__(256, 3) void k_ncc_mfma(const u64* __restrict__ bit
             ro = min((u32)ro, (u32)(ro - RING));         // ro >= RING ? ro - RING : ro
             const h8 bh = *reinterpret_cast<const h8*>(rhi + ro);
             const h8 bl = *reinterpret_cast<const h8*>(rlo + ro);
-            const h8 bc = *reinterpret_cast<const h8*>(rct + ro);
             G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bh, G, 0, 0, 0);
             G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bl, G, 0, 0, 0);
             G = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[s], bh, G, 0, 0, 0);
-            C = __builtin_amdgcn_mfma_f32_16x16x32_f16(one[s], bc, C, 0, 0, 0);
         }
+#pragma unroll
+        for (int s = 0; s < NK8; ++s) {
+            // 16 rows per lane group; groups past the ring carry zero weights and may read any valid 16 bytes
+            int ro = base + 16 * min(4 * s + g, NT - 1);
+            ro = min((u32)ro, (u32)(ro - RING));
+            const i4 bc = *reinterpret_cast<const i4*>(rct + ro);
+            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(one8[s], bc, C, 0, 0, 0);
+        }
+#ifdef VBS_DEBUG_KNOBS
+        if (dbg == 8 && mask_u8) {                       // tools/gpu_mask_diff.py: the window counts instead of the mask
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = yo + 4 * g + r, x = xw + q;
+                if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)C[r];
+            }
+            continue;
+        }
+#endif
         if (dbg == 2) { asm volatile("" :: "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(C[0]), "v"(C[1]), "v"(C[2]), "v"(C[3])); continue; }
         // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
         const int x = xw + q;
         const bool interior = (yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
-        float th[4];
-        float rel = NCC_REL, abs_ = NCC_ABS;             // margins of this tile (uniform)
-        if (interior && th0 > 0.0f) {                    // wave-uniform; th0 > 0: an empty window is background
+        const f2 Gp[2] = {{G[0], G[1]}, {G[2], G[3]}};
+        const f2 Cp[2] = {{(float)C[0], (float)C[1]}, {(float)C[2], (float)C[3]}};
+        // pw[r] / uw[r]: 64-bit masks (wave-uniform, kept in scalar registers) of the pixels decided foreground / left
+        // undecided by the filter, bit = lane
+        u64 pw[4] = {0, 0, 0, 0}, uw[4] = {0, 0, 0, 0};
+        if (interior && th0pos) {                        // wave-uniform; th0 > 0: an empty window is background
+            // G > theta(c)  <=>  u = G - (kc c + k0) > 0 and u^2 > ks^2 c (l^2 - c), taken with G (1 -+ rel): no square
+            // root, and a tile whose every u is negative (the template correlates negatively: about half of them) is
+            // background after three packed operations per pixel pair.  k0e >= 0.01 keeps an empty window (G = 0
+            // exactly) at u < 0; against kc c ~ 1e5 for c >= 1 it is far inside the margin.
+            const f2 rel2 = {NCC_REL, NCC_REL}, nkc2 = {-kc, -kc}, k02 = {k0e, k0e};
+            f2 u[2], uhi[2];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float cf = C[r];                   // exact integer; c = 0 <=> G = 0 < 0.01
-                th[r] = fmaxf(__builtin_fmaf(ks, __builtin_amdgcn_sqrtf(cf * ((float)L2 - cf)), __builtin_fmaf(kc, cf, k0)), 0.01f);
+            for (int i = 0; i < 2; ++i) {                // (one scalar operand per packed instruction)
+                u[i] = __builtin_elementwise_fma(Cp[i], nkc2, Gp[i] - k02);
+                uhi[i] = __builtin_elementwise_fma(Gp[i], rel2, u[i]);
+            }
+            const float umax = fmaxf(fmaxf(uhi[0].x, uhi[0].y), fmaxf(uhi[1].x, uhi[1].y));
+            if (__ballot(umax >= 0.0f)) {
+                // (the roundings of a and of the two squares, 2.4e-7 relative, sit inside NCC_REL - 2^-16 = 4.7e-6)
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f2 ulo = __builtin_elementwise_fma(Gp[i], -rel2, u[i]);
+                    const f2 a = (Cp[i] * ((float)L2 - Cp[i])) * ks2;     // c (l^2 - c) is an exact integer < 2^24
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int r = 2 * i + j;
+                        pw[r] = __ballot(ulo[j] * fabsf(ulo[j]) > a[j]);          // ulo > 0 and ulo^2 > ks^2 p: foreground
+                        uw[r] = ~(pw[r] | __ballot(uhi[i][j] * fabsf(uhi[i][j]) <= a[j]));   // uhi < 0 or uhi^2 <= ks^2 p: background
+                    }
+                }
             }
         } else {
             // Border tile (or th0 <= 0): theta in float32 from the collected form of the general window,
             //   var = 255^2 c (1 - c / l^2) + (1 - nn / l^2) mu (nn mu - 510 c),   rest = -tbar 255 c - mu (sum_t - nn tbar),
             // whose error stays below 1e-4 theta + 1 in these units (var loses at most 5e-6 to cancellation, the last
             // subtraction 1e-4 absolute on theta 255): pixels within 1e-3 theta + 2 of it go to the exact path.
-            rel = 1e-3f; abs_ = 2.0f;
+            const int xq = min(x, W - 1);
+            const float nxf = (float)(min(xq + HI, W - 1) - max(xq + LO, 0) + 1), rxf = (float)rx[xq];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int yc = min(yo + 4 * g + r, H - 1);
-                const float cf = C[r];
+                const float cf = Cp[r >> 1][r & 1];
                 const float nn = (float)(min(yc + HI, H - 1) - max(yc + LO, 0) + 1) * nxf, st = (float)ry[yc] * rxf;
-                const float rest = -(ktf * cf) - muf * (st - nn * tbarf);
-                const float var = 65025.0f * cf * (1.0f - cf * il2f) + (1.0f - nn * il2f) * muf * (nn * muf - 510.0f * cf);
+                const float d0 = st - nn * tbarf, a0 = 1.0f - nn * il2f;
+                const float rest = -(ktf * cf) - muf * d0;
+                const float var = 65025.0f * cf * (1.0f - cf * il2f) + a0 * muf * (nn * muf - 510.0f * cf);
                 const float t1 = (__builtin_amdgcn_sqrtf(fmaxf(krf * var, 0.0f)) - rest) * (float)(NCC_WSCALE * NCC_WSCALE / 255.0);
                 // empty window: G = 0, num = rest = -mu d0 and rhs = thr2 T2 a nn mu^2: background unless d0 < 0 and
                 // d0^2 > thr2 T2 a nn (mu cancels); decided here with a factor 2 to spare, else left to the exact path
-                const float d0 = st - nn * tbarf, a0 = 1.0f - nn * il2f;
-                th[r] = cf == 0.0f ? ((d0 > -1e-4f || d0 * d0 < 0.5f * krf * a0 * nn) ? (float)NCC_NEVER : 0.0f) : t1;
+                const float t0 = ((d0 > -1e-4f) | (d0 * d0 < 0.5f * krf * a0 * nn)) ? (float)NCC_NEVER : 0.0f;
+                const float th = cf == 0.0f ? t0 : t1;
+                const float m = __builtin_fmaf(fabsf(th), 1e-3f, 2.0f), d = G[r] - th;
+                pw[r] = __ballot(d > m);
+                uw[r] = ~(pw[r] | __ballot(d < -m));
             }
         }
-        const bool allvalid = (yo + 15 < H) && (xw + 15 < W);   // uniform
-        // pw[r]: 64-bit masks (wave-uniform, kept in scalar registers) of the pixels decided foreground, bit = lane
-        u64 pw[4];
-        u32 ubits = 0;                                   // bit r: this lane's pixel r is neither above theta (1 + e) nor below theta (1 - e)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const float m = __builtin_fmaf(fabsf(th[r]), rel, abs_), d = G[r] - th[r];
-            const bool v = allvalid || ((yo + 4 * g + r < H) && (x < W));
-            pw[r] = __ballot((d > m) && v);
-            ubits |= (!(d > m) && !(d < -m) && v) ? (1u << r) : 0u;
-        }
-        if (__ballot(ubits != 0)) {
-            // Rare (a handful of pixels per frame): exact float64 G straight from the bits, one pixel at a time by the
-            // whole wave: lane i sums rows i and i + 64 of the window from their runs, then the L products are added
-            // in ascending row order exactly as ncc_exact_G does.  Every lane computes the same numbers; the decision is
-            // made wave-uniform explicitly so that the masks stay in scalar registers.
+        if (!((yo + 15 < H) && (xw + 15 < W))) {         // uniform: tiles that stick out of the image
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                u64 ur = __ballot((ubits >> r) & 1u);
-                const float crl = C[r];
+                const u64 v = __ballot((yo + 4 * g + r < H) && (x < W));
+                pw[r] &= v; uw[r] &= v;
+            }
+        }
+#ifdef VBS_DEBUG_KNOBS
+        if (dbg == 9 && mask_u8) {                       // tools/gpu_mask_diff.py: the filter's verdict (1 fg, 2 undecided)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int y = yo + 4 * g + r;
+                if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)(((pw[r] >> lane) & 1ull) | (((uw[r] >> lane) & 1ull) << 1));
+            }
+            continue;
+        }
+#endif
+        if (uw[0] | uw[1] | uw[2] | uw[3]) {
+            // Rare (a handful of pixels per frame): exact float64 G straight from the bits, one pixel at a time by the
+            // whole wave: lane i sums rows i and i + 64 of the window from their runs, then the L products are added
+            // in ascending row order exactly as ncc_exact_G does (row sums broadcast from their lanes, template factors
+            // read as scalars).  The decision is wave-uniform, so the masks stay in scalar registers.
+            const double* cgd = tab + VBS_NCC_MAXL;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                u64 ur = uw[r];
+                const int crl = C[r];
                 u64 add = 0;
                 while (ur) {
                     const int l = __ffsll((long long)ur) - 1;
                     ur &= ur - 1ull;
                     const int y = yo + 4 * (l >> 4) + r, xe = xw + (l & 15);
-                    const float cr = __shfl(crl, l);
+                    const int cr = __builtin_amdgcn_readlane(crl, l);
+                    double hv[(L + 63) / 64];
 #pragma unroll
                     for (int k = 0; k < (L + 63) / 64; ++k) {
                         const int i = lane + 64 * k, yy = y + LO + i;
                         u32 dummy = 0;
-                        if (i < L) hrow_s[wave][i] = (yy >= 0 && yy < H) ? ncc_row_exact<L, LO>(fbits + (int64_t)yy * WW, WW, xe, cg, &dummy) : 0.0;
+                        hv[k] = (i < L && yy >= 0 && yy < H) ? ncc_row_exact<L, LO>(fbits + (int64_t)yy * WW, WW, xe, cgd, &dummy) : 0.0;
                     }
                     double Ge = 0.0;
+#pragma unroll
+                    for (int k = 0; k < (L + 63) / 64; ++k) {
+                        const u32 hl = (u32)__double_as_longlong(hv[k]), hh = (u32)((u64)__double_as_longlong(hv[k]) >> 32);
 #pragma unroll 8
-                    for (int i = 0; i < L; ++i) Ge = __builtin_fma(gsh[i], hrow_s[wave][i], Ge);
+                        for (int i = 64 * k; i < min(L, 64 * k + 64); ++i) {
+                            const u64 hb = (u64)(u32)__builtin_amdgcn_readlane((int)hl, i - 64 * k) |
+                                           ((u64)(u32)__builtin_amdgcn_readlane((int)hh, i - 64 * k) << 32);
+                            Ge = __builtin_fma(tab[i], __longlong_as_double((long long)hb), Ge);
+                        }
+                    }
                     int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
                     int nx = min(xe + HI, W - 1) - max(xe + LO, 0) + 1;
                     double nn = (double)(ny * nx), sum_t = ry[y] * rx[xe];
@@ -662,11 +753,11 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         dim3 grid(h->WW, nseg, nb);
         if (!h->bp.small)
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
-                       h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
+                       h->ncc_ry, h->ncc_frags, h->ncc_tab, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
                        VBS_KNOB("VBS_NCC_DBG"), h->ncc);
         else
             VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
-                       h->ncc_ry, h->ncc_frags, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
+                       h->ncc_ry, h->ncc_frags, h->ncc_tab, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
                        VBS_KNOB("VBS_NCC_DBG"), h->ncc);
         return;
     }
