@@ -85,7 +85,7 @@ struct vbs_handle {
     u32* slow_flag;    // [maxb]  1 = the fast labelling path handed the frame on
     int gray_bits = 15;             // BGR2GRAY fixed-point coefficient set: 15 (OpenCV 4) | 14 (OpenCV <= 3.4.1)
     bool force_seq_match = false;   // vbs_set_option(VBS_OPT_FORCE_SEQ_MATCH)
-    bool gray_side = true;          // vbs_set_option(VBS_OPT_GRAY_SIDE_STREAM)
+    bool gray_side = false;         // vbs_set_option(VBS_OPT_GRAY_SIDE_STREAM)
     u8* lut;           // [256] contour vertex table
     short* umap1;      // [H][W][2] int16 undistortion source pixel (CV_16SC2)
     unsigned short* umap2;   // [H][W] fractional index into the bilinear weight table

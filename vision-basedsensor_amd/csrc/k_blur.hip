@@ -34,28 +34,42 @@ __device__ __forceinline__ u32 bgr4_to_gray(u32 a, u32 b, u32 c, const GrayCoef&
 __global__ __launch_bounds__(256) void k_gray(const u8* __restrict__ frames, int channels, int64_t stride_n,
                                               int64_t stride_row, u8* __restrict__ gray, int H, int W, int P, GrayCoef gc,
                                               int vec_ok, int flat) {
-    __shared__ __align__(16) uint4 raw[3 * 256];        // 12 KB: the 48 bytes of each thread's 16 pixels, loaded coalesced
+    __shared__ __align__(16) uint4 raw[2][3 * 256];     // 24 KB: the 48 bytes of each thread's 16 pixels, loaded coalesced
     const int n = blockIdx.z;
     if (flat) {
-        // dense BGR frame (row stride 3 W, gray pitch W): one run of H W pixels, 4096 per block, loaded as consecutive
-        // 16-byte pieces by consecutive lanes and handed to their owners through LDS
-        const int64_t npx = (int64_t)H * W, pb = (int64_t)blockIdx.x * 4096, p0 = pb + threadIdx.x * 16;
+        // dense BGR frame (row stride 3 W, gray pitch W): one run of H W pixels, 2 x 4096 per block, loaded as consecutive
+        // 16-byte pieces by consecutive lanes (both halves in flight together, streamed past the caches) and handed to
+        // their owners through LDS
+        const int64_t npx = (int64_t)H * W, pb = (int64_t)blockIdx.x * 8192;
         const u8* src = frames + (int64_t)n * stride_n;
-        u8* dst = gray + (int64_t)n * H * P + p0;
-        uint4 r0, r1, r2;
-        if (pb + 4096 <= npx) {                          // block-uniform
+        u8* dstf = gray + (int64_t)n * H * P;
+        if (pb + 8192 <= npx) {                          // block-uniform
             const uint4* s4 = reinterpret_cast<const uint4*>(src + pb * 3);
+            uint4 v[6];
 #pragma unroll
-            for (int q = 0; q < 3; ++q) raw[q * 256 + threadIdx.x] = s4[q * 256 + threadIdx.x];
+            for (int q = 0; q < 6; ++q) v[q] = __builtin_nontemporal_load(s4 + q * 256 + threadIdx.x);
+#pragma unroll
+            for (int q = 0; q < 6; ++q) raw[q / 3][(q % 3) * 256 + threadIdx.x] = v[q];
             __syncthreads();
-            r0 = raw[3 * threadIdx.x]; r1 = raw[3 * threadIdx.x + 1]; r2 = raw[3 * threadIdx.x + 2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const uint4 r0 = raw[hf][3 * threadIdx.x], r1 = raw[hf][3 * threadIdx.x + 1], r2 = raw[hf][3 * threadIdx.x + 2];
+                *reinterpret_cast<uint4*>(dstf + pb + 4096 * hf + threadIdx.x * 16) =
+                    make_uint4(bgr4_to_gray(r0.x, r0.y, r0.z, gc), bgr4_to_gray(r0.w, r1.x, r1.y, gc),
+                               bgr4_to_gray(r1.z, r1.w, r2.x, gc), bgr4_to_gray(r2.y, r2.z, r2.w, gc));
+            }
         } else {
-            if (p0 >= npx) return;                       // (H W is a multiple of 16 in flat mode)
-            const uint4* s4 = reinterpret_cast<const uint4*>(src + p0 * 3);
-            r0 = s4[0]; r1 = s4[1]; r2 = s4[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const int64_t p0 = pb + 4096 * hf + threadIdx.x * 16;
+                if (p0 >= npx) return;                   // (H W is a multiple of 16 in flat mode)
+                const uint4* s4 = reinterpret_cast<const uint4*>(src + p0 * 3);
+                const uint4 r0 = s4[0], r1 = s4[1], r2 = s4[2];
+                *reinterpret_cast<uint4*>(dstf + p0) =
+                    make_uint4(bgr4_to_gray(r0.x, r0.y, r0.z, gc), bgr4_to_gray(r0.w, r1.x, r1.y, gc),
+                               bgr4_to_gray(r1.z, r1.w, r2.x, gc), bgr4_to_gray(r2.y, r2.z, r2.w, gc));
+            }
         }
-        *reinterpret_cast<uint4*>(dst) = make_uint4(bgr4_to_gray(r0.x, r0.y, r0.z, gc), bgr4_to_gray(r0.w, r1.x, r1.y, gc),
-                                                    bgr4_to_gray(r1.z, r1.w, r2.x, gc), bgr4_to_gray(r2.y, r2.z, r2.w, gc));
         return;
     }
     const int x0 = (blockIdx.x * 256 + threadIdx.x) * 16, y = blockIdx.y;
@@ -350,7 +364,7 @@ void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t 
                  int64_t stride_row, u8* gray, hipStream_t s) {
     const int vec_ok = (reinterpret_cast<uintptr_t>(frames) % 16 == 0) && (stride_n % 16 == 0) && (stride_row % 16 == 0);
     const int flat = vec_ok && channels == 3 && stride_row == (int64_t)h->W * 3 && h->P == h->W && ((int64_t)h->H * h->W) % 16 == 0;
-    dim3 grid = flat ? dim3((unsigned)(((int64_t)h->H * h->W + 4095) / 4096), 1, nb) : dim3((h->P / 16 + 255) / 256, h->H, nb);
+    dim3 grid = flat ? dim3((unsigned)(((int64_t)h->H * h->W + 8191) / 8192), 1, nb) : dim3((h->P / 16 + 255) / 256, h->H, nb);
     VBS_LAUNCH(h, s, "k_gray", k_gray, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row, gray,
                        h->H, h->W, h->P, gray_coef(h->gray_bits), vec_ok, flat);
 }

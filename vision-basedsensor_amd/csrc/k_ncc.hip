@@ -271,12 +271,17 @@ __device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, d
 
 typedef int i4 __attribute__((ext_vector_type(4)));
 
-template <int L, int LO>
+template <int L, int LO, bool U8OUT>                    // U8OUT: also the uint8 mask of the staged API
 __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
                                                      const double* __restrict__ tab, u64* __restrict__ mbits,
                                                      u8* __restrict__ mask_u8, u32* __restrict__ fstat, int H, int W,
-                                                     int WW, int tiles_per_seg, int dbg, NccConst nc) {
+                                                     int WW, int tiles_per_seg, int dbg_arg, NccConst nc) {
+#ifdef VBS_DEBUG_KNOBS
+    const int dbg = dbg_arg;                            // tools/ phase timing and dumps
+#else
+    constexpr int dbg = 0;
+#endif
     constexpr int HI = L - 1 + LO;
     constexpr int NT = (16 + L - 1 + 15) / 16;          // horizontal tiles under one output tile
     constexpr int NKS = (16 * NT + 31) / 32;            // k-steps of 32 (float16 products)
@@ -347,7 +352,13 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     const float th0 = (float)ncc_theta(0.0, nc.l2, full_t, mu, nc);
     const float k0e = uni(fmaxf(k0, 0.01f));
     const float ks2 = uni(ks * ks);
+    // Loop-invariant conditions as integer bounds on the tile row (a uniform bool costs a 64-bit mask in two scalar
+    // registers, and this kernel has none to spare): a tile takes the plain decision for plain_lo <= yo <= plain_hi,
+    // and lies wholly inside the image for yo <= valid_hi.
     const bool th0pos = __builtin_amdgcn_readfirstlane(th0 > 0.0f ? 1 : 0) != 0;
+    const bool xin = (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
+    const int plain_lo = (th0pos && xin) ? -LO : 0x7FFFFFFF, plain_hi = H - 1 - 15 - HI;
+    const int valid_hi = (xw + 15 < W) ? H - 16 : -1;
     // constants of the border tiles' threshold
     const float muf = uni((float)mu), tbarf = uni((float)nc.tbar), ktf = uni((float)(nc.tbar * 255.0)), il2f = uni((float)nc.inv_l2);
     const float krf = uni((float)(nc.thr2 * nc.T2));
@@ -355,6 +366,8 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     _Float16* rlo = &ring[wave][1][q * RSTR];
     u8* rct = &ringc[wave][q * CSTR];
     u32 amb = 0, nexact = 0;
+    const u32 sel1 = 0u - ((u32)lane & 1u), sel2 = 0u - (((u32)lane >> 1) & 1u);
+    unsigned short* mb16 = reinterpret_cast<unsigned short*>(mbits) + ((int64_t)n * H * WW + blockIdx.x) * 4 + wave;   // (uniform)
     // Row bits of a horizontal tile: lane (g, q) takes row q's window [xw + LO, xw + LO + 32 NKS) as dwords.  Strips
     // whose window lies inside the row load them with one branch-free 16-byte load (issued a step ahead); the
     // first / last strips of a row go through clamped 64-bit loads.
@@ -362,11 +375,12 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     const int d0 = wstart >> 5, dsh = wstart & 31;
     const bool wide = (d0 >= 0) && (d0 + 4 <= 2 * WW);
     uint4 nraw = make_uint4(0, 0, 0, 0);
+    const u32* fb32 = reinterpret_cast<const u32*>(fbits) + d0;   // (uniform)
     auto load_rows = [&](int t) {
         const int y = Y0 + LO + 16 * t + q;
         const u64* row = fbits + (int64_t)min(max(y, 0), H - 1) * WW;
-        if (wide) {
-            const u32* r32 = reinterpret_cast<const u32*>(row) + d0;
+        if (wide) {                                      // (32-bit offset from a scalar base: no 64-bit multiply per step)
+            const u32* r32 = fb32 + (u32)__mul24(min(max(y, 0), H - 1), 2 * WW);
             nraw = make_uint4(r32[0], r32[1], r32[2], r32[3]);
         } else {
             u64 w0 = load_bits(row, WW, wstart), w1 = load_bits(row, WW, wstart + 64);
@@ -374,10 +388,13 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
         }
     };
     load_rows(0);
+    u32 pend_piece = 0, pend_off = 0xFFFFFFFFu;
     for (int t = 0; t < nsteps; ++t) {
         const uint4 raw = nraw;
         const int ytile = Y0 + LO + 16 * t;
         if (t + 1 < nsteps) load_rows(t + 1);
+        if (pend_off != 0xFFFFFFFFu) mb16[pend_off] = (unsigned short)pend_piece;   // the previous step's mask rows
+        pend_off = 0xFFFFFFFFu;
         u32 dw[3];
         if (wide) {
             dw[0] = __builtin_amdgcn_alignbit(raw.y, raw.x, dsh);
@@ -457,13 +474,12 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
         if (dbg == 2) { asm volatile("" :: "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(C[0]), "v"(C[1]), "v"(C[2]), "v"(C[3])); continue; }
         // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
         const int x = xw + q;
-        const bool interior = (yo + LO >= 0) && (yo + 15 + HI <= H - 1) && (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
         const f2 Gp[2] = {{G[0], G[1]}, {G[2], G[3]}};
         const f2 Cp[2] = {{(float)C[0], (float)C[1]}, {(float)C[2], (float)C[3]}};
         // pw[r] / uw[r]: 64-bit masks (wave-uniform, kept in scalar registers) of the pixels decided foreground / left
         // undecided by the filter, bit = lane
         u64 pw[4] = {0, 0, 0, 0}, uw[4] = {0, 0, 0, 0};
-        if (interior && th0pos) {                        // wave-uniform; th0 > 0: an empty window is background
+        if (yo >= plain_lo && yo <= plain_hi) {          // wave-uniform: windows inside the image, empty window = background
             // G > theta(c)  <=>  u = G - (kc c + k0) > 0 and u^2 > ks^2 c (l^2 - c), taken with G (1 -+ rel): no square
             // root, and a tile whose every u is negative (the template correlates negatively: about half of them) is
             // background after three packed operations per pixel pair.  k0e >= 0.01 keeps an empty window (G = 0
@@ -515,7 +531,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 uw[r] = ~(pw[r] | __ballot(d < -m));
             }
         }
-        if (!((yo + 15 < H) && (xw + 15 < W))) {         // uniform: tiles that stick out of the image
+        if (yo > valid_hi) {                             // uniform: tiles that stick out of the image
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const u64 v = __ballot((yo + 4 * g + r < H) && (x < W));
@@ -584,7 +600,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 pw[r] |= add;
             }
         }
-        if (mask_u8) {
+        if (U8OUT) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int y = yo + 4 * g + r;
@@ -594,14 +610,24 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
         if (dbg == 1) { asm volatile("" :: "s"(pw[0]), "s"(pw[1]), "s"(pw[2]), "s"(pw[3])); continue; }
         // (Combining the four strips' quarters of a word through LDS into 8-byte stores was measured: the barrier it needs
         //  per step costs more than the 2-byte stores - 3.5 us per frame against 3.2.)
-        if (lane < 16) {                                 // lane = row of the tile: 16 mask bits of this strip
+        {
+            // lane j < 16 stores row yo + j: quarter j >> 2 of pw[j & 3].  Written as masked arithmetic on the two halves
+            // (a chain of ?: on the scalar masks compiles to nested branches) and with a 32-bit offset from a scalar base.
+            const u32 x01l = (u32)pw[0] ^ (u32)pw[1], x01h = (u32)(pw[0] >> 32) ^ (u32)(pw[1] >> 32);
+            const u32 x23l = (u32)pw[2] ^ (u32)pw[3], x23h = (u32)(pw[2] >> 32) ^ (u32)(pw[3] >> 32);
+            const u32 t0l = (x01l & sel1) ^ (u32)pw[0], t0h = (x01h & sel1) ^ (u32)(pw[0] >> 32);
+            const u32 t1l = (x23l & sel1) ^ (u32)pw[2], t1h = (x23h & sel1) ^ (u32)(pw[2] >> 32);
+            const u32 vl = ((t0l ^ t1l) & sel2) ^ t0l, vh = ((t0h ^ t1h) & sel2) ^ t0h;
+            const u32 piece = (lane & 8 ? vh : vl) >> (16 * ((lane >> 2) & 1));
+            // The store itself is issued at the top of the NEXT step, behind that step's load: the wait for the row bits at
+            // a step's top then only ever covers a store that is a whole step old (issued here it cost 0.35 us per frame,
+            // the wait taking the store's acknowledgement with it).
             const int y = yo + lane;
-            const u64 wsel = (lane & 3) == 0 ? pw[0] : (lane & 3) == 1 ? pw[1] : (lane & 3) == 2 ? pw[2] : pw[3];
-            if (y < H)
-                reinterpret_cast<unsigned short*>(mbits)[(((int64_t)n * H + y) * WW + blockIdx.x) * 4 + wave] =
-                    (unsigned short)(wsel >> (16 * (lane >> 2)));
+            pend_piece = piece;
+            pend_off = (lane < 16 && y < H) ? (u32)__mul24(y, 4 * WW) : 0xFFFFFFFFu;
         }
     }
+    if (pend_off != 0xFFFFFFFFu) mb16[pend_off] = (unsigned short)pend_piece;
     if (lane == 0) {                                     // (wave-uniform counters)
         if (amb) atomicAdd(&fstat[n * 8 + 1], amb);
         if (nexact) atomicAdd(&fstat[n * 8 + 3], nexact);
@@ -751,14 +777,13 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         const int tps = (tilesY + nseg - 1) / nseg;
         nseg = (tilesY + tps - 1) / tps;
         dim3 grid(h->WW, nseg, nb);
-        if (!h->bp.small)
-            VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<80, -40>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
-                       h->ncc_ry, h->ncc_frags, h->ncc_tab, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
-                       VBS_KNOB("VBS_NCC_DBG"), h->ncc);
-        else
-            VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,
-                       h->ncc_ry, h->ncc_frags, h->ncc_tab, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,
-                       VBS_KNOB("VBS_NCC_DBG"), h->ncc);
+#define NCC_GO(L_, LO_, U8)                                                                                      \
+    VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<L_, LO_, U8>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,    \
+               h->ncc_ry, h->ncc_frags, h->ncc_tab, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,     \
+               VBS_KNOB("VBS_NCC_DBG"), h->ncc)
+        if (!h->bp.small) { if (mask_u8) NCC_GO(80, -40, true); else NCC_GO(80, -40, false); }
+        else { if (mask_u8) NCC_GO(33, -16, true); else NCC_GO(33, -16, false); }
+#undef NCC_GO
         return;
     }
     dim3 grid(h->WW, (h->H + 63) / 64, nb);
