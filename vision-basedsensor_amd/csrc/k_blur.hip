@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256) void k_gray(const u8* __restrict__ frames, int
             const uint4* s4 = reinterpret_cast<const uint4*>(src + pb * 3);
             uint4 v[6];
 #pragma unroll
-            for (int q = 0; q < 6; ++q) v[q] = __builtin_nontemporal_load(s4 + q * 256 + threadIdx.x);
+            for (int q = 0; q < 6; ++q) {
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(s4 + q * 256 + threadIdx.x));
+                v[q] = make_uint4(t.x, t.y, t.z, t.w);
+            }
 #pragma unroll
             for (int q = 0; q < 6; ++q) raw[q / 3][(q % 3) * 256 + threadIdx.x] = v[q];
             __syncthreads();

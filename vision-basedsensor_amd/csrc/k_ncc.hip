@@ -290,10 +290,15 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     constexpr int RSTR = RING + 8;                      // halves per ring column (+16 B: conflict-free 16-byte reads)
     constexpr int CSTR = RING + 16;                     // bytes per count-ring column (conflict-free as well)
     constexpr int L2 = L * L;
-    // 37.9 KB for l = 80: four workgroups (16 waves) per CU; the time of this kernel goes with 1 / waves per SIMD
-    __shared__ __align__(16) uint4 lut[256];
-    __shared__ __align__(16) _Float16 ring[4][2][16 * RSTR];
-    __shared__ __align__(16) u8 ringc[4][16 * CSTR];
+    constexpr int ECAP = 2 * NT + 2;                    // tiles with undecided pixels a wave may queue before it drains them
+    // 39.5 KB for l = 80: four workgroups (16 waves) per CU; the time of this kernel goes with 1 / waves per SIMD.
+    // (One struct: the table first, so that a ring address minus one ring length is still a valid LDS address.)
+    __shared__ struct __align__(16) {
+        uint4 lut[256];
+        _Float16 ring[4][2][16 * RSTR];
+        u8 ringc[4][16 * CSTR];
+        u32 elist[4][ECAP][10];                         // yo, -, uw[0..3] of a queued tile
+    } sm;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, and known to the compiler to be
     const int g = lane >> 4, q = lane & 15;
@@ -309,10 +314,10 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
         u32 w[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) w[d] = (((u32)tid >> (2 * d)) & 1u ? 0x3C00u : 0u) | (((u32)tid >> (2 * d + 1)) & 1u ? 0x3C000000u : 0u);
-        lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);
+        sm.lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    for (int i = lane; i < 2 * 16 * RSTR / 8; i += 64) reinterpret_cast<uint4*>(&ring[wave][0][0])[i] = make_uint4(0, 0, 0, 0);
-    for (int i = lane; i < 16 * CSTR / 16; i += 64) reinterpret_cast<uint4*>(&ringc[wave][0])[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < 2 * 16 * RSTR / 8; i += 64) reinterpret_cast<uint4*>(&sm.ring[wave][0][0])[i] = make_uint4(0, 0, 0, 0);
+    for (int i = lane; i < 16 * CSTR / 16; i += 64) reinterpret_cast<uint4*>(&sm.ringc[wave][0])[i] = make_uint4(0, 0, 0, 0);
     h8 whi[NKS], wlo[NKS], one[NKS];
 #pragma unroll
     for (int s = 0; s < NKS; ++s) {
@@ -340,12 +345,12 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
 
     const double mu = (double)(255ull * (u64)fstat[n * 8 + 0]) / (double)((int64_t)H * W);
     const double full_t = ry[min(max(-LO, 0), H - 1)] * rx[min(max(-LO, 0), W - 1)];
-    // theta(c) = ks sqrt(c (l^2 - c)) + kc c + k0 on 2^20 G; th0 decides the empty window.  (Uniform values are made so
-    // explicitly: they then live in scalar registers.)
-    // (as inline assembly: the builtin is folded away for a value the compiler already knows to be uniform, and the
-    //  value then stays in the vector register its float64 -> float32 conversion produced)
-    auto uni = [](float v) { float o; asm("s_nop 4\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(o) : "v"(v)); return o; };   // (s_nop: the hazards the
-    // compiler pads for v_readfirstlane after a VALU write, and before a read of the scalar, are ours inside an asm)
+    // theta(c) = ks sqrt(c (l^2 - c)) + kc c + k0 on 2^20 G; th0 decides the empty window.  Uniform values are made so
+    // explicitly and then live in scalar registers.  (As inline assembly: the builtin is folded away for a value the
+    // compiler already knows to be uniform, which then stays in the vector register its float64 -> float32 conversion
+    // produced.  The s_nop are the hazards the compiler pads for v_readfirstlane after a VALU write, and before a read of
+    // the scalar: inside an asm they are ours.)
+    auto uni = [](float v) { float o; asm("s_nop 4\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(o) : "v"(v)); return o; };
     const float ks = (float)(sqrt(nc.thr2 * nc.T2) / (double)L * (NCC_WSCALE * NCC_WSCALE));
     const float kc = uni((float)(nc.tbar * (NCC_WSCALE * NCC_WSCALE)));
     const float k0 = (float)(mu * (full_t - nc.l2 * nc.tbar) / 255.0 * (NCC_WSCALE * NCC_WSCALE));
@@ -357,14 +362,30 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     // and lies wholly inside the image for yo <= valid_hi.
     const bool th0pos = __builtin_amdgcn_readfirstlane(th0 > 0.0f ? 1 : 0) != 0;
     const bool xin = (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
+#ifdef VBS_DEBUG_KNOBS
+    const int plain_lo = dbg == 10 ? -0x40000000 : (th0pos && xin && dbg != 11) ? -LO : 0x7FFFFFFF, plain_hi = dbg == 10 ? 0x40000000 : H - 1 - 15 - HI;
+#else
     const int plain_lo = (th0pos && xin) ? -LO : 0x7FFFFFFF, plain_hi = H - 1 - 15 - HI;
+#endif
     const int valid_hi = (xw + 15 < W) ? H - 16 : -1;
     // constants of the border tiles' threshold
     const float muf = uni((float)mu), tbarf = uni((float)nc.tbar), ktf = uni((float)(nc.tbar * 255.0)), il2f = uni((float)nc.inv_l2);
     const float krf = uni((float)(nc.thr2 * nc.T2));
-    _Float16* rhi = &ring[wave][0][q * RSTR];
-    _Float16* rlo = &ring[wave][1][q * RSTR];
-    u8* rct = &ringc[wave][q * CSTR];
+    const float mukf = uni((float)(mu / 255.0 * (NCC_WSCALE * NCC_WSCALE)));
+    // per-lane (column) factors of a border window, and the window sums of a column whose rows are all inside
+    const int xq = min(xw + q, W - 1);
+    const float nxf = (float)(min(xq + HI, W - 1) - max(xq + LO, 0) + 1), rxf = (float)rx[xq];
+    const float nnc = (float)L * nxf, stc = (float)ry[min(max(-LO, 0), H - 1)] * rxf, dd0c = stc - nnc * tbarf;
+    // Ring addresses.  The step loop is unrolled over the NT ring slots, so every slot offset is a constant of its copy
+    // of the body and folds into the LDS instruction; what depends on the lane is kept in these pointers.  A k-step of
+    // 32 ring rows that starts in the last slot wraps to slot 0 for lane groups 2 and 3: they use rdw.
+    _Float16* const ringw = &sm.ring[wave][0][q * RSTR];
+    _Float16* const wr = ringw + 4 * g;                 // + 16 slot: this lane's four rows of a new tile
+    const _Float16* const rd = ringw + 8 * g;           // + first row of the k-step: eight rows of column q
+    const _Float16* const rdw = rd - (g >= 2 ? RING : 0);
+    u8* const cw = &sm.ringc[wave][q * CSTR] + 4 * g;
+    const u8* const cbase = &sm.ringc[wave][q * CSTR];
+    constexpr int LOFS = 16 * RSTR;                     // hi plane -> lo plane, in halves
     u32 amb = 0, nexact = 0;
     const u32 sel1 = 0u - ((u32)lane & 1u), sel2 = 0u - (((u32)lane >> 1) & 1u);
     unsigned short* mb16 = reinterpret_cast<unsigned short*>(mbits) + ((int64_t)n * H * WW + blockIdx.x) * 4 + wave;   // (uniform)
@@ -378,199 +399,50 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     const u32* fb32 = reinterpret_cast<const u32*>(fbits) + d0;   // (uniform)
     auto load_rows = [&](int t) {
         const int y = Y0 + LO + 16 * t + q;
-        const u64* row = fbits + (int64_t)min(max(y, 0), H - 1) * WW;
         if (wide) {                                      // (32-bit offset from a scalar base: no 64-bit multiply per step)
             const u32* r32 = fb32 + (u32)__mul24(min(max(y, 0), H - 1), 2 * WW);
             nraw = make_uint4(r32[0], r32[1], r32[2], r32[3]);
         } else {
+            const u64* row = fbits + (int64_t)min(max(y, 0), H - 1) * WW;
             u64 w0 = load_bits(row, WW, wstart), w1 = load_bits(row, WW, wstart + 64);
             nraw = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, 0u);
         }
     };
-    load_rows(0);
+    // Undecided pixels (a handful per frame) leave the loop: a tile that has any is queued - its row and the four masks
+    // of its undecided pixels - with those pixels stored as background, and the queue is drained every NT steps at the
+    // latest: exact float64 G straight from the bits, one pixel at a time by the whole wave (lane i sums rows i and
+    // i + 64 of the window from their runs, the L products are added in ascending row order exactly as ncc_exact_G does,
+    // row sums broadcast from their lanes, template factors read as scalars), and a pixel found foreground is OR-ed
+    // into the stored mask word.
+    int ecnt = 0;
     u32 pend_piece = 0, pend_off = 0xFFFFFFFFu;
-    for (int t = 0; t < nsteps; ++t) {
-        const uint4 raw = nraw;
-        const int ytile = Y0 + LO + 16 * t;
-        if (t + 1 < nsteps) load_rows(t + 1);
-        if (pend_off != 0xFFFFFFFFu) mb16[pend_off] = (unsigned short)pend_piece;   // the previous step's mask rows
+    auto flush_pending = [&]() {
+        if (pend_off != 0xFFFFFFFFu) mb16[pend_off] = (unsigned short)pend_piece;
         pend_off = 0xFFFFFFFFu;
-        u32 dw[3];
-        if (wide) {
-            dw[0] = __builtin_amdgcn_alignbit(raw.y, raw.x, dsh);
-            dw[1] = __builtin_amdgcn_alignbit(raw.z, raw.y, dsh);
-            dw[2] = __builtin_amdgcn_alignbit(raw.w, raw.z, dsh);
-        } else {
-            dw[0] = raw.x; dw[1] = raw.y; dw[2] = raw.z;
-        }
-        if (ytile < 0 || ytile + 15 >= H) {              // uniform: rows outside the image are empty
-            const bool rowin = (ytile + q >= 0) && (ytile + q < H);
-            dw[0] = rowin ? dw[0] : 0u; dw[1] = rowin ? dw[1] : 0u; dw[2] = rowin ? dw[2] : 0u;
-        }
-        // ---- horizontal tile t ----
-        f4 ah = {0, 0, 0, 0}, ac = {0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            const u32 byte = (dw[s] >> (8 * g)) & 255u;
-            const h8 a = __builtin_bit_cast(h8, lut[byte]);
-            ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, whi[s], ah, 0, 0, 0);
-            ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wlo[s], ah, 0, 0, 0);
-            ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, one[s], ac, 0, 0, 0);
-        }
-        {
-            // hi = the float32 cut to float16's 10 mantissa bits (exact in float16: 0.25 <= h <= 1024), lo = the rest;
-            // the count (an integer <= l) goes to the ring as a byte
-            h4 vh, vl;
-            u32 vc = 0;
-#pragma unroll
+    };
+    auto drain = [&]() {
+        __builtin_amdgcn_s_waitcnt(0x0F70);              // the plain stores of these rows are out before the atomics
+        const double* cgd = tab + VBS_NCC_MAXL;
+        u32* mb32 = reinterpret_cast<u32*>(mbits) + (int64_t)n * H * WW * 2;
+        for (int e = 0; e < ecnt; ++e) {
+            const int yo = (int)__builtin_amdgcn_readfirstlane((int)sm.elist[wave][e][0]);
+#pragma unroll 1
             for (int r = 0; r < 4; ++r) {
-                const float hi_f = __uint_as_float(__float_as_uint(ah[r]) & 0xFFFFE000u);
-                vh[r] = (_Float16)hi_f;
-                vl[r] = (_Float16)(ah[r] - hi_f);
-                vc = __builtin_amdgcn_cvt_pk_u8_f32(ac[r], r, vc);
-            }
-            const int ro = 16 * (t % NT) + 4 * g;
-            *reinterpret_cast<h4*>(rhi + ro) = vh;
-            *reinterpret_cast<h4*>(rlo + ro) = vl;
-            *reinterpret_cast<u32*>(rct + ro) = vc;
-        }
-        if (t < NT - 1 || dbg == 3) continue;            // (dbg: tools/ phase timing, always 0 in the product library)
-        // ---- vertical: output tile rows yo .. yo + 15 from ring tiles t-NT+1 .. t ----
-        const int yo = Y0 + 16 * (t - (NT - 1));
-        const int base = 16 * ((t - (NT - 1)) % NT);
-        f4 G = {0, 0, 0, 0};
-        i4 C = {0, 0, 0, 0};
-#pragma unroll
-        for (int s = 0; s < NKS; ++s) {
-            int ub = base + 32 * s;                      // uniform part of the ring offset, wraps at RING
-            ub = ub >= RING ? ub - RING : ub;
-            ub = ub >= RING ? ub - RING : ub;
-            int ro = ub + 8 * g;
-            ro = min((u32)ro, (u32)(ro - RING));         // ro >= RING ? ro - RING : ro
-            const h8 bh = *reinterpret_cast<const h8*>(rhi + ro);
-            const h8 bl = *reinterpret_cast<const h8*>(rlo + ro);
-            G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bh, G, 0, 0, 0);
-            G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bl, G, 0, 0, 0);
-            G = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[s], bh, G, 0, 0, 0);
-        }
-#pragma unroll
-        for (int s = 0; s < NK8; ++s) {
-            // 16 rows per lane group; groups past the ring carry zero weights and may read any valid 16 bytes
-            int ro = base + 16 * min(4 * s + g, NT - 1);
-            ro = min((u32)ro, (u32)(ro - RING));
-            const i4 bc = *reinterpret_cast<const i4*>(rct + ro);
-            C = __builtin_amdgcn_mfma_i32_16x16x64_i8(one8[s], bc, C, 0, 0, 0);
-        }
-#ifdef VBS_DEBUG_KNOBS
-        if (dbg == 8 && mask_u8) {                       // tools/gpu_mask_diff.py: the window counts instead of the mask
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = yo + 4 * g + r, x = xw + q;
-                if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)C[r];
-            }
-            continue;
-        }
-#endif
-        if (dbg == 2) { asm volatile("" :: "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(C[0]), "v"(C[1]), "v"(C[2]), "v"(C[3])); continue; }
-        // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
-        const int x = xw + q;
-        const f2 Gp[2] = {{G[0], G[1]}, {G[2], G[3]}};
-        const f2 Cp[2] = {{(float)C[0], (float)C[1]}, {(float)C[2], (float)C[3]}};
-        // pw[r] / uw[r]: 64-bit masks (wave-uniform, kept in scalar registers) of the pixels decided foreground / left
-        // undecided by the filter, bit = lane
-        u64 pw[4] = {0, 0, 0, 0}, uw[4] = {0, 0, 0, 0};
-        if (yo >= plain_lo && yo <= plain_hi) {          // wave-uniform: windows inside the image, empty window = background
-            // G > theta(c)  <=>  u = G - (kc c + k0) > 0 and u^2 > ks^2 c (l^2 - c), taken with G (1 -+ rel): no square
-            // root, and a tile whose every u is negative (the template correlates negatively: about half of them) is
-            // background after three packed operations per pixel pair.  k0e >= 0.01 keeps an empty window (G = 0
-            // exactly) at u < 0; against kc c ~ 1e5 for c >= 1 it is far inside the margin.
-            const f2 rel2 = {NCC_REL, NCC_REL}, nkc2 = {-kc, -kc}, k02 = {k0e, k0e};
-            f2 u[2], uhi[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {                // (one scalar operand per packed instruction)
-                u[i] = __builtin_elementwise_fma(Cp[i], nkc2, Gp[i] - k02);
-                uhi[i] = __builtin_elementwise_fma(Gp[i], rel2, u[i]);
-            }
-            const float umax = fmaxf(fmaxf(uhi[0].x, uhi[0].y), fmaxf(uhi[1].x, uhi[1].y));
-            if (__ballot(umax >= 0.0f)) {
-                // (the roundings of a and of the two squares, 2.4e-7 relative, sit inside NCC_REL - 2^-16 = 4.7e-6)
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const f2 ulo = __builtin_elementwise_fma(Gp[i], -rel2, u[i]);
-                    const f2 a = (Cp[i] * ((float)L2 - Cp[i])) * ks2;     // c (l^2 - c) is an exact integer < 2^24
-#pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        const int r = 2 * i + j;
-                        pw[r] = __ballot(ulo[j] * fabsf(ulo[j]) > a[j]);          // ulo > 0 and ulo^2 > ks^2 p: foreground
-                        uw[r] = ~(pw[r] | __ballot(uhi[i][j] * fabsf(uhi[i][j]) <= a[j]));   // uhi < 0 or uhi^2 <= ks^2 p: background
-                    }
-                }
-            }
-        } else {
-            // Border tile (or th0 <= 0): theta in float32 from the collected form of the general window,
-            //   var = 255^2 c (1 - c / l^2) + (1 - nn / l^2) mu (nn mu - 510 c),   rest = -tbar 255 c - mu (sum_t - nn tbar),
-            // whose error stays below 1e-4 theta + 1 in these units (var loses at most 5e-6 to cancellation, the last
-            // subtraction 1e-4 absolute on theta 255): pixels within 1e-3 theta + 2 of it go to the exact path.
-            const int xq = min(x, W - 1);
-            const float nxf = (float)(min(xq + HI, W - 1) - max(xq + LO, 0) + 1), rxf = (float)rx[xq];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int yc = min(yo + 4 * g + r, H - 1);
-                const float cf = Cp[r >> 1][r & 1];
-                const float nn = (float)(min(yc + HI, H - 1) - max(yc + LO, 0) + 1) * nxf, st = (float)ry[yc] * rxf;
-                const float d0 = st - nn * tbarf, a0 = 1.0f - nn * il2f;
-                const float rest = -(ktf * cf) - muf * d0;
-                const float var = 65025.0f * cf * (1.0f - cf * il2f) + a0 * muf * (nn * muf - 510.0f * cf);
-                const float t1 = (__builtin_amdgcn_sqrtf(fmaxf(krf * var, 0.0f)) - rest) * (float)(NCC_WSCALE * NCC_WSCALE / 255.0);
-                // empty window: G = 0, num = rest = -mu d0 and rhs = thr2 T2 a nn mu^2: background unless d0 < 0 and
-                // d0^2 > thr2 T2 a nn (mu cancels); decided here with a factor 2 to spare, else left to the exact path
-                const float t0 = ((d0 > -1e-4f) | (d0 * d0 < 0.5f * krf * a0 * nn)) ? (float)NCC_NEVER : 0.0f;
-                const float th = cf == 0.0f ? t0 : t1;
-                const float m = __builtin_fmaf(fabsf(th), 1e-3f, 2.0f), d = G[r] - th;
-                pw[r] = __ballot(d > m);
-                uw[r] = ~(pw[r] | __ballot(d < -m));
-            }
-        }
-        if (yo > valid_hi) {                             // uniform: tiles that stick out of the image
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const u64 v = __ballot((yo + 4 * g + r < H) && (x < W));
-                pw[r] &= v; uw[r] &= v;
-            }
-        }
-#ifdef VBS_DEBUG_KNOBS
-        if (dbg == 9 && mask_u8) {                       // tools/gpu_mask_diff.py: the filter's verdict (1 fg, 2 undecided)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = yo + 4 * g + r;
-                if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)(((pw[r] >> lane) & 1ull) | (((uw[r] >> lane) & 1ull) << 1));
-            }
-            continue;
-        }
-#endif
-        if (uw[0] | uw[1] | uw[2] | uw[3]) {
-            // Rare (a handful of pixels per frame): exact float64 G straight from the bits, one pixel at a time by the
-            // whole wave: lane i sums rows i and i + 64 of the window from their runs, then the L products are added
-            // in ascending row order exactly as ncc_exact_G does (row sums broadcast from their lanes, template factors
-            // read as scalars).  The decision is wave-uniform, so the masks stay in scalar registers.
-            const double* cgd = tab + VBS_NCC_MAXL;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                u64 ur = uw[r];
-                const int crl = C[r];
-                u64 add = 0;
+                u64 ur = (u64)(u32)__builtin_amdgcn_readfirstlane((int)sm.elist[wave][e][2 + 2 * r]) |
+                         ((u64)(u32)__builtin_amdgcn_readfirstlane((int)sm.elist[wave][e][3 + 2 * r]) << 32);
                 while (ur) {
                     const int l = __ffsll((long long)ur) - 1;
                     ur &= ur - 1ull;
                     const int y = yo + 4 * (l >> 4) + r, xe = xw + (l & 15);
-                    const int cr = __builtin_amdgcn_readlane(crl, l);
                     double hv[(L + 63) / 64];
+                    u32 cnt = 0;
 #pragma unroll
                     for (int k = 0; k < (L + 63) / 64; ++k) {
                         const int i = lane + 64 * k, yy = y + LO + i;
-                        u32 dummy = 0;
-                        hv[k] = (i < L && yy >= 0 && yy < H) ? ncc_row_exact<L, LO>(fbits + (int64_t)yy * WW, WW, xe, cgd, &dummy) : 0.0;
+                        hv[k] = (i < L && yy >= 0 && yy < H) ? ncc_row_exact<L, LO>(fbits + (int64_t)yy * WW, WW, xe, cgd, &cnt) : 0.0;
                     }
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) cnt += (u32)__shfl_xor((int)cnt, off);
                     double Ge = 0.0;
 #pragma unroll
                     for (int k = 0; k < (L + 63) / 64; ++k) {
@@ -585,7 +457,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                     int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
                     int nx = min(xe + HI, W - 1) - max(xe + LO, 0) + 1;
                     double nn = (double)(ny * nx), sum_t = ry[y] * rx[xe];
-                    double sum_I = 255.0 * (double)cr;
+                    double sum_I = 255.0 * (double)cnt;
                     double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
                     double s1 = sum_I - nn * mu;
                     double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
@@ -594,40 +466,238 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                     double num = 255.0 * Ge + rest;
                     const int flags = __builtin_amdgcn_readfirstlane((var > 0.0 ? 1 : 0) | ((var > 0.0 && num > 0.0 && num * num > rhs) ? 2 : 0) |
                                                                      ((var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) ? 4 : 0));
-                    if (flags & 2) add |= 1ull << l;
+                    if ((flags & 2) && lane == 0) {
+                        atomicOr(&mb32[(u32)__mul24(y, 2 * WW) + (u32)(xe >> 5)], 1u << (xe & 31));
+                        if (U8OUT) mask_u8[((int64_t)n * H + y) * W + xe] = 1;
+                    }
                     if (flags & 1) { nexact++; if (flags & 4) amb++; }
                 }
-                pw[r] |= add;
             }
         }
-        if (U8OUT) {
+        ecnt = 0;
+    };
+    load_rows(0);
+    for (int t0 = 0; t0 < nsteps; t0 += NT) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int y = yo + 4 * g + r;
-                if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)((pw[r] >> lane) & 1ull);
+        for (int u = 0; u < NT; ++u) {                   // u = ring slot of step t: a constant of this copy of the body
+            const int t = t0 + u;
+            if (t >= nsteps) break;                      // uniform
+            const uint4 raw = nraw;
+            const int ytile = Y0 + LO + 16 * t;
+            if (t + 1 < nsteps) load_rows(t + 1);
+            // The previous step's mask rows, stored behind this step's load: the wait for the row bits at a step's top
+            // then only ever covers a store that is a whole step old.
+            flush_pending();
+            u32 dw[3];
+            if (wide) {
+                dw[0] = __builtin_amdgcn_alignbit(raw.y, raw.x, dsh);
+                dw[1] = __builtin_amdgcn_alignbit(raw.z, raw.y, dsh);
+                dw[2] = __builtin_amdgcn_alignbit(raw.w, raw.z, dsh);
+            } else {
+                dw[0] = raw.x; dw[1] = raw.y; dw[2] = raw.z;
+            }
+            if (ytile < 0 || ytile + 15 >= H) {          // uniform: rows outside the image are empty
+                const bool rowin = (ytile + q >= 0) && (ytile + q < H);
+                dw[0] = rowin ? dw[0] : 0u; dw[1] = rowin ? dw[1] : 0u; dw[2] = rowin ? dw[2] : 0u;
+            }
+            // ---- horizontal tile t ----
+            f4 ah = {0, 0, 0, 0}, ac = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const u32 byte = (dw[s] >> (8 * g)) & 255u;
+                const h8 a = __builtin_bit_cast(h8, sm.lut[byte]);
+                ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, whi[s], ah, 0, 0, 0);
+                ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wlo[s], ah, 0, 0, 0);
+                ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, one[s], ac, 0, 0, 0);
+            }
+            {
+                // hi = the float32 cut to float16's 10 mantissa bits (exact in float16: 0.25 <= h <= 1024), lo = the
+                // rest; the count (an integer <= l) goes to the ring as a byte
+                h4 vh, vl;
+                u32 vc = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hi_f = __uint_as_float(__float_as_uint(ah[r]) & 0xFFFFE000u);
+                    vh[r] = (_Float16)hi_f;
+                    vl[r] = (_Float16)(ah[r] - hi_f);
+                    vc = __builtin_amdgcn_cvt_pk_u8_f32(ac[r], r, vc);
+                }
+                *reinterpret_cast<h4*>(wr + 16 * u) = vh;
+                *reinterpret_cast<h4*>(wr + LOFS + 16 * u) = vl;
+                *reinterpret_cast<u32*>(cw + 16 * u) = vc;
+            }
+            if (t < NT - 1 || dbg == 3) continue;        // (dbg: tools/ phase timing, always 0 in the product library)
+            // ---- vertical: output tile rows yo .. yo + 15 from ring tiles t-NT+1 .. t (slots B, B + 1, ...) ----
+            const int yo = Y0 + 16 * (t - (NT - 1));
+            constexpr int dummy_nt = NT;                 // (u + 1) % NT below is a constant after unrolling
+            const int B = (u + 1) % dummy_nt;
+            f4 G = {0, 0, 0, 0};
+            i4 C = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) {
+                const int r0 = (16 * B + 32 * s) % RING;  // first ring row of the k-step
+                const _Float16* p = (r0 + 32 <= RING ? rd : rdw) + r0;
+                const h8 bh = *reinterpret_cast<const h8*>(p);
+                const h8 bl = *reinterpret_cast<const h8*>(p + LOFS);
+                G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bh, G, 0, 0, 0);
+                G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bl, G, 0, 0, 0);
+                G = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[s], bh, G, 0, 0, 0);
+            }
+#pragma unroll
+            for (int s = 0; s < NK8; ++s) {
+                // 16 rows per lane group; groups past the ring carry zero weights and may read any valid 16 bytes
+                const int gi = min(4 * s + g, NT - 1);
+                const int slot = B + gi - (gi >= NT - B ? NT : 0);
+                const i4 bc = *reinterpret_cast<const i4*>(cbase + 16 * slot);
+                C = __builtin_amdgcn_mfma_i32_16x16x64_i8(one8[s], bc, C, 0, 0, 0);
+            }
+#ifdef VBS_DEBUG_KNOBS
+            if (dbg == 8 && mask_u8) {                   // tools/gpu_mask_diff.py: the window counts instead of the mask
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = yo + 4 * g + r, x = xw + q;
+                    if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)C[r];
+                }
+                continue;
+            }
+#endif
+            if (dbg == 2) { asm volatile("" :: "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(C[0]), "v"(C[1]), "v"(C[2]), "v"(C[3])); continue; }
+            // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
+            const int x = xw + q;
+            const f2 Gp[2] = {{G[0], G[1]}, {G[2], G[3]}};
+            const f2 Cp[2] = {{(float)C[0], (float)C[1]}, {(float)C[2], (float)C[3]}};
+            // pw[r] / uw[r]: 64-bit masks (wave-uniform, kept in scalar registers) of the pixels decided foreground / left
+            // undecided by the filter, bit = lane
+            u64 pw[4] = {0, 0, 0, 0}, uw[4] = {0, 0, 0, 0};
+            if (yo >= plain_lo && yo <= plain_hi) {      // wave-uniform: windows inside the image, empty window = background
+                // G > theta(c)  <=>  u = G - (kc c + k0) > 0 and u^2 > ks^2 c (l^2 - c), taken with G (1 -+ rel): no square
+                // root, and a tile whose every u is negative (the template correlates negatively: about half of them) is
+                // background after three packed operations per pixel pair.  k0e >= 0.01 keeps an empty window (G = 0
+                // exactly) at u < 0; against kc c ~ 1e5 for c >= 1 it is far inside the margin.
+                const f2 rel2 = {NCC_REL, NCC_REL}, nkc2 = {-kc, -kc}, k02 = {k0e, k0e};
+                f2 uu[2], uhi[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {            // (one scalar operand per packed instruction)
+                    uu[i] = __builtin_elementwise_fma(Cp[i], nkc2, Gp[i] - k02);
+                    uhi[i] = __builtin_elementwise_fma(Gp[i], rel2, uu[i]);
+                }
+                const float umax = fmaxf(fmaxf(uhi[0].x, uhi[0].y), fmaxf(uhi[1].x, uhi[1].y));
+                if (__ballot(umax >= 0.0f) || dbg == 12) {
+                    // (the roundings of a and of the two squares, 2.4e-7 relative, sit inside NCC_REL - 2^-16 = 4.7e-6)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const f2 ulo = __builtin_elementwise_fma(Gp[i], -rel2, uu[i]);
+                        const f2 a = (Cp[i] * ((float)L2 - Cp[i])) * ks2;     // c (l^2 - c) is an exact integer < 2^24
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int r = 2 * i + j;
+                            pw[r] = __ballot(ulo[j] * fabsf(ulo[j]) > a[j]);          // ulo > 0 and ulo^2 > ks^2 p: foreground
+                            uw[r] = ~(pw[r] | __ballot(uhi[i][j] * fabsf(uhi[i][j]) <= a[j]));   // uhi < 0 or uhi^2 <= ks^2 p: background
+                        }
+                    }
+                }
+            } else {
+                // Border tile (or th0 <= 0): theta in float32 from the collected form of the general window,
+                //   var = 255^2 c (1 - c / l^2) + (1 - nn / l^2) mu (nn mu - 510 c),   rest = -tbar 255 c - mu (sum_t - nn tbar),
+                // whose error stays below 1e-4 theta + 1 in these units (var loses at most 5e-6 to cancellation, the last
+                // subtraction 1e-4 absolute on theta 255): pixels within 1e-3 theta + 2 of it go to the exact path.
+                // num > 0 <=> G > lin = kc c + (mu 2^20 / 255) d0 with d0 = sum_t - nn tbar: a tile whose every pixel has
+                // G - lin + margin < 0 is background (most border tiles: their windows hang over the dark frame).  The
+                // margin covers G's 2^-16 and the float32 roundings of lin (1e-6 of its terms, also where they cancel).
+                // A strip at the left / right edge of the image is border all the way down, but with whole rows inside
+                // for most of it: there nn, sum_t and d0 are the per-lane constants of the prologue.
+                float nnv[4], stv[4], dd0[4], uhi[4];
+                if (yo + LO >= 0 && yo <= plain_hi) {    // uniform: the windows' rows are all inside
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { nnv[r] = nnc; stv[r] = stc; dd0[r] = dd0c; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int yc = min(yo + 4 * g + r, H - 1);
+                        nnv[r] = (float)(min(yc + HI, H - 1) - max(yc + LO, 0) + 1) * nxf;
+                        stv[r] = (float)ry[yc] * rxf;
+                        dd0[r] = stv[r] - nnv[r] * tbarf;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float cf = Cp[r >> 1][r & 1], kcc = kc * cf;
+                    const float mrg = __builtin_fmaf(1e-3f, G[r] + kcc, __builtin_fmaf(1e-5f * mukf, stv[r], 2.0f));
+                    uhi[r] = (G[r] - kcc) - mukf * dd0[r] + mrg;
+                }
+                if (__ballot(fmaxf(fmaxf(uhi[0], uhi[1]), fmaxf(uhi[2], uhi[3])) >= 0.0f)) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float cf = Cp[r >> 1][r & 1];
+                        const float nn = nnv[r], a0 = 1.0f - nn * il2f;
+                        const float rest = -(ktf * cf) - muf * dd0[r];
+                        const float var = 65025.0f * cf * (1.0f - cf * il2f) + a0 * muf * (nn * muf - 510.0f * cf);
+                        const float t1 = (__builtin_amdgcn_sqrtf(fmaxf(krf * var, 0.0f)) - rest) * (float)(NCC_WSCALE * NCC_WSCALE / 255.0);
+                        // empty window: G = 0, num = rest = -mu d0 and rhs = thr2 T2 a nn mu^2: background unless d0 < 0 and
+                        // d0^2 > thr2 T2 a nn (mu cancels); decided here with a factor 2 to spare, else left to the exact path
+                        const float t0v = ((dd0[r] > -1e-4f) | (dd0[r] * dd0[r] < 0.5f * krf * a0 * nn)) ? (float)NCC_NEVER : 0.0f;
+                        const float th = cf == 0.0f ? t0v : t1;
+                        const float m = __builtin_fmaf(fabsf(th), 1e-3f, 2.0f), d = G[r] - th;
+                        pw[r] = __ballot(d > m);
+                        uw[r] = ~(pw[r] | __ballot(d < -m));
+                    }
+                }
+            }
+            if (yo > valid_hi) {                         // uniform: tiles that stick out of the image
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const u64 v = __ballot((yo + 4 * g + r < H) && (x < W));
+                    pw[r] &= v; uw[r] &= v;
+                }
+            }
+#ifdef VBS_DEBUG_KNOBS
+            if (dbg == 9 && mask_u8) {                   // tools/gpu_mask_diff.py: the filter's verdict (1 fg, 2 undecided)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = yo + 4 * g + r;
+                    if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)(((pw[r] >> lane) & 1ull) | (((uw[r] >> lane) & 1ull) << 1));
+                }
+                continue;
+            }
+#endif
+            if (uw[0] | uw[1] | uw[2] | uw[3]) {         // rare: queue the tile (see drain)
+                u32 v = (u32)yo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v = lane == 2 + 2 * r ? (u32)uw[r] : v;
+                    v = lane == 3 + 2 * r ? (u32)(uw[r] >> 32) : v;
+                }
+                if (lane < 10) sm.elist[wave][ecnt][lane] = v;
+                ecnt++;
+            }
+            if (U8OUT) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int y = yo + 4 * g + r;
+                    if (y < H && x < W) mask_u8[((int64_t)n * H + y) * W + x] = (u8)((pw[r] >> lane) & 1ull);
+                }
+            }
+            if (dbg == 1) { asm volatile("" :: "s"(pw[0]), "s"(pw[1]), "s"(pw[2]), "s"(pw[3])); continue; }
+            {
+                // lane j < 16 stores row yo + j: quarter j >> 2 of pw[j & 3].  Written as masked arithmetic on the two
+                // halves (a chain of ?: on the scalar masks compiles to nested branches), with a 32-bit offset from a
+                // scalar base.  (Combining the four strips' quarters of a word through LDS into 8-byte stores was measured:
+                // the barrier it needs per step costs more than the 2-byte stores.)
+                const u32 x01l = (u32)pw[0] ^ (u32)pw[1], x01h = (u32)(pw[0] >> 32) ^ (u32)(pw[1] >> 32);
+                const u32 x23l = (u32)pw[2] ^ (u32)pw[3], x23h = (u32)(pw[2] >> 32) ^ (u32)(pw[3] >> 32);
+                const u32 t0l = (x01l & sel1) ^ (u32)pw[0], t0h = (x01h & sel1) ^ (u32)(pw[0] >> 32);
+                const u32 t1l = (x23l & sel1) ^ (u32)pw[2], t1h = (x23h & sel1) ^ (u32)(pw[2] >> 32);
+                const u32 vl = ((t0l ^ t1l) & sel2) ^ t0l, vh = ((t0h ^ t1h) & sel2) ^ t0h;
+                const int y = yo + lane;
+                pend_piece = (lane & 8 ? vh : vl) >> (16 * ((lane >> 2) & 1));
+                pend_off = (lane < 16 && y < H) ? (u32)__mul24(y, 4 * WW) : 0xFFFFFFFFu;
             }
         }
-        if (dbg == 1) { asm volatile("" :: "s"(pw[0]), "s"(pw[1]), "s"(pw[2]), "s"(pw[3])); continue; }
-        // (Combining the four strips' quarters of a word through LDS into 8-byte stores was measured: the barrier it needs
-        //  per step costs more than the 2-byte stores - 3.5 us per frame against 3.2.)
-        {
-            // lane j < 16 stores row yo + j: quarter j >> 2 of pw[j & 3].  Written as masked arithmetic on the two halves
-            // (a chain of ?: on the scalar masks compiles to nested branches) and with a 32-bit offset from a scalar base.
-            const u32 x01l = (u32)pw[0] ^ (u32)pw[1], x01h = (u32)(pw[0] >> 32) ^ (u32)(pw[1] >> 32);
-            const u32 x23l = (u32)pw[2] ^ (u32)pw[3], x23h = (u32)(pw[2] >> 32) ^ (u32)(pw[3] >> 32);
-            const u32 t0l = (x01l & sel1) ^ (u32)pw[0], t0h = (x01h & sel1) ^ (u32)(pw[0] >> 32);
-            const u32 t1l = (x23l & sel1) ^ (u32)pw[2], t1h = (x23h & sel1) ^ (u32)(pw[2] >> 32);
-            const u32 vl = ((t0l ^ t1l) & sel2) ^ t0l, vh = ((t0h ^ t1h) & sel2) ^ t0h;
-            const u32 piece = (lane & 8 ? vh : vl) >> (16 * ((lane >> 2) & 1));
-            // The store itself is issued at the top of the NEXT step, behind that step's load: the wait for the row bits at
-            // a step's top then only ever covers a store that is a whole step old (issued here it cost 0.35 us per frame,
-            // the wait taking the store's acknowledgement with it).
-            const int y = yo + lane;
-            pend_piece = piece;
-            pend_off = (lane < 16 && y < H) ? (u32)__mul24(y, 4 * WW) : 0xFFFFFFFFu;
+        if (t0 + NT >= nsteps || ecnt > ECAP - NT) {     // uniform
+            flush_pending();
+            if (ecnt) drain();
         }
     }
-    if (pend_off != 0xFFFFFFFFu) mb16[pend_off] = (unsigned short)pend_piece;
     if (lane == 0) {                                     // (wave-uniform counters)
         if (amb) atomicAdd(&fstat[n * 8 + 1], amb);
         if (nexact) atomicAdd(&fstat[n * 8 + 3], nexact);
