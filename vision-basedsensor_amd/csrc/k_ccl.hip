@@ -244,20 +244,31 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
         for (int it = tid; it < items; it += CCL_NT) {
             CCL_ITEM_DECODE
             const u64* row = bits + (int64_t)y * WW;
+            // the chunk's words (CW <= 5, and the first word of the next chunk for the windows that straddle it) are all
+            // requested before any is used: one memory latency per chunk, not one per word
+            const int nw = j1 - j0;
+            const bool hasd = MODE == 1 && y + 1 < H;
+            u64 wv[6], dv[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const bool in = k <= nw && j0 + k < WW && (k < nw || MODE == 1);
+                wv[k] = in ? row[j0 + k] : 0ull;
+                dv[k] = (in && hasd) ? row[j0 + k + WW] : 0ull;
+            }
             u32 cnt = 0, p = j0 ? (u32)(row[j0 - 1] >> 63) : 0u;
             u64 any = 0;
-            for (int j = j0; j < j1; ++j) {
-                const u64 w = row[j];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                if (k >= nw) break;
+                const int j = j0 + k;
+                const u64 w = wv[k];
                 cnt += (u32)__popcll(ccl_starts(w, p));
                 p = (u32)(w >> 63);
                 any |= w;
                 if (MODE == 1) {
                     // bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the zero-padded
                     // image; this word counts the windows whose top row is its row (row 0 also the padding row above)
-                    const bool hasd = y + 1 < H;
-                    const u64 dn = hasd ? row[j + WW] : 0ull;
-                    const u64 wn_ = j + 1 < WW ? row[j + 1] : 0ull;
-                    const u64 dn_ = (hasd && j + 1 < WW) ? row[j + 1 + WW] : 0ull;
+                    const u64 dn = dv[k], wn_ = wv[k + 1], dn_ = dv[k + 1];
                     if (!(w | dn) && y != 0 && !((wn_ | dn_) & 1ull)) continue;
 #pragma unroll
                     for (int q = 0; q < 2; ++q) {
