@@ -67,11 +67,15 @@ int vbs_version(void);
  * - 15 (default): OpenCV 4.x, (3735 B + 19235 G + 9798 R + 2^14) >> 15;  14: OpenCV <= 3.4.1, (1868 B + 9617 G +
  * 4899 R + 2^13) >> 14.  The two agree wherever B = G = R.  VBS_OPT_FORCE_SEQ_MATCH (test hook): 1 makes
  * vbs_marker_center replay the reference's sequential contour <-> centre matching (:203-243) instead of the parallel
- * form that is proven equal to it.  VBS_OPT_GRAY_SIDE_STREAM (tuning, results identical): 1 (default) converts the
- * BGR frames of internal pass k + 1 on the handle's own stream while pass k computes, 0 converts in line. */
+ * form that is proven equal to it.  VBS_OPT_GRAY_SIDE_STREAM (tuning, results identical): 1 converts the
+ * BGR frames of internal pass k + 1 on the handle's own stream while pass k computes, 0 (default) converts in line.
+ * VBS_OPT_NCC_MARGIN (test hook, results identical): relative margin of the NCC's float32 filter in units of 1e-6
+ * (never below the 20 the error bound needs); a wide margin sends thousands of pixels per frame through the queued
+ * float64 re-evaluation. */
 #define VBS_OPT_GRAY_COEFFS      1
 #define VBS_OPT_FORCE_SEQ_MATCH  2
 #define VBS_OPT_GRAY_SIDE_STREAM 3
+#define VBS_OPT_NCC_MARGIN       4
 int vbs_set_option(vbs_handle* h, int option, int value);
 /* host-only helper: the 256-entry table that classifies a border pixel's 8-neighbourhood into the
  * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain

@@ -789,9 +789,8 @@ def test_real_sensor_frame(golden_dir, tmp_path):
 
 
 def test_bgr_frames_large_branch_fused_and_fallback():
-    """a3 + a4 on coloured 1280x1024 BGR frames (large branch): the blur kernel converts inside its loader when the rows
-    are 16-byte aligned (LDS-DMA), and through a gray plane otherwise (a crop view at an odd offset); both equal the
-    oracle, under both coefficient sets."""
+    """a3 + a4 on coloured 1280x1024 BGR frames (large branch): dense 16-byte-aligned frames take `k_gray`'s coalesced
+    path, a crop view at an odd offset its strided one; both equal the oracle, under both coefficient sets."""
     rng = np.random.default_rng(12)
     spec = S.config2()
     g = S.make_frames(spec, [0, 3], seed=5)
@@ -811,6 +810,34 @@ def test_bgr_frames_large_branch_fused_and_fallback():
                 assert np.array_equal(mask[i].cpu().numpy(), want[i][0]), (bits, i)
         eng.close()
     assert not np.array_equal(O.bgr2gray(frames[0], 15), O.bgr2gray(frames[0], 14))
+
+
+@pytest.mark.parametrize("cfg", ["c1", "c2"])
+def test_ncc_wide_margin_drives_the_queued_exact_path(cfg):
+    """a7-a8: with the float32 filter's margin widened 250x (VBS_OPT_NCC_MARGIN, a test hook) thousands of pixels per
+    frame are left undecided, queued tile by tile and re-evaluated in float64 after the step loop (queue drains in
+    mid-strip, several pixels per tile, atomic OR into stored mask words, the uint8 mask patched): the masks must still
+    equal the oracle's and the fused path's table must not change by a bit."""
+    from vbs_amd.pipeline import reference_from_frame0
+    spec = S.config1() if cfg == "c1" else S.config2()
+    f = S.make_frames(spec, [0, 1, 2, 5], seed=3)
+    ft = torch.from_numpy(f).cuda()
+    eng = engine(spec.height, spec.width, max_batch=4)
+    ref_ids, ref_xy = reference_from_frame0(eng, ft[:1], 5, "full", "optimal")
+    t0, _, c0 = eng.track_to_3d(ft, ref_xy, 20.0, None, 5.0)
+    base = eng.ncc_counters()
+    eng.set_option(L.OPT_NCC_MARGIN, 5000)
+    mask, area = eng.find_markers(ft)                       # staged form: uint8 mask written by the kernel
+    t1, _, c1 = eng.track_to_3d(ft, ref_xy, 20.0, None, 5.0)    # fused form: bit masks only
+    wide = eng.ncc_counters()
+    for i in range(len(f)):
+        om, oa = O.find_markers(f[i])
+        assert np.array_equal(area[i].cpu().numpy(), oa)
+        assert np.array_equal(mask[i].cpu().numpy(), om), i
+    assert torch.equal(t0, t1) and torch.equal(c0, c1)
+    per_frame = (wide["exact"] - base["exact"]) / (2 * len(f))
+    assert per_frame > 200, per_frame                      # the hook did widen the margin
+    eng.close()
 
 
 def test_bgr2gray_both_coefficient_sets():

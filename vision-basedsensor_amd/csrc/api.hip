@@ -360,6 +360,10 @@ extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
     switch (option) {
         case VBS_OPT_FORCE_SEQ_MATCH: h->force_seq_match = value != 0; return VBS_OK;
         case VBS_OPT_GRAY_SIDE_STREAM: h->gray_side = value != 0; return VBS_OK;
+        case VBS_OPT_NCC_MARGIN:
+            if (value < 0 || value > 100000) break;
+            h->ncc_margin_ppm = value;
+            return VBS_OK;
         case VBS_OPT_GRAY_COEFFS:
             if (value != 14 && value != 15) break;
             h->gray_bits = value;

@@ -86,6 +86,7 @@ struct vbs_handle {
     int gray_bits = 15;             // BGR2GRAY fixed-point coefficient set: 15 (OpenCV 4) | 14 (OpenCV <= 3.4.1)
     bool force_seq_match = false;   // vbs_set_option(VBS_OPT_FORCE_SEQ_MATCH)
     bool gray_side = false;         // vbs_set_option(VBS_OPT_GRAY_SIDE_STREAM)
+    int ncc_margin_ppm = 0;         // vbs_set_option(VBS_OPT_NCC_MARGIN): test hook, widens the float32 filter's margin
     u8* lut;           // [256] contour vertex table
     short* umap1;      // [H][W][2] int16 undistortion source pixel (CV_16SC2)
     unsigned short* umap2;   // [H][W] fractional index into the bilinear weight table

@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
                                                      const double* __restrict__ tab, u64* __restrict__ mbits,
                                                      u8* __restrict__ mask_u8, u32* __restrict__ fstat, int H, int W,
-                                                     int WW, int tiles_per_seg, int dbg_arg, NccConst nc) {
+                                                     int WW, int tiles_per_seg, int dbg_arg, float rel_arg, NccConst nc) {
 #ifdef VBS_DEBUG_KNOBS
     const int dbg = dbg_arg;                            // tools/ phase timing and dumps
 #else
@@ -574,7 +574,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 // root, and a tile whose every u is negative (the template correlates negatively: about half of them) is
                 // background after three packed operations per pixel pair.  k0e >= 0.01 keeps an empty window (G = 0
                 // exactly) at u < 0; against kc c ~ 1e5 for c >= 1 it is far inside the margin.
-                const f2 rel2 = {NCC_REL, NCC_REL}, nkc2 = {-kc, -kc}, k02 = {k0e, k0e};
+                const f2 rel2 = {rel_arg, rel_arg}, nkc2 = {-kc, -kc}, k02 = {k0e, k0e};   // rel_arg >= NCC_REL (VBS_OPT_NCC_MARGIN)
                 f2 uu[2], uhi[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {            // (one scalar operand per packed instruction)
@@ -850,7 +850,7 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
 #define NCC_GO(L_, LO_, U8)                                                                                      \
     VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<L_, LO_, U8>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,    \
                h->ncc_ry, h->ncc_frags, h->ncc_tab, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,     \
-               VBS_KNOB("VBS_NCC_DBG"), h->ncc)
+               VBS_KNOB("VBS_NCC_DBG"), std::max(NCC_REL, 1e-6f * (float)h->ncc_margin_ppm), h->ncc)
         if (!h->bp.small) { if (mask_u8) NCC_GO(80, -40, true); else NCC_GO(80, -40, false); }
         else { if (mask_u8) NCC_GO(33, -16, true); else NCC_GO(33, -16, false); }
 #undef NCC_GO

@@ -148,7 +148,8 @@ class Engine:
         return (out, mask) if want_mask else out
 
     def set_option(self, option: int, value: int):
-        """`vbs_set_option`: L.OPT_GRAY_COEFFS (15 | 14), L.OPT_FORCE_SEQ_MATCH (test hook)."""
+        """`vbs_set_option`: L.OPT_GRAY_COEFFS (15 | 14), L.OPT_GRAY_SIDE_STREAM (0 | 1), test hooks L.OPT_FORCE_SEQ_MATCH,
+        L.OPT_NCC_MARGIN (units of 1e-6)."""
         self._check(self.lib.vbs_set_option(self._h, int(option), int(value)), "vbs_set_option")
 
     def profile(self, enable: bool):
