@@ -210,7 +210,12 @@ void launch_morph(vbs_handle* h, int nb, hipStream_t s) {
     const int G = 64 / h->WW;                            // strips per wave (WW <= 64)
     // strips per frame: enough waves to fill the chip several times over, but strips much longer than the ns - 1 rows
     // each re-reads
-    int wpf = (8192 + nb - 1) / nb;                      // waves per frame for ~8192 waves in flight
+    // one round of resident waves when the batch is large (94 / 78 VGPRs: 5 / 6 waves per SIMD on 1024 SIMDs; with 6144
+    // waves the large branch ran a full round and then a 20 % one), else as many as the strip length allows
+    const int resident = (h->bp.ns == 14 ? 5 : 6) * 1024;
+    int wpf = resident / std::max(nb, 1);
+    if (wpf < 4) wpf = (2 * resident + nb - 1) / nb;     // small strips would dominate: take two rounds instead
+    if (VBS_KNOB("VBS_MORPH_WPF")) wpf = VBS_KNOB("VBS_MORPH_WPF");
     wpf = std::max(1, std::min(wpf, h->H / (2 * h->bp.ns) / G));      // strips of at least 2 ns rows
     const int strips = wpf * G, rps = (h->H + strips - 1) / strips;
     const int waves = nb * wpf;
