@@ -104,6 +104,20 @@ __global__ __launch_bounds__(256) void k_gray(const u8* __restrict__ frames, int
     *reinterpret_cast<uint4*>(dst) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
+// k_gray's dense path without LDS (48 contiguous bytes per thread, 3 KB per wave): the form the side stream launches, so
+// that its workgroups fit next to k_ncc_mfma's, which leave registers and wave slots but no LDS
+__global__ __launch_bounds__(256) void k_gray_flat(const u8* __restrict__ frames, int64_t stride_n, u8* __restrict__ gray,
+                                                   int64_t npx, GrayCoef gc) {
+    const int n = blockIdx.z;
+    const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (p0 >= npx) return;
+    const uint4* s4 = reinterpret_cast<const uint4*>(frames + (int64_t)n * stride_n + p0 * 3);
+    const uint4 r0 = s4[0], r1 = s4[1], r2 = s4[2];
+    *reinterpret_cast<uint4*>(gray + (int64_t)n * npx + p0) =
+        make_uint4(bgr4_to_gray(r0.x, r0.y, r0.z, gc), bgr4_to_gray(r0.w, r1.x, r1.y, gc),
+                   bgr4_to_gray(r1.z, r1.w, r2.x, gc), bgr4_to_gray(r2.y, r2.z, r2.w, gc));
+}
+
 // the cvtColor stage on its own (vbs_bgr2gray): dense [n,H,W] output, one pixel per thread
 __global__ void k_gray_dense(const u8* __restrict__ frames, int64_t stride_n, int64_t stride_row,
                              u8* __restrict__ out, int H, int W, GrayCoef gc) {
@@ -368,6 +382,12 @@ void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t 
                  int64_t stride_row, u8* gray, hipStream_t s) {
     const int vec_ok = (reinterpret_cast<uintptr_t>(frames) % 16 == 0) && (stride_n % 16 == 0) && (stride_row % 16 == 0);
     const int flat = vec_ok && channels == 3 && stride_row == (int64_t)h->W * 3 && h->P == h->W && ((int64_t)h->H * h->W) % 16 == 0;
+    if (flat && s == h->side) {
+        const int64_t npx = (int64_t)h->H * h->W;
+        VBS_LAUNCH(h, s, "k_gray", k_gray_flat, dim3((unsigned)((npx / 16 + 255) / 256), 1, nb), dim3(256), 0, s, frames, stride_n,
+                   gray, npx, gray_coef(h->gray_bits));
+        return;
+    }
     dim3 grid = flat ? dim3((unsigned)(((int64_t)h->H * h->W + 8191) / 8192), 1, nb) : dim3((h->P / 16 + 255) / 256, h->H, nb);
     VBS_LAUNCH(h, s, "k_gray", k_gray, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row, gray,
                        h->H, h->W, h->P, gray_coef(h->gray_bits), vec_ok, flat);
