@@ -1,5 +1,6 @@
 """Phase timing of k_ncc_mfma through the debug library's VBS_NCC_DBG knob (3: loads + horizontal products + ring
-only; 2: + vertical products; 0: everything).  usage: gpu_ncc_phase.py [frames]"""
+only; 2: + vertical products; 0: everything; PHASES=3,2,1,0 selects), or of k_blur_mfma with KNOB=VBS_BLUR_DBG (2: no
+vertical products, 1: no range test / store).  usage: gpu_ncc_phase.py [frames]"""
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -21,6 +22,6 @@ if len(sys.argv) > 2 and sys.argv[2] == "child":
 else:
     n = sys.argv[1] if len(sys.argv) > 1 else "512"
     for dbg in [int(x) for x in os.environ.get("PHASES", "3,2,1,0").split(",")]:
-        env = dict(os.environ, VBS_NCC_DBG=str(dbg))
+        env = dict(os.environ, **{os.environ.get("KNOB", "VBS_NCC_DBG"): str(dbg)})
         r = subprocess.run([sys.executable, __file__, n, "child"], env=env, capture_output=True, text=True, timeout=300)
         print("dbg", dbg, r.stdout.strip(), r.stderr.strip()[-300:] if r.returncode else "", flush=True)

@@ -182,14 +182,20 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
                                                       int64_t gstride_row, const uint4* __restrict__ frags,
                                                       u64* __restrict__ bits, u8* __restrict__ area_u8,
                                                       u32* __restrict__ fstat, int H, int W, int WW,
-                                                      int tiles_per_seg, int k3, int k8, int span_i) {
+                                                      int tiles_per_seg, int k3, int k8, int span_i, int dbg_arg) {
+#ifdef VBS_DEBUG_KNOBS
+    const int dbg = dbg_arg;                            // tools/gpu_ncc_phase.py: phase timing by early exit
+#else
+    constexpr int dbg = 0;
+#endif
     constexpr int LEFT = 32 * ((NK - 1) / 2);
     constexpr int ROWB = 128 + 32 * (NK - 1);          // bytes staged per image row
     constexpr int CH = ROWB / 16;
     constexpr int STRIDE = ROWB + 16;                  // 68 (52) dwords: 16 consecutive rows hit all banks
     constexpr int NIT = (32 * CH + 255) / 256;
     __shared__ __align__(16) u8 tile[2][32 * STRIDE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform, and known to the compiler to be
     const int hh = lane >> 5, m = lane & 31;
     const int X0 = blockIdx.x * 128, n = blockIdx.z;
     const int tilesY = (H + 31) / 32;
@@ -199,6 +205,7 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
     const int Y0 = tile0 * 32, nsteps = ntiles + NK - 1;
     const u8* g = gray + (int64_t)n * gstride_n;
     const bool aligned = ((gstride_row & 3) == 0) && ((gstride_n & 3) == 0) && ((reinterpret_cast<uintptr_t>(gray) & 3) == 0);
+    const bool rows24 = gstride_row > 0 && gstride_row < (1 << 24) && (int64_t)H * gstride_row < (1ll << 31);   // (uniform)
 
     v4i bh[NK], bha[NKA], tv[NK], tva[NKA];
 #pragma unroll
@@ -228,14 +235,18 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
         c_fast[it] = aligned && c_px[it] >= 0 && c_px[it] + 16 <= W;
     }
     // plain chunks are loaded a step ahead into registers and written to LDS at the end of the step; border chunks
-    // (few, only in the first / last workgroup of a row) are gathered byte by byte at commit time
+    // (few, only in the first / last workgroup of a row) are gathered byte by byte at commit time.  (Two steps ahead,
+    // paid for by reading the small kernel's vertical fragments from LDS: measured slower, 1.65 against 1.44 us.)
     uint4 stage[NIT];
     auto row_of = [&](int t, int it) { return g + (int64_t)reflect101(Y0 - LEFT + 32 * t + c_row[it], H) * gstride_row; };
     auto fetch = [&](int t) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it)
             if (c_on[it] && c_fast[it]) {
-                const u32* s32 = reinterpret_cast<const u32*>(row_of(t, it) + c_px[it]);
+                // (rows24: the row pitch and a frame's size fit 24 / 31 bits - one full-rate multiply and a 32-bit
+                //  offset from the scalar frame pointer instead of a 64-bit multiply per chunk and step)
+                const u32* s32 = rows24 ? reinterpret_cast<const u32*>(g + (u32)(__mul24(reflect101(Y0 - LEFT + 32 * t + c_row[it], H), (int)gstride_row) + c_px[it]))
+                                        : reinterpret_cast<const u32*>(row_of(t, it) + c_px[it]);
                 stage[it] = make_uint4(s32[0], s32[1], s32[2], s32[3]);
             }
     };
@@ -259,12 +270,13 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
 #pragma unroll
     for (int s = 0; s < NK; ++s) rLh[s] = rLl[s] = rSh[s] = rSl[s] = v4i{0, 0, 0, 0};
     const int xw = X0 + 32 * wave;                     // first column of this wave's strip
+    u32* const bits32 = reinterpret_cast<u32*>(bits) + ((int64_t)n * H * WW + (xw >> 6)) * 2 + ((xw >> 5) & 1);   // (uniform)
     const u32 colmask = xw + 32 <= W ? 0xFFFFFFFFu : (xw >= W ? 0u : ((1u << (W - xw)) - 1u));
     // sum tap*H = 256*Dhi + Dlo + 256*(128 + 32768); + 2^15 to round; the large kernel also carries
     // (15 - thresh) << 16 so that its high word is im_blur_8 + 15 - thresh (mod 2^16)
     // (host computes k3 = 256*(128+32768) + 2^15, k8 = k3 + (15 - thresh) << 16, span = hi - thresh)
     const u32 span = (u32)span_i;
-    u32 total = 0;
+    u32 total = 0, pend_off = 0xFFFFFFFFu, pend_full = 0;
 
     fetch(0);
     commit(0, 0);
@@ -295,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
                 for (int s = 0; s < NKA; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[SA0 + s], bha[s], acc, 0, 0, 0);
                 pack_tile(acc, rSh[u], rSl[u]);
             }
-            if (t >= NK - 1) {
+            if (t >= NK - 1 && dbg != 2) {
                 v16i d8 = {}, d3 = {};
 #pragma unroll
                 for (int o = 0; o < NK; ++o) d8 = __builtin_amdgcn_mfma_i32_32x32x32_i8(rLh[(u + 1 + o) % NK], tv[o], d8, 0, 0, 0);
@@ -309,6 +321,10 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
                 for (int i = 0; i < 16; ++i) d3[i] = (d3[i] << 8) + k3;
 #pragma unroll
                 for (int o = 0; o < NKA; ++o) d3 = __builtin_amdgcn_mfma_i32_32x32x32_i8(rSl[(u + 1 + SA0 + o) % NK], tva[o], d3, 0, 0, 0);
+                if (dbg == 1) {
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) asm volatile("" :: "v"(d8[i]), "v"(d3[i]));
+                } else {
                 u32 sgn = 0;                           // bit i = 1 when register i is OUT of range
 #pragma unroll
                 for (int i = 15; i >= 0; --i) {
@@ -320,8 +336,9 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
                 const int y = Y0 + 32 * (t - (NK - 1)) + m;
                 w32 = (y < H) ? (w32 & colmask) : 0u;
                 u32 full = w32 | (u32)__shfl_xor((int)w32, 32);
-                if (hh == 0 && y < H && (xw >> 6) < WW) {
-                    reinterpret_cast<u32*>(bits)[(((int64_t)n * H + y) * WW + (xw >> 6)) * 2 + ((xw >> 5) & 1)] = full;
+                if (hh == 0 && y < H && (xw >> 6) < WW) {    // stored behind this step's commit (below)
+                    pend_off = (u32)__mul24(y, 2 * WW);
+                    pend_full = full;
                     total += __popc(full);
                 }
                 if (U8OUT && y < H) {                    // uint8 image for the staged API: 4 pixels per store where possible
@@ -339,8 +356,12 @@ __global__ __launch_bounds__(256, 2) void k_blur_mfma(const u8* __restrict__ gra
                         }
                     }
                 }
+                }                                      // (dbg != 1)
             }
             if (more) commit(t + 1, (t + 1) & 1);
+            // The mask word goes out only now: issued before the commit, its acknowledgement would be part of the commit's
+            // wait for the prefetched rows, every step and for all four waves at the barrier.
+            if (pend_off != 0xFFFFFFFFu) { bits32[pend_off] = pend_full; pend_off = 0xFFFFFFFFu; }
             __syncthreads();
         }
     }
@@ -404,7 +425,7 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
 #define BLUR_GO(NK, SA0, NKA, U8)                                                                            \
     VBS_LAUNCH(h, s, "k_blur_mfma", (k_blur_mfma<NK, SA0, NKA, U8>), grid, dim3(256), 0, s, gray, gstride_n, \
                gstride_row, h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8,  \
-               h->bp.hi - h->bp.thresh)
+               h->bp.hi - h->bp.thresh, VBS_KNOB("VBS_BLUR_DBG"))
     if (!h->bp.small) { if (area_u8) BLUR_GO(5, 1, 3, true); else BLUR_GO(5, 1, 3, false); }
     else { if (area_u8) BLUR_GO(3, 0, 3, true); else BLUR_GO(3, 0, 3, false); }
 #undef BLUR_GO
