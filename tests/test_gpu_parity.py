@@ -713,6 +713,35 @@ def test_batch_and_chunk_independence():
     eng_d.close()
 
 
+def test_benchmark_launch_shape_properties():
+    """BASELINE config 3's launch shape (internal passes of 512 frames, workgroup grids of the size the benchmark times)
+    through size-independent properties: every frame finds its 169 markers, every observation gets its 3-D point, the
+    table does not depend on the pass size (512 / 96), BGR frames with B = G = R give the gray frames' table, and the
+    NCC decision counters report no ambiguous pixel."""
+    spec = S.config2()
+    n = 1024
+    ft = S.make_frames_torch(spec, range(n), seed=4, device="cuda", chunk=16)
+    from vbs_amd.pipeline import reference_from_frame0
+    eng = engine(spec.height, spec.width, max_batch=512)
+    ids, xy = reference_from_frame0(eng, ft[:1], 5, "full", "optimal")
+    cam = L.make_camera(*S.default_camera(spec), 2.0)
+    eng.ncc_counters(reset=True)
+    t512, _, c512 = eng.track_to_3d(ft, xy, 20.0, cam, 5.0)
+    cnt = eng.ncc_counters()
+    assert int(c512.min()) == spec.n_markers and int(c512.max()) == spec.n_markers
+    flags = t512[..., 0].int()
+    assert int((flags & 1).sum()) == n * spec.n_markers          # tracked
+    assert int(((flags >> 1) & 1).sum()) == n * spec.n_markers   # 3-D solved
+    assert cnt["frames"] == n and cnt["ambiguous"] == 0
+    tb, _, _ = eng.track_to_3d(ft[:600].unsqueeze(-1).expand(-1, -1, -1, 3).contiguous(), xy, 20.0, cam, 5.0)
+    assert torch.equal(tb, t512[:600])
+    eng.close()
+    eng2 = engine(spec.height, spec.width, max_batch=96)
+    t96, _, c96 = eng2.track_to_3d(ft, xy, 20.0, cam, 5.0)
+    assert torch.equal(t96, t512) and torch.equal(c96, c512)
+    eng2.close()
+
+
 def test_engine_argument_errors():
     from vbs_amd.engine import Engine
     with pytest.raises(ValueError):
