@@ -170,6 +170,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     std::vector<u32> nfrags = ncc_mfma_fragments(h->ncc, bp.ncc_l);
     ALLOC(ncc_frags, nfrags.size() / 4);
     ALLOC(ncc_tab, (size_t)2 * VBS_NCC_MAXL + 1);
+    ALLOC(ncc_rowf, (size_t)height);
     ALLOC(umap1, (size_t)height * width * 2); ALLOC(umap2, (size_t)height * width); ALLOC(uwtab, 4096);
 #undef ALLOC
     std::vector<double> rx(width), ry(height);
@@ -190,6 +191,14 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     HIPCHK(h, hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->blur_frags, frags.data(), frags.size() * sizeof(u32), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->ncc_frags, nfrags.data(), nfrags.size() * sizeof(u32), hipMemcpyHostToDevice));
+    {
+        std::vector<float2> rowf(height);
+        for (int y = 0; y < height; ++y) {
+            const int ny = std::min(y + bp.ncc_hi, height - 1) - std::max(y + bp.ncc_lo, 0) + 1;
+            rowf[y] = make_float2((float)ny, (float)ry[y]);
+        }
+        HIPCHK(h, hipMemcpy(h->ncc_rowf, rowf.data(), height * sizeof(float2), hipMemcpyHostToDevice));
+    }
     HIPCHK(h, hipMemcpy(h->ncc_tab, h->ncc.g, VBS_NCC_MAXL * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->ncc_tab + VBS_NCC_MAXL, h->ncc.cg, (VBS_NCC_MAXL + 1) * sizeof(double), hipMemcpyHostToDevice));
     {

@@ -67,6 +67,7 @@ struct vbs_handle {
     double* ncc_rx;    // [W]  sum of g over the in-image part of the window (columns)
     double* ncc_ry;    // [H]
     uint4* ncc_frags;  // Toeplitz operand fragments of k_ncc_mfma (ncc_mfma_fragments)
+    float2* ncc_rowf;  // [H] {rows of the NCC window inside the image, (float) ncc_ry}: border tiles of k_ncc_mfma
     double* ncc_tab;   // [VBS_NCC_MAXL] g, then [VBS_NCC_MAXL + 1] cg: the exact path of k_ncc_mfma reads them from memory
     u32* fstat;        // [maxb][8]  0: area popcount, 1: ambiguous ncc pixels, 2: status
     u32* wbase;        // [maxb][2][H*WW]   first node index of each word

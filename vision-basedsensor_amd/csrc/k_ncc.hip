@@ -274,9 +274,10 @@ typedef int i4 __attribute__((ext_vector_type(4)));
 template <int L, int LO, bool U8OUT>                    // U8OUT: also the uint8 mask of the staged API
 __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
-                                                     const double* __restrict__ tab, u64* __restrict__ mbits,
-                                                     u8* __restrict__ mask_u8, u32* __restrict__ fstat, int H, int W,
-                                                     int WW, int tiles_per_seg, int dbg_arg, float rel_arg, NccConst nc) {
+                                                     const double* __restrict__ tab, const float2* __restrict__ rowf,
+                                                     u64* __restrict__ mbits, u8* __restrict__ mask_u8,
+                                                     u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
+                                                     int dbg_arg, float rel_arg, NccConst nc) {
 #ifdef VBS_DEBUG_KNOBS
     const int dbg = dbg_arg;                            // tools/ phase timing and dumps
 #else
@@ -613,9 +614,9 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const int yc = min(yo + 4 * g + r, H - 1);
-                        nnv[r] = (float)(min(yc + HI, H - 1) - max(yc + LO, 0) + 1) * nxf;
-                        stv[r] = (float)ry[yc] * rxf;
+                        const float2 rf = rowf[min(yo + 4 * g + r, H - 1)];   // {rows of the window inside the image, (float)ry}
+                        nnv[r] = rf.x * nxf;
+                        stv[r] = rf.y * rxf;
                         dd0[r] = stv[r] - nnv[r] * tbarf;
                     }
                 }
@@ -849,7 +850,8 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         dim3 grid(h->WW, nseg, nb);
 #define NCC_GO(L_, LO_, U8)                                                                                      \
     VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<L_, LO_, U8>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,    \
-               h->ncc_ry, h->ncc_frags, h->ncc_tab, h->mask_bits, mask_u8, h->fstat, h->H, h->W, h->WW, tps,     \
+               h->ncc_ry, h->ncc_frags, h->ncc_tab, h->ncc_rowf, h->mask_bits, mask_u8, h->fstat, h->H, h->W,   \
+               h->WW, tps,                                                                                       \
                VBS_KNOB("VBS_NCC_DBG"), std::max(NCC_REL, 1e-6f * (float)h->ncc_margin_ppm), h->ncc)
         if (!h->bp.small) { if (mask_u8) NCC_GO(80, -40, true); else NCC_GO(80, -40, false); }
         else { if (mask_u8) NCC_GO(33, -16, true); else NCC_GO(33, -16, false); }
