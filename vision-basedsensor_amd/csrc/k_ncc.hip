@@ -328,19 +328,13 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
         one[s] = __builtin_bit_cast(h8, c);
     }
     // int8 Toeplitz of ones (A operand of the vertical count product): lane (g, row q), byte j <-> k = 64 s + 16 g + j
+    // (from the fragment table as well: built here it cost 250 vector instructions per wave)
     i4 one8[NK8];
 #pragma unroll
-    for (int s = 0; s < NK8; ++s)
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-            u32 w = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int idx = 64 * s + 16 * g + 4 * d + j - q;
-                w |= (idx >= 0 && idx < L) ? (1u << (8 * j)) : 0u;
-            }
-            one8[s][d] = (int)w;
-        }
+    for (int s = 0; s < NK8; ++s) {
+        const uint4 a = wfrag[(3 * NKS + s) * 64 + lane];
+        one8[s] = i4{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);                 // operand fragments landed (see k_blur_mfma)
     __syncthreads();
 
@@ -709,8 +703,14 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
 // pairs with the other operand's element j of the same g): weight index (32 s + 8 g + j) - column.  The same
 // fragments serve as B operand of the horizontal and as A operand of the vertical product.
 std::vector<u32> ncc_mfma_fragments(const NccConst& nc, int l) {
-    const int nt = (16 + l - 1 + 15) / 16, nks = (16 * nt + 31) / 32;
-    std::vector<u32> out((size_t)3 * nks * 64 * 4, 0);
+    const int nt = (16 + l - 1 + 15) / 16, nks = (16 * nt + 31) / 32, nk8 = (16 * nt + 63) / 64;
+    std::vector<u32> out((size_t)(3 * nks + nk8) * 64 * 4, 0);
+    for (int s = 0; s < nk8; ++s)                        // kind 3: int8 ones, byte j of lane (g, row q) <-> k = 64 s + 16 g + j
+        for (int lane = 0; lane < 64; ++lane)
+            for (int j = 0; j < 16; ++j) {
+                const int idx = 64 * s + 16 * (lane >> 4) + j - (lane & 15);
+                if (idx >= 0 && idx < l) out[((size_t)(3 * nks + s) * 64 + lane) * 4 + (j >> 2)] |= 1u << (8 * (j & 3));
+            }
     auto bits16 = [](double v) { _Float16 hv = (_Float16)v; unsigned short b; memcpy(&b, &hv, 2); return (u32)b; };
     for (int kind = 0; kind < 3; ++kind)
         for (int s = 0; s < nks; ++s)
