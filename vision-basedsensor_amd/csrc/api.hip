@@ -244,8 +244,9 @@ static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, in
     return check_launch(h);
 }
 
-// BGR frames over several internal passes: cvtColor of pass k + 1 runs on the handle's side stream while pass k's
-// kernels run on `s` (two gray planes; fork / join by events, so a caller may capture the whole call in a graph).
+// BGR frames over several internal passes with VBS_OPT_GRAY_SIDE_STREAM set: cvtColor of pass k + 1 runs on the handle's
+// side stream while pass k's kernels run on `s` (two gray planes; fork / join by events, so a caller may capture the whole
+// call in a graph).  Off by default (`on` false: every pass converts in line, see detect_pass).
 struct GrayPipe {
     vbs_handle* h; const u8* frames; int n, channels; int64_t stride_n, stride_row; hipStream_t s;
     bool on;

@@ -26,9 +26,10 @@ __device__ __forceinline__ u32 bgr4_to_gray(u32 a, u32 b, u32 c, const GrayCoef&
 }
 
 // cvtColor(BGR2GRAY) (or a plain copy for 1 channel) into the pitched gray plane the blur reads: a streaming kernel,
-// 16 pixels per thread (three 16-byte loads, one 16-byte store) when the rows are 16-byte aligned.  The product path
-// runs it on the handle's side stream one internal pass ahead of the matrix-core kernels (api.hip), which leave the
-// HBM idle: a BGR frame then costs its 3 H W bytes of read, hidden behind the blur / NCC of the previous pass.
+// 16 pixels per thread (three 16-byte loads, one 16-byte store) when the rows are 16-byte aligned: 0.85-1.0 us per
+// 1280x1024 frame (5.3-6.2 TB/s of its 5.2 MB).  It runs in line in front of the blur; VBS_OPT_GRAY_SIDE_STREAM moves it one
+// internal pass ahead onto the handle's own stream (api.hip), which measured no faster: the matrix-core kernels leave
+// the HBM idle but not the registers, LDS and issue slots a conversion workgroup needs next to them.
 // (Converting inside the blur's own loader was built and measured: LDS-DMA staging of the raw bytes kept the matrix
 //  operands in registers only at the price of 50 spilled VGPRs - 5 us per frame against 1.45.)
 __global__ __launch_bounds__(256) void k_gray(const u8* __restrict__ frames, int channels, int64_t stride_n,
