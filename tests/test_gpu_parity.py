@@ -869,6 +869,29 @@ def test_ncc_wide_margin_drives_the_queued_exact_path(cfg):
     eng.close()
 
 
+def test_bgr_side_stream_option_gives_the_same_results():
+    """VBS_OPT_GRAY_SIDE_STREAM: BGR frames over several internal passes, the conversion of pass k + 1 on the handle's own
+    stream (lead pass, two gray planes, event fork / join) - tables and masks identical to the in-line conversion."""
+    rng = np.random.default_rng(21)
+    spec = S.config1()
+    g = S.make_frames(spec, range(11), seed=6)
+    frames = np.clip(g[..., None].astype(int) + rng.integers(-6, 7, g.shape + (3,)), 0, 255).astype(np.uint8)
+    ft = torch.from_numpy(frames).cuda()
+    eng = engine(spec.height, spec.width, max_batch=3)
+    from vbs_amd.pipeline import reference_from_frame0
+    ids, xy = reference_from_frame0(eng, ft[:1], 5, "full", "optimal")
+    t0, _, c0 = eng.track_to_3d(ft, xy, 20.0, None, 5.0)
+    m0, a0 = eng.find_markers(ft)
+    eng.set_option(L.OPT_GRAY_SIDE_STREAM, 1)
+    for _ in range(2):                                         # twice: the planes and events are reused across calls
+        t1, _, c1 = eng.track_to_3d(ft, xy, 20.0, None, 5.0)
+        m1, a1 = eng.find_markers(ft)
+        assert torch.equal(t0, t1) and torch.equal(c0, c1) and torch.equal(m0, m1) and torch.equal(a0, a1)
+    om, oa = O.find_markers(frames[7])
+    assert np.array_equal(m1[7].cpu().numpy(), om) and np.array_equal(a1[7].cpu().numpy(), oa)
+    eng.close()
+
+
 def test_bgr2gray_both_coefficient_sets():
     """a3 on coloured pixels, where the 15-bit (OpenCV 4) and 14-bit sets differ; also through `find_markers`."""
     rng = np.random.default_rng(9)
