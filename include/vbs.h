@@ -71,11 +71,14 @@ int vbs_version(void);
  * BGR frames of internal pass k + 1 on the handle's own stream while pass k computes, 0 (default) converts in line.
  * VBS_OPT_NCC_MARGIN (test hook, results identical): relative margin of the NCC's float32 filter in units of 1e-6
  * (never below the 20 the error bound needs); a wide margin sends thousands of pixels per frame through the queued
- * float64 re-evaluation. */
+ * float64 re-evaluation.  VBS_OPT_STAGE_IMPL (test hook / fallback, results identical): 0 (default) runs band / open /
+ * labelling / sums of `_marker_center` (:170-196) in the fused kernel (k_stage.hip) where the frame geometry allows it,
+ * 1 always runs the separate kernels (k_morph + k_ccl) that other geometries take. */
 #define VBS_OPT_GRAY_COEFFS      1
 #define VBS_OPT_FORCE_SEQ_MATCH  2
 #define VBS_OPT_GRAY_SIDE_STREAM 3
 #define VBS_OPT_NCC_MARGIN       4
+#define VBS_OPT_STAGE_IMPL       5
 int vbs_set_option(vbs_handle* h, int option, int value);
 /* host-only helper: the 256-entry table that classifies a border pixel's 8-neighbourhood into the
  * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain
@@ -140,6 +143,14 @@ int vbs_profile_read(vbs_handle* h, char* buf, int cap);
  * cv2.findContours(RETR_EXTERNAL) ignores them, so this is 0 unless the fill pass ran out of capacity), 5 / 6: connected
  * components of the band / opened mask, 7: holes that were filled}] (synchronises). */
 int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n);
+/* Diagnostic / parity entry: host copies of the per-component tables the labelling kernels left for the first n frames of
+ * the LAST internal pass (synchronises; any pointer may be NULL): ncomp [n][2] components of the band / opened mask,
+ * band_sums [n][max_markers][4] (count, sum x, sum y, spare), area_first [n][max_markers] first pixel (y * w + x) of every
+ * opened component, area_sums [n][max_markers][16] contour-vertex moments about it, probe [n][max_markers][4] component ids
+ * of the 2x2 pixel cell around every band centroid (0xFFFF = background), slow [n] 1 = the general kernel redid the frame.
+ * Entries past a frame's component counts are unspecified. */
+int vbs_stage_tables(vbs_handle* h, int n, uint32_t* ncomp, uint64_t* band_sums, uint32_t* area_first, int64_t* area_sums,
+                     uint16_t* probe, uint32_t* slow);
 /* Running totals over EVERY internal pass of the detection stage since the last reset (vbs_frame_stats only sees the
  * last pass): out = {NCC pixels inside the ambiguity band of the 0.1 threshold (`:133`; 0 = every decision equals the
  * float64 one), NCC pixels re-evaluated in float64, frames}.  Synchronises. */

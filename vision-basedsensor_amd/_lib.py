@@ -8,14 +8,15 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvbs.so")
 VBS_OK, VBS_EINVAL, VBS_ECAPACITY, VBS_EHIP, VBS_ENOMEM = 0, -1, -2, -3, -4
 DET_COLS, TABLE_COLS, DISP_COLS, PLANE_COLS = 6, 10, 5, 5
 FLAG_TRACKED, FLAG_XYZ = 1, 2
-OPT_GRAY_COEFFS, OPT_FORCE_SEQ_MATCH, OPT_GRAY_SIDE_STREAM, OPT_NCC_MARGIN = 1, 2, 3, 4
+OPT_GRAY_COEFFS, OPT_FORCE_SEQ_MATCH, OPT_GRAY_SIDE_STREAM, OPT_NCC_MARGIN, OPT_STAGE_IMPL = 1, 2, 3, 4, 5
 
 # every symbol include/vbs.h declares (tests check the export list against the header)
 SYMBOLS = ("vbs_create", "vbs_destroy", "vbs_last_error", "vbs_version", "vbs_contour_lut",
            "vbs_gaussian_taps_q8", "vbs_ncc_template", "vbs_set_undistort", "vbs_undistort_frames", "vbs_find_markers", "vbs_ncc_map", "vbs_normxcorr2",
            "vbs_profile", "vbs_profile_read", "vbs_frame_stats", "vbs_undistort_points", "vbs_calculate_3d", "vbs_marker_center",
            "vbs_track", "vbs_solve3d", "vbs_track_to_3d", "vbs_displacement", "vbs_displacement_range", "vbs_displacement_f64",
-           "vbs_plane_fit", "vbs_assign_ids", "vbs_set_option", "vbs_bgr2gray", "vbs_ncc_counters", "vbs_normxcorr2_general")
+           "vbs_plane_fit", "vbs_assign_ids", "vbs_set_option", "vbs_bgr2gray", "vbs_ncc_counters", "vbs_normxcorr2_general",
+           "vbs_stage_tables")
 
 
 class Camera(C.Structure):
@@ -73,6 +74,7 @@ def lib():
         "vbs_bgr2gray": (i32, [vp, vp, i32, i64, i64, vp, vp]),
         "vbs_ncc_counters": (i32, [vp, vp, i32]),
         "vbs_normxcorr2_general": (i32, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp]),
+        "vbs_stage_tables": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)            # AttributeError here = stale library

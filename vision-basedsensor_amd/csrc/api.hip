@@ -374,6 +374,10 @@ extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
             if (value < 0 || value > 100000) break;
             h->ncc_margin_ppm = value;
             return VBS_OK;
+        case VBS_OPT_STAGE_IMPL:
+            if (value != 0 && value != 1) break;
+            h->stage_impl = value;
+            return VBS_OK;
         case VBS_OPT_GRAY_COEFFS:
             if (value != 14 && value != 15) break;
             h->gray_bits = value;
@@ -463,6 +467,21 @@ extern "C" int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n) {
     return VBS_OK;
 }
 
+extern "C" int vbs_stage_tables(vbs_handle* h, int n, uint32_t* ncomp, uint64_t* band_sums, uint32_t* area_first,
+                                int64_t* area_sums, uint16_t* probe, uint32_t* slow) {
+    if (!h || n < 0 || n > h->maxb) return VBS_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());
+    const size_t N = (size_t)n, M = (size_t)h->maxm;
+    if (ncomp) HIPCHK(h, hipMemcpy(ncomp, h->ncomp, N * 2 * sizeof(u32), hipMemcpyDeviceToHost));
+    if (band_sums) HIPCHK(h, hipMemcpy(band_sums, h->band_sums, N * M * 4 * sizeof(u64), hipMemcpyDeviceToHost));
+    if (area_first) HIPCHK(h, hipMemcpy(area_first, h->area_first, N * M * sizeof(u32), hipMemcpyDeviceToHost));
+    if (area_sums) HIPCHK(h, hipMemcpy(area_sums, h->area_sums, N * M * VBS_AREA_SUMS * sizeof(i64), hipMemcpyDeviceToHost));
+    if (probe) HIPCHK(h, hipMemcpy(probe, h->probe, N * M * 4 * sizeof(unsigned short), hipMemcpyDeviceToHost));
+    if (slow) HIPCHK(h, hipMemcpy(slow, h->slow_flag, N * sizeof(u32), hipMemcpyDeviceToHost));
+    return VBS_OK;
+}
+
 extern "C" int vbs_ncc_counters(vbs_handle* h, uint64_t out[3], int reset) {
     if (!h || !out) return VBS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
@@ -500,8 +519,7 @@ extern "C" int vbs_marker_center(vbs_handle* h, const uint8_t* mask, const uint8
         int nb = std::min(h->maxb, n - off);
         HIPCHK(h, hipMemsetAsync(h->fstat, 0, (size_t)nb * 8 * sizeof(u32), s));
         launch_threshold(h, mask + off * hw, area_mask + off * hw, nb, s);
-        launch_morph(h, nb, s);
-        launch_label(h, nb, s);
+        launch_labelling(h, nb, s);
         launch_finalize(h, nb, det + (size_t)off * h->maxm * VBS_DET_COLS, counts + off, s);
         int rc = check_launch(h);
         if (rc != VBS_OK) return rc;
@@ -559,8 +577,7 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
                          s, plane);
         if (rc != VBS_OK) return rc;
         if ((rc = gp.release(k)) != VBS_OK) return rc;
-        launch_morph(h, nb, s);
-        launch_label(h, nb, s);
+        launch_labelling(h, nb, s);
         launch_finalize(h, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr,
                         counts ? counts + off : nullptr, s);
         if (table)

@@ -84,6 +84,8 @@ struct vbs_handle {
     unsigned short* probe;   // [maxb][maxm][4]  component ids of the 2x2 cell around every band centroid
     u64* ncc_tot;      // [4]  running NCC decision counters (vbs_ncc_counters)
     u32* slow_flag;    // [maxb]  1 = the fast labelling path handed the frame on
+    size_t stage_lds_set = 0, ccl_lds_set[2] = {0, 0};   // dynamic LDS declared for k_stage / k_ccl<0|1> through this handle
+    int stage_impl = 0;             // vbs_set_option(VBS_OPT_STAGE_IMPL): 0 fused k_stage, 1 the round-2 kernels (k_morph + k_ccl)
     int gray_bits = 15;             // BGR2GRAY fixed-point coefficient set: 15 (OpenCV 4) | 14 (OpenCV <= 3.4.1)
     bool force_seq_match = false;   // vbs_set_option(VBS_OPT_FORCE_SEQ_MATCH)
     bool gray_side = false;         // vbs_set_option(VBS_OPT_GRAY_SIDE_STREAM)
@@ -128,8 +130,7 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
 void launch_points(int which, const double* in, int n, const vbs_camera& cam, double* out, int32_t* ok,
                    hipStream_t s);
 void launch_threshold(vbs_handle* h, const u8* mask, const u8* area, int nb, hipStream_t s);
-void launch_morph(vbs_handle* h, int nb, hipStream_t s);
-void launch_label(vbs_handle* h, int nb, hipStream_t s);
+void launch_labelling(vbs_handle* h, int nb, hipStream_t s);    // band / open planes, their components and sums (a9 - a12)
 void launch_finalize(vbs_handle* h, int nb, double* det, int32_t* counts, hipStream_t s);
 void launch_track(vbs_handle* h, const double* det, const int32_t* counts32, int nb,
                   const double* ref_xy, int m_ref, double min_dist, float* table, hipStream_t s);

@@ -17,16 +17,9 @@
 #include <algorithm>
 #include <cstdlib>
 
-#include "common.h"
+#include "ccl_common.h"
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ u64 valid_mask(int j, int W) {
-    int rem = W - 64 * j;
-    if (rem >= 64) return ~0ull;
-    if (rem <= 0) return 0ull;
-    return (1ull << rem) - 1ull;
-}
-
 __device__ __forceinline__ u32 nz4(u32 x) {       // 4 bytes -> 4 bits (byte != 0)
     u32 t = (((x & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | x) >> 7;
     return __builtin_amdgcn_udot4(t & 0x01010101u, 0x08040201u, 0u, false);
@@ -104,20 +97,6 @@ __device__ __forceinline__ u64 hmorph(u64 wl, u64 wc, u64 wr, int lo, int hi) {
     return ulo;                                          // bit i = AND / OR of pixels i + lo .. i + hi
 }
 
-// ---- wave64 cross-lane primitives on DPP (gfx9: wave_shr/wave_shl/row_shr/row_bcast), a few cycles each;
-//      __shfl_* would go through ds_bpermute and its LDS-crossbar latency on every step of a row ----------
-__device__ __forceinline__ u32 dpp_shr1(u32 x) {        // lane i <- lane i-1, lane 0 <- 0
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xf, 0xf, false);
-}
-__device__ __forceinline__ u32 dpp_shl1(u32 x) {        // lane i <- lane i+1, lane 63 <- 0
-    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xf, 0xf, false);
-}
-__device__ __forceinline__ u64 dpp_shr1(u64 x) {
-    return ((u64)dpp_shr1((u32)(x >> 32)) << 32) | dpp_shr1((u32)x);
-}
-__device__ __forceinline__ u64 dpp_shl1(u64 x) {
-    return ((u64)dpp_shl1((u32)(x >> 32)) << 32) | dpp_shl1((u32)x);
-}
 // band = mask & ~erode_ns(mask) and open = dilate5(erode5(area)), separably, as a stream down the image:
 // a wave holds G = 64 / WW strips of rows side by side (lane = strip * WW + word column) and takes one image row per
 // step; the horizontal passes get their neighbour words by DPP lane shifts, the vertical passes are delay lines in
@@ -126,12 +105,13 @@ __device__ __forceinline__ u64 dpp_shl1(u64 x) {
 // Outside the image erosion sees 1s (pixels ignored), dilation sees 0s - scipy 'reflect' / cv2's default border.
 template <int NS14>                                      // ns = 14 (large frames) or 8 (small)
 __global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits, const u64* __restrict__ abits,
-                                               u64* __restrict__ band, u64* __restrict__ opn, int nb, int H, int W, int WW,
-                                               int G, int strips, int rows_per_strip, int waves_per_frame) {
+                                               u64* __restrict__ band, u64* __restrict__ opn, const u32* __restrict__ only,
+                                               int nb, int H, int W, int WW, int G, int strips, int rows_per_strip,
+                                               int waves_per_frame) {
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = gw / waves_per_frame;
-    if (n >= nb) return;                                 // wave-uniform
+    if (n >= nb || (only && !only[n])) return;           // wave-uniform (`only`: just the frames the fused path handed on)
     const int sidx = (gw - n * waves_per_frame) * G + lane / WW, j = lane % WW;
     const bool act = lane < G * WW && sidx < strips;
     const int ra = min(sidx * rows_per_strip, H), rb = min(ra + rows_per_strip, H);
@@ -206,7 +186,7 @@ __global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits, co
     }
 }
 
-void launch_morph(vbs_handle* h, int nb, hipStream_t s) {
+static void launch_morph(vbs_handle* h, int nb, const u32* only, hipStream_t s) {
     const int G = 64 / h->WW;                            // strips per wave (WW <= 64)
     // strips per frame: enough waves to fill the chip several times over, but strips much longer than the ns - 1 rows
     // each re-reads
@@ -222,10 +202,10 @@ void launch_morph(vbs_handle* h, int nb, hipStream_t s) {
     dim3 grid((waves + 3) / 4);
     if (h->bp.ns == 14)
         VBS_LAUNCH(h, s, "k_morph", k_morph<14>, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits, h->open_bits,
-                   nb, h->H, h->W, h->WW, G, strips, rps, wpf);
+                   only, nb, h->H, h->W, h->WW, G, strips, rps, wpf);
     else
         VBS_LAUNCH(h, s, "k_morph", k_morph<8>, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits, h->open_bits,
-                   nb, h->H, h->W, h->WW, G, strips, rps, wpf);
+                   only, nb, h->H, h->W, h->WW, G, strips, rps, wpf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -344,7 +324,6 @@ __device__ __forceinline__ u32 block_exclusive_scan(u32 v, u32* tmp, u32* total)
     return ex;
 }
 
-#define NMOM 15
 // moment index of x^a y^b, a+b <= 4:  (0,0) (1,0) (0,1) (2,0) (1,1) (0,2) (3,0) (2,1) (1,2) (0,3) (4,0) (3,1) (2,2) (1,3) (0,4)
 #define NONE32 0xFFFFFFFFu
 
@@ -880,12 +859,22 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     }                                                   // frames
 }
 
-bool launch_ccl(vbs_handle* h, int nb, hipStream_t s);   // false: geometry outside the fast path
+bool launch_ccl(vbs_handle* h, int nb, hipStream_t s);   // false: geometry outside the round-2 fast path
+bool launch_stage(vbs_handle* h, int nb, hipStream_t s);  // false: geometry outside the fused path
 
-// a9-a13 labelling: the parallel fast path (k_ccl.hip), then the general kernel over the frames it handed on (none on
-// marker frames: its workgroups find no flagged frame and exit)
-void launch_label(vbs_handle* h, int nb, hipStream_t s) {
-    const int all = launch_ccl(h, nb, s) ? 0 : 1;
+// a9-a12: band / opened planes, labelling, per-component sums.  The fused kernel (k_stage.hip) takes the pass; k_morph and
+// the general kernel then run over the frames it handed on (none on marker frames: their waves / workgroups find no
+// flagged frame and exit).  Geometries outside the fused path - and VBS_OPT_STAGE_IMPL = 1 - take the round-2 kernels:
+// k_morph over every frame, k_ccl<0|1>, the general kernel over what those hand on.
+void launch_labelling(vbs_handle* h, int nb, hipStream_t s) {
+    (void)hipMemsetAsync(h->slow_flag, 0, (size_t)nb * sizeof(u32), s);
+    int all = 0;
+    if (h->stage_impl == 0 && launch_stage(h, nb, s)) {
+        launch_morph(h, nb, h->slow_flag, s);
+    } else {
+        launch_morph(h, nb, nullptr, s);
+        all = launch_ccl(h, nb, s) ? 0 : 1;
+    }
     VBS_LAUNCH(h, s, "k_label", k_label, dim3(nb < 64 ? nb : 64), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
                h->node_pos, h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first, h->area_sums, h->fstat,
                h->lut, h->slow_flag, h->probe, nb, all, h->H, h->W, h->WW, h->maxm, VBS_KNOB("VBS_LABEL_STOP"));

@@ -170,6 +170,19 @@ class Engine:
         self._check(self.lib.vbs_frame_stats(self._h, out.ctypes.data_as(C.c_void_p), n), "vbs_frame_stats")
         return out
 
+    def stage_tables(self, n):
+        """Host copies of the labelling kernels' per-component tables for the first n frames of the last internal pass
+        (`vbs_stage_tables`, diagnostic): dict of ncomp [n,2], band_sums [n,M,4], area_first [n,M], area_sums [n,M,16],
+        probe [n,M,4], slow [n]."""
+        M = self.max_markers
+        t = {"ncomp": np.zeros((n, 2), np.uint32), "band_sums": np.zeros((n, M, 4), np.uint64),
+             "area_first": np.zeros((n, M), np.uint32), "area_sums": np.zeros((n, M, 16), np.int64),
+             "probe": np.zeros((n, M, 4), np.uint16), "slow": np.zeros((n,), np.uint32)}
+        self._check(self.lib.vbs_stage_tables(self._h, n, *(t[k].ctypes.data_as(C.c_void_p) for k in
+                                                            ("ncomp", "band_sums", "area_first", "area_sums", "probe", "slow"))),
+                    "vbs_stage_tables")
+        return t
+
     def ncc_counters(self, reset=False):
         """{ambiguous, exact, frames} over every detection pass since the last reset (`vbs_ncc_counters`)."""
         out = np.zeros(3, dtype=np.uint64)
