@@ -1,5 +1,7 @@
-"""Phase timing of the labelling fast path (k_ccl): runs the fused path with the debug library (libvbs_dbg.so, built with
--DVBS_DEBUG_KNOBS) and VBS_CCL_STOP = 1..6, printing the live per-kernel times.  usage: gpu_ccl_phase.py [frames] [c3|c5]"""
+"""Phase timing of the fused labelling kernel (k_stage): runs the fused path with the debug library (libvbs_dbg.so, built
+with -DVBS_DEBUG_KNOBS) and VBS_STAGE_STOP set, printing the live per-kernel times (us per frame).
+stops: 1 band morph | 2 + band walk (labels + sums) | 3 + tile links | 4 + components | 10 + sums out, probe requests |
+11 + open morph, Euler | 12 + walk 1 (labels) | 13 + tile links | 14 + components | 0 + walk 2 (moments, probes).  usage: gpu_stage_phase.py [frames] [c3|c5]"""
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -17,11 +19,11 @@ if len(sys.argv) > 3 and sys.argv[3] == "child":
     for _ in range(3):
         _, _, counts = eng.track_to_3d(ft)
     p = eng.profile_read()
-    print(json.dumps({k: round(1e3 * v[1] / v[0] / n, 4) for k, v in p.items() if "ccl" in k or "label" in k or "morph" in k or "slow" in k or "final" in k or "stage" in k}))
+    print(json.dumps({k: round(1e3 * v[1] / v[0] / n, 4) for k, v in p.items() if "stage" in k or "label" in k or "morph" in k or "final" in k}))
 else:
     n = sys.argv[1] if len(sys.argv) > 1 else "512"
     w = sys.argv[2] if len(sys.argv) > 2 else "c3"
-    for stop in (2, 7, 8, 3, 4, 5, 9, 6, 0):    # counts+scan | parents | jumping | other links | ids | anchors | border-pixel list | moments | all
-        env = dict(os.environ, VBS_CCL_STOP=str(stop))
+    for stop in (1, 2, 3, 4, 10, 11, 12, 13, 14, 0):
+        env = dict(os.environ, VBS_STAGE_STOP=str(stop))
         r = subprocess.run([sys.executable, __file__, n, w, "child"], env=env, capture_output=True, text=True, timeout=300)
         print("stop", stop, r.stdout.strip(), r.stderr.strip()[-300:] if r.returncode else "", flush=True)

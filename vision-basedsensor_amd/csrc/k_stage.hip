@@ -1,48 +1,68 @@
 // a9-a13, fused fast path (marker_detection.py:170-196): band = mask & ~erode(mask) and the 5x5 opening of the area
 // mask, the connected components of both (4- / 8-connectivity) and the per-component sums k_finalize needs, in ONE
 // kernel per pass, one workgroup of 1024 threads per frame.  Nothing but the two input bit planes is read from memory
-// and neither the band / opened planes nor any list of pixels is written: a frame's planes live in the registers of its
-// workgroup.
+// (every row once) and neither the band / opened planes nor any list of pixels or runs is written: a frame's planes
+// live in the registers of its workgroup.
 //
-// A thread owns a COLUMN SEGMENT: word column j (64 px) x R consecutive rows (R = 22 at 1280x1024: 2 VGPRs per row).
-// A wave holds G = 64 / WW such segments side by side per word column (lane = g * WW + j), so the words left and right
-// of a lane's word are in the neighbouring lanes (DPP moves) and the rows above / below it are its own registers; the
-// segment also keeps one halo row above and below (computed, not exchanged).  All passes over the rows are unrolled:
-//   morph  the source rows a segment needs (R + NS, R + 10) are loaded once; the vertical 14- / 5-row AND / OR runs in
-//          place by doubling (2, 4, 8, 14 rows), the horizontal one on 64-bit words by doubling with the neighbour
-//          lane's word (v_alignbit funnel shifts)
-//   A      runs that start in each word (+ bit-quad Euler number of the opened mask); the runs (union-find nodes) are
-//          numbered in RASTER order: counts packed two rows per register, a segmented prefix sum over the lanes of a
-//          row block, and a block prefix sum over the image rows in LDS.  Raster order makes the run that enters a word
-//          from the left the node `word base - 1`, the root of a component its first run, and the rank of the roots
-//          ndimage.label's / cv2.findContours' order.
-//   B, C   links to the row above (ccl_common.h: first link = parent, further links -> pair list), pointer jumping,
-//          the pair unions, flatten, rank the roots: as k_ccl.hip, on the node table in LDS
-//   D      band: count / sum x / sum y; the sums of a segment stay in registers (two entries: first run of a word,
-//          other runs) and go to the component's LDS accumulators when the component under the segment changes
-//          open: CHAIN_APPROX_SIMPLE vertex multiplicity BIT-PARALLEL (the 256-entry table as boolean functions of
-//          the eight shifted neighbour planes: an arc of background neighbours that starts at direction a counts unless
-//          it has no 4-neighbour or is exactly {a, a+1, a+2}), so only real vertices are visited; per run the row sums
-//          s_a = sum mult dx^a, then the 15 moments as s_a dy^b: orders 0-3 cached in registers like the band sums,
-//          order 4 by LDS atomics per run; the component ids of the 2x2 cell around every band centroid ("probes")
-//          are answered by the segment that owns the pixel (requests posted through a small LDS mailbox)
-// Frames the fast path cannot take (more runs than the node table holds, too many components / root candidates / pair
-// links, holes in the opened mask, a vertex of multiplicity > 2, a crowded mailbox) set their slow flag: k_morph and
-// k_label (k_label.hip) redo them.
+// A thread owns a SEGMENT OF A WORD COLUMN: word column j (64 px) x R consecutive rows (R = 22 at 1280x1024: 2 VGPRs
+// per row).  A wave holds G = 64 / WW row blocks side by side (lane = g * WW + j): the words left and right of a lane's
+// word are in the neighbouring lanes (DPP moves), the rows above / below it are its own registers.  Every pass over the
+// rows is unrolled.
+//   morph   the rows of the neighbouring row blocks that a block's windows reach come through LDS (each thread publishes
+//           its first / last rows once).  The rows stream through register delay lines (vertical 14- / 5-row AND / OR by
+//           doubling: 2, 4, 8, 14 rows); results lag their sources, so they overwrite the tile in place.  The horizontal
+//           windows work on 64-bit words by doubling with the neighbour lane's word (v_alignbit funnel shifts).
+//   label   NOT run by run: a thread labels its own 64 x R tile in registers.  It keeps up to K "slots"; a slot is a
+//           tile-local piece of a component ("segment") = the mask of its pixels in the previous row.  The pixels of a
+//           segment in the next row are the runs that touch that mask, found for all runs at once with two carry chains
+//           (add the seeds to the row: the carry fills each run upwards from its lowest seed; the same on the reversed
+//           word fills downwards).  Runs no slot reaches start new segments.  Only what crosses a tile goes through the
+//           union-find in LDS (uint16 parents over <= 8 segments per thread): two segments that meet in a run, the
+//           segment holding bit 63 of a row with the one holding bit 0 of the word to the right (ids by DPP;
+//           8-connectivity: also the rows above / below), and after the walk the first row of a tile with the last row
+//           of the tile above.
+//   sums    band: count / sum x / sum y per slot in registers (sum of bit positions by six masked popcounts), one record
+//           per segment; records -> components once the union-find is resolved.
+//           open: the labelling walk is replayed once the components and their first pixels are known;
+//           CHAIN_APPROX_SIMPLE vertex multiplicity BIT-PARALLEL (the 256-entry table as boolean functions of the eight
+//           shifted neighbour planes: an arc of background neighbours that starts at direction a counts unless it has no
+//           4-neighbour or is exactly {a, a+1, a+2}), so only real vertices are visited; per slot and row
+//           s_a = sum mult dx^a, the 15 moments as s_a dy^b: orders 0-3 in registers until the slot is reused, order 4
+//           by LDS atomics per row
+//   order   components are ranked by their first pixel (ndimage.label's order; reversed: cv2.findContours')
+//   probes  component ids of the 2x2 pixel cell around every band centroid, answered during the replay by the thread
+//           that owns the pixel (requests posted through a small LDS mailbox)
+// Frames the fast path cannot take (more than K segments alive in a tile or 8 in all, too many records / components, a
+// component that reaches more than 150 px from its first pixel, holes in the opened mask, a vertex of multiplicity > 2,
+// a crowded mailbox) set their slow flag (the value says why): k_morph and k_label (k_label.hip) redo them.
 #include "ccl_common.h"
 
 #define ST_NT 1024
-#define ST_MB_CAP 8                // probe requests a segment can hold (one per centroid, row and word)
+#define ST_MB_CAP 8                // probe requests a thread can hold (one per centroid, row and word)
+#define SG_KB 4                    // slots of the band walk (a ring crosses a tile as two arcs)
+#define SG_KO 3                    // slots of the opened-mask walks
+#define SG_SEGMAX 8                // segments a thread can start; segment id = 8 tid + i
+#define SG_REC 2048                // segment records per frame
+#define SG_PQ 4096                 // segment pairs waiting to be united
 #define NONE32 0xFFFFFFFFu
+// why a frame was handed on (slow_flag value)
+#define SLOW_SLOTS 1               // a tile needed more slots / segments / records than there are
+#define SLOW_NCOMP 2               // more components than max_markers (band: 1024, open: 512)
+#define SLOW_MAILBOX 3
+#define SLOW_HOLES 4
+#define SLOW_VERTEX 5              // a contour vertex of multiplicity > 2
+#define SLOW_LARGE 6               // a component reaches more than 150 px from its first pixel
 
 struct StageGeom {
     int H, W, WW, G, NB, maxm;      // G row blocks per wave, NB = 16 G row blocks of R rows
-    u32 node_cap, pair_cap;
-    u32 off_rowb, off_acc, off_mb, off_tmp;      // byte offsets into the dynamic LDS
+    u32 off_rec, off_bot, off_pq, off_mb, off_tmp;       // byte offsets into the dynamic LDS (parents / row exchange at 0)
     int stop;                       // debug builds: leave after phase `stop`
 };
 
 __device__ __forceinline__ u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
+__device__ __forceinline__ u64 brev64(u64 x) {
+    return mk64(__builtin_bitreverse32((u32)(x >> 32)), __builtin_bitreverse32((u32)x));
+}
 
 // bit p of the result = bit p + s of the row (this word, then the right neighbour's); `fill` = what lies past the row
 // end.  Every lane must execute it (DPP), s = 1 .. 31.
@@ -89,46 +109,423 @@ __device__ __forceinline__ u64 hwin(u64 v, bool hasl, bool hasr) {
     return ERODE ? (f & b) : (f | b);
 }
 
-// in-place vertical window over N consecutive entries of a[0 .. CNT): a[t] = op(a[t .. t + N - 1])
-template <int N, int CNT, bool ERODE>
-__device__ __forceinline__ void vwin(u64 (&a)[CNT]) {
-#define VSTEP(S, LEN)                                                          \
-    _Pragma("unroll") for (int t = 0; t + (S) < CNT; ++t) a[t] = ERODE ? (a[t] & a[t + (S)]) : (a[t] | a[t + (S)]);
-    if (N >= 2) { VSTEP(1, 2) }
-    if (N >= 4) { VSTEP(2, 4) }
-    if (N == 5) { VSTEP(1, 5) }
-    if (N >= 8) { VSTEP(4, 8) }
-    if (N == 14) { VSTEP(6, 14) }
-#undef VSTEP
+// the runs of B that hold a bit of S (S a subset of B); rB = brev64(B).  Adding S to B carries from the lowest seed of
+// every run to the run's top; the same on the reversed words fills from the highest seed down.
+__device__ __forceinline__ u64 fill_runs(u64 B, u64 rB, u64 S) {
+    const u64 up = ((S + B) ^ B) & B;
+    const u64 rS = brev64(S);
+    const u64 dn = brev64(((rS + rB) ^ rB) & rB);
+    return up | dn | S;
 }
 
-#define WB(t) ((wbp[(t) >> 1] >> (((t) & 1) * 16)) & 0xFFFFu)
+// sum of the positions of the set bits
+__device__ __forceinline__ u32 sum_bitpos(u64 x) {
+    const u32 lo = (u32)x, hi = (u32)(x >> 32);
+    u32 s = (u32)__popc(lo & 0xAAAAAAAAu) + (u32)__popc(hi & 0xAAAAAAAAu);
+    s += 2u * ((u32)__popc(lo & 0xCCCCCCCCu) + (u32)__popc(hi & 0xCCCCCCCCu));
+    s += 4u * ((u32)__popc(lo & 0xF0F0F0F0u) + (u32)__popc(hi & 0xF0F0F0F0u));
+    s += 8u * ((u32)__popc(lo & 0xFF00FF00u) + (u32)__popc(hi & 0xFF00FF00u));
+    s += 16u * ((u32)__popc(lo & 0xFFFF0000u) + (u32)__popc(hi & 0xFFFF0000u));
+    s += 32u * (u32)__popc(hi);
+    return s;
+}
 
-// Phases A - C for the plane in Bw (tile rows 0 .. R + 1 = image rows y0 - 1 .. y0 + R; row 0 and R + 1 are halos).
-// Returns 0, or (workgroup-uniform) why the fast path cannot take the frame: 1 more runs than the node table holds,
-// 2 pair list full, 3 too many components, 4 holes in the opened mask, 5 root list full.  On return P[node] = component id (bit 15
-// marks the root run), wbp = node index before each word of tile rows 0 .. R (two per register).
-template <int R, int MODE>
-__device__ __forceinline__ int stage_label(const u64 (&Bw)[R + 2], u32 lm, u32 rm, u32 (&wbp)[(R + 2) / 2],
-                                            unsigned short* P, unsigned short* rowb, unsigned char* accb, u32* tmp,
-                                            int* misc, const StageGeom& geo, int y0, int j, bool act, u32& total_out,
-                                            u32& ncomp_out) {
-    constexpr int NP = (R + 2) / 2;
+// Segments found to belong together are only NOTED during a walk (a pair in an LDS queue, a handful of instructions where
+// it happens); the unions run densely, one pair per thread, once the walk is over.
+struct PairQ { u32* q; int* n; };
+__device__ __forceinline__ void pq_push(const PairQ& Q, u32 a, u32 b) {
+    const int i = atomicAdd(Q.n, 1);
+    if (i < SG_PQ) Q.q[i] = (a << 16) | b;               // (an overflowing queue hands the frame on: checked after the walk)
+}
+
+// One row of a labelling walk: Rn[k] = the runs of B that continue the segment in slot k (pm[k] = its pixels in the row
+// above).  A run two segments reach stays with the lower slot and the two are united.  Returns the pixels given out.
+template <int K, bool C8, bool UNITE>
+__device__ __forceinline__ u64 seg_update(u64 B, u64 rB, const u64 (&pm)[K], const u32 (&sid)[K], u64 (&Rn)[K],
+                                          const PairQ& Q) {
+    u64 claimed = 0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        Rn[k] = 0;
+        if (!__any(pm[k] != 0ull)) continue;             // (wave-uniform)
+        u64 adj = pm[k];
+        if (C8) adj |= (adj << 1) | (adj >> 1);
+        u64 Rk = fill_runs(B, rB, B & adj);
+        const u64 ov = Rk & claimed;
+        if (ov) {
+            if (UNITE) {
+#pragma unroll
+                for (int m = 0; m < K; ++m)
+                    if (m < k && (Rn[m] & ov)) pq_push(Q, sid[k], sid[m]);
+            }
+            Rk &= ~claimed;
+        }
+        claimed |= Rk;
+        Rn[k] = Rk;
+    }
+    return claimed;
+}
+
+// links across the right edge of the word: the segment holding bit 63 of this row with the one holding bit 0 of the word
+// to the right (and, 8-connectivity, with bit 0 of its previous row; bit 63 of my previous row with its bit 0).
+// Executed by every lane (DPP).  p63 / prs0: the values of the previous row; la / lb: the last pair united.
+template <int K, bool C8>
+__device__ __forceinline__ void seg_hlinks(const u64 (&pm)[K], const u32 (&sid)[K], bool hasr, u32& p63, u32& prs0, u32& la,
+                                           u32& lb, const PairQ& Q) {
+    u32 s63 = NONE16, s0 = NONE16;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        if (pm[k] >> 63) s63 = sid[k];
+        if (pm[k] & 1ull) s0 = sid[k];
+    }
+    u32 rs0 = dpp_shl1(s0);
+    if (!hasr) rs0 = NONE16;
+    auto link = [&](u32 a, u32 b) {
+        if (a != NONE16 && b != NONE16 && (a != la || b != lb)) { pq_push(Q, a, b); la = a; lb = b; }
+    };
+    link(s63, rs0);
+    if (C8) { link(s63, prs0); link(p63, rs0); }
+    p63 = s63; prs0 = rs0;
+}
+
+// After a walk: the queued unions, then the components of the segments.  The roots (P[s] == s after flattening) are numbered, every segment's
+// entry becomes the number of its root (bit 15 marks the root), comp_pos[c] = first pixel of component c in raster order
+// (minimum over its segments' first pixels), cidmap[c] = rank of that pixel = the component's id.  Workgroup-uniform
+// return: components, or NONE32 when there are more than `limit`.
+__device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nseg, const unsigned short* rec_sid,
+                                           const u32* rec_pos, u32 nrec, u32* comp_pos, unsigned short* cidmap, u32* tmp,
+                                           u32 limit, const PairQ& Q) {
     const int tid = threadIdx.x;
-    const int WW = geo.WW, W = geo.W;
-    // ---- A: run starts per word, raster numbering (+ Euler number) ---------------------------------------------
-    u32 cpk[NP];
-    int e4 = 0;
+    {
+        const int np = min(*Q.n, SG_PQ);
+        for (int i = tid; i < np; i += ST_NT) { const u32 pr = Q.q[i]; ccl_union(P, pr >> 16, pr & 0xFFFFu); }
+    }
+    __syncthreads();
+    for (u32 i = 0; i < nseg; ++i) {                     // flatten (no halving: a late store must be a root)
+        u32 x = sbase + i, p;
+        while ((p = ((volatile unsigned short*)P)[x]) != x) x = p;
+        if (x != sbase + i) P[sbase + i] = (unsigned short)x;
+    }
+    __syncthreads();
+    u32 nroot = 0;
+    for (u32 i = 0; i < nseg; ++i) nroot += (P[sbase + i] == sbase + i);
+    u32 ncomp;
+    u32 c0 = ccl_scan(nroot, tmp, &ncomp);
+    if (ncomp > limit) return NONE32;
+    for (u32 i = 0; i < nseg; ++i)
+        if (P[sbase + i] == sbase + i) { comp_pos[c0] = NONE32; P[sbase + i] = (unsigned short)(0x8000u | c0++); }
+    __syncthreads();
+    for (u32 i = 0; i < nseg; ++i) {
+        const u32 v = P[sbase + i];
+        if (!(v & 0x8000u)) P[sbase + i] = (unsigned short)(P[v] & 0x7FFFu);
+    }
+    __syncthreads();
+    for (u32 r = tid; r < nrec; r += ST_NT) atomicMin(&comp_pos[P[rec_sid[r]] & 0x7FFFu], rec_pos[r]);
+    __syncthreads();
+    for (u32 c = tid; c < ncomp; c += ST_NT) {           // rank by first pixel (positions are distinct)
+        const u32 p = comp_pos[c];
+        u32 rank = 0;
+        for (u32 q = 0; q < ncomp; ++q) rank += comp_pos[q] < p;
+        cidmap[c] = (unsigned short)rank;
+    }
+    __syncthreads();
+    return ncomp;
+}
+
+struct MomEntry { int m[10]; };                          // moments of order 0 - 3 about the component's first pixel
+
+__device__ __forceinline__ void mom_flush(MomEntry& e, u32 cid, u64* acc) {
+    if (e.m[0]) {
+        u64* a = acc + cid * NMOM;
 #pragma unroll
-    for (int k = 0; k < NP; ++k) cpk[k] = 0;
+        for (int q = 0; q < 10; ++q)
+            if (e.m[q]) atomicAdd(&a[q], (u64)(i64)e.m[q]);
+    }
 #pragma unroll
-    for (int t = 0; t <= R; ++t) {
-        const u64 B = Bw[t];
-        const u32 c = (u32)__popcll(ccl_starts(B, (lm >> t) & 1u));
-        cpk[t >> 1] |= c << ((t & 1) * 16);
-        if (MODE == 1 && t >= 1) {
-            // bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the zero-padded image;
-            // a word counts the windows whose top row is its row (image row 0 also the padding row above it)
+    for (int q = 0; q < 10; ++q) e.m[q] = 0;
+}
+
+template <int R, int NS>
+__global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask_all, const u64* __restrict__ area_all,
+                                                    u32* __restrict__ ncomp_all, u64* __restrict__ band_sums,
+                                                    u32* __restrict__ area_first, i64* __restrict__ area_sums,
+                                                    unsigned short* __restrict__ probe_all, u32* __restrict__ fstat,
+                                                    u32* __restrict__ slow_flag, StageGeom geo) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    u64* hx = reinterpret_cast<u64*>(smem);                                               // row exchange of the morph steps
+    unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [8 ST_NT] segment parents
+    unsigned char* recb = smem + geo.off_rec;                                            // segment records
+    unsigned char* botb = smem + geo.off_bot;                                            // last-row slots | component tables
+    u32* mb_cnt = reinterpret_cast<u32*>(smem + geo.off_mb);                              // [ST_NT] probe requests
+    u32* mb_req = mb_cnt + ST_NT;                                                         // [ST_NT][ST_MB_CAP]
+    PairQ Q;
+    Q.q = reinterpret_cast<u32*>(smem + geo.off_pq);                                      // [SG_PQ]
+    u32* tmp = reinterpret_cast<u32*>(smem + geo.off_tmp);                                // [32]
+    int* misc = reinterpret_cast<int*>(tmp + 32);                                         // [16]
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = geo.H, W = geo.W, WW = geo.WW, G = geo.G, maxm = geo.maxm;
+    const int g = lane / WW, j = lane - g * WW;
+    const bool act = g < G;
+    const int blk = wave * G + g, y0 = blk * R;
+    const bool hasl = j > 0, hasr = act && j + 1 < WW;
+    const u64 vm = act ? valid_mask(j, W) : 0ull;
+    const int NBW = geo.NB * WW, bj = act ? blk * WW + j : 0;
+    const bool hasu = act && blk > 0, hasd = act && blk + 1 < geo.NB;
+    const u32 sbase = (u32)tid * SG_SEGMAX;
+    Q.n = &misc[5];
+    if (tid < 16) misc[tid] = 0;     // [0] Euler sum, [4] records, [5] queued pairs, [6] hand the frame on (why)
+    mb_cnt[tid] = 0;
+    const int64_t fo = (int64_t)n * H * WW;
+    unsigned short* rec_sid = reinterpret_cast<unsigned short*>(recb);                   // [SG_REC] records, by column
+    u32* rec_pos = reinterpret_cast<u32*>(recb + 2 * SG_REC);
+    u32* rec_cnt = rec_pos + SG_REC;
+    u32* rec_sx = rec_cnt + SG_REC;
+    u32* rec_sy = rec_sx + SG_REC;
+    // last-row slots of every tile; the component tables take their place once the tiles are linked
+    u64* bot_mask = reinterpret_cast<u64*>(botb);                                         // [K][NBW]
+    unsigned short* bot_sid = reinterpret_cast<unsigned short*>(botb + (size_t)8 * SG_KB * NBW);   // [K][NBW]
+    u32* comp_pos = reinterpret_cast<u32*>(botb);                                         // [1024] first pixel of a component
+    unsigned short* cidmap = reinterpret_cast<unsigned short*>(botb + 4096);              // [1024] its rank = component id
+    unsigned char* accb = botb + 4096 + 2048;                                            // band sums | anchors + moments
+    u64 Bw[R + 2];
+
+    // ================================ band plane ====================================================================
+    {
+        constexpr int NA = NS / 2, NBL = NS / 2 - 1;     // rows of the window above / below its row
+        const u64* M = mask_all + fo;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int y = y0 + t;
+            Bw[t] = (act && y < H) ? (M[(int64_t)y * WW + j] | ~vm) : ~0ull;    // outside the image: ones (ignored)
+        }
+        if (act) {                                       // what the neighbouring row blocks' windows reach
+#pragma unroll
+            for (int k = 0; k < NA; ++k) hx[(size_t)k * NBW + bj] = Bw[R - NA + k];
+#pragma unroll
+            for (int k = 0; k < NBL; ++k) hx[(size_t)(NA + k) * NBW + bj] = Bw[k];
+        }
+        __syncthreads();
+        // the rows stream through the delay lines: h1 = the row before, a2[i] = AND of 2 rows ending i + 1 rows back, ..
+        u64 h1 = ~0ull, a2[2] = {~0ull, ~0ull}, a4[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        u64 a8[6] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
+#pragma unroll
+        for (int q = 0; q < R + NS - 1; ++q) {
+            const int r = q - NA;                        // source row relative to y0
+            u64 v;
+            if (r < 0) v = hasu ? hx[(size_t)(NA + r) * NBW + bj - WW] : ~0ull;
+            else if (r < R) v = Bw[r];
+            else v = hasd ? hx[(size_t)(NA + r - R) * NBW + bj + WW] : ~0ull;
+            const u64 n2 = h1 & v, n4 = a2[1] & n2;
+            u64 e;
+            if (NS == 14) {
+                const u64 n8 = a4[3] & n4;
+                e = a8[5] & n8;                          // rows r - 13 .. r
+                a8[5] = a8[4]; a8[4] = a8[3]; a8[3] = a8[2]; a8[2] = a8[1]; a8[1] = a8[0]; a8[0] = n8;
+            } else {
+                e = a4[3] & n4;                          // ns = 8: rows r - 7 .. r
+            }
+            a4[3] = a4[2]; a4[2] = a4[1]; a4[1] = a4[0]; a4[0] = n4;
+            a2[1] = a2[0]; a2[0] = n2;
+            h1 = v;
+            const int t = r - NBL;                       // the row whose window ends at r
+            if (t >= 0 && t < R) {
+                const u64 eh = hwin<NS, true>(e, hasl, hasr);
+                Bw[t] = (act && y0 + t < H) ? (Bw[t] & ~eh & vm) : 0ull;        // :171-174  maxima = mask & (window holds a 0)
+            }
+        }
+    }
+    __syncthreads();                                     // the exchange rows are read: their place becomes the parent table
+    if (geo.stop == 1) return;
+    u32 nband = 0;
+    {
+        u64 pm[SG_KB];
+        u32 sid[SG_KB], cnt[SG_KB], sy[SG_KB], sk[SG_KB], pos[SG_KB];
+#pragma unroll
+        for (int k = 0; k < SG_KB; ++k) { pm[k] = 0; sid[k] = 0; cnt[k] = 0; sy[k] = 0; sk[k] = 0; pos[k] = 0; }
+        u32 nseg = 0, la = NONE16, lb = NONE16, p63 = NONE16, prs0 = NONE16;
+        bool fail = false;
+        const u32 first_row = (u32)Bw[0], first_row_hi = (u32)(Bw[0] >> 32);
+        auto emit = [&](u32 sid_, u32 pos_, u32 cnt_, u32 sk_, u32 sy_) {
+            const int r = atomicAdd(&misc[4], 1);
+            if (r < SG_REC) {
+                rec_sid[r] = (unsigned short)sid_; rec_pos[r] = pos_; rec_cnt[r] = cnt_;
+                rec_sx[r] = 64u * (u32)j * cnt_ + sk_; rec_sy[r] = sy_;
+            } else fail = true;
+        };
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const u64 B = Bw[t];
+            bool live = false;
+#pragma unroll
+            for (int k = 0; k < SG_KB; ++k) live |= pm[k] != 0ull;
+            if (!__any(B != 0ull || live)) continue;     // (wave-uniform)
+            const u32 y = (u32)(y0 + t);
+            const u64 rB = brev64(B);
+            u64 Rn[SG_KB];
+            const u64 claimed = seg_update<SG_KB, false, true>(B, rB, pm, sid, Rn, Q);
+#pragma unroll
+            for (int k = 0; k < SG_KB; ++k) {
+                const u64 Rk = Rn[k];
+                if (__any(Rk != 0ull)) {
+                    const u32 c = (u32)__popcll(Rk);
+                    cnt[k] += c; sy[k] += c * y; sk[k] += sum_bitpos(Rk);
+                }
+                pm[k] = Rk;
+            }
+            u64 N = B & ~claimed;
+            while (N) {                                  // runs no segment reaches: new segments
+                const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                N &= t2;
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < SG_KB; ++k) {
+                    if (!done && pm[k] == 0ull) {
+                        if (cnt[k]) emit(sid[k], pos[k], cnt[k], sk[k], sy[k]);
+                        if (nseg < SG_SEGMAX) { sid[k] = sbase + nseg; P[sbase + nseg] = (unsigned short)(sbase + nseg); }
+                        else fail = true;
+                        ++nseg;
+                        const u32 c = (u32)__popcll(gg);
+                        pos[k] = y * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
+                        pm[k] = gg; cnt[k] = c; sy[k] = c * y; sk[k] = sum_bitpos(gg);
+                        done = true;
+                    }
+                }
+                if (!done) fail = true;
+            }
+            seg_hlinks<SG_KB, false>(pm, sid, hasr, p63, prs0, la, lb, Q);
+        }
+#pragma unroll
+        for (int k = 0; k < SG_KB; ++k) {
+            if (cnt[k]) emit(sid[k], pos[k], cnt[k], sk[k], sy[k]);
+            if (act) { bot_mask[(size_t)k * NBW + bj] = pm[k]; bot_sid[(size_t)k * NBW + bj] = (unsigned short)sid[k]; }
+        }
+        if (fail) misc[6] = SLOW_SLOTS;
+        __syncthreads();
+        if (misc[6]) { if (tid == 0) slow_flag[n] = (u32)misc[6]; return; }
+        if (geo.stop == 2) return;
+        // the first row of the tile against the last row of the tile above (its runs are segments sbase + 0, 1, .. in order)
+        if (hasu) {
+            u64 N = mk64(first_row, first_row_hi);
+            u32 i = 0;
+            while (N) {
+                const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                N &= t2;
+#pragma unroll
+                for (int k = 0; k < SG_KB; ++k)
+                    if (gg & bot_mask[(size_t)k * NBW + bj - WW]) pq_push(Q, sbase + i, bot_sid[(size_t)k * NBW + bj - WW]);
+                ++i;
+            }
+        }
+        __syncthreads();
+        if (geo.stop == 3) return;
+        const u32 nrec = (u32)misc[4];
+        const u32 ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, comp_pos, cidmap, tmp,
+                                      min((u32)maxm, 1024u), Q);
+        if (misc[5] > SG_PQ) { if (tid == 0) slow_flag[n] = SLOW_SLOTS; return; }
+        if (ncomp == NONE32) { if (tid == 0) slow_flag[n] = SLOW_NCOMP; return; }
+        if (geo.stop == 4) return;
+        // ---- component sums (center_of_mass :181) ----------------------------------------------------------------------
+        u32* acnt = reinterpret_cast<u32*>(accb);                                        // [maxm]
+        u64* asx = reinterpret_cast<u64*>(accb + 8 * ((maxm + 1) / 2));                   // [maxm]
+        u64* asy = asx + maxm;                                                           // [maxm]
+        for (u32 c = tid; c < ncomp; c += ST_NT) { acnt[c] = 0; asx[c] = 0; asy[c] = 0; }
+        __syncthreads();
+        for (u32 r = tid; r < nrec; r += ST_NT) {
+            const u32 cid = cidmap[P[rec_sid[r]] & 0x7FFFu];
+            atomicAdd(&acnt[cid], rec_cnt[r]); atomicAdd(&asx[cid], (u64)rec_sx[r]); atomicAdd(&asy[cid], (u64)rec_sy[r]);
+        }
+        __syncthreads();
+        // the sums go out; the probe requests (2x2 pixel cell around every centroid) go to the threads that own the pixels
+        u64* bs = band_sums + (int64_t)n * maxm * 4;
+        unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
+        for (u32 c = tid; c < ncomp; c += ST_NT) {
+            const u32 cn_ = acnt[c];
+            const u64 sx = asx[c], sy_ = asy[c];
+            bs[c * 4 + 0] = cn_; bs[c * 4 + 1] = sx; bs[c * 4 + 2] = sy_;
+            const double cn = (double)cn_;
+            const float xf = (float)((double)sx / cn), yf = (float)((double)sy_ / cn);
+            const int ix = (int)floorf(xf), iy = (int)floorf(yf);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int px = ix + (q & 1), py = iy + (q >> 1);
+                if (px < 0 || py < 0 || px >= W || py >= H) { pr[c * 4 + q] = (unsigned short)NONE16; continue; }
+                // one request per row and word: the pixel (ix + 1, py) rides along when it lies in the same word
+                const bool pair = (q & 1) == 0 && px + 1 < W && (px & 63) != 63;
+                if ((q & 1) && px > 0 && (px & 63) != 0) continue;                   // rode along with (ix, py)
+                const int ob = py / R, oi = py - ob * R + 1, ow = ob / G, og = ob - ow * G;
+                const int owner = ow * 64 + og * WW + (px >> 6);
+                const u32 slot = atomicAdd(&mb_cnt[owner], 1u);
+                if (slot < ST_MB_CAP)
+                    mb_req[owner * ST_MB_CAP + slot] = c | ((u32)q << 10) | ((u32)oi << 12) | ((u32)(px & 63) << 17) | ((u32)pair << 23);
+                else misc[6] = SLOW_MAILBOX;
+            }
+        }
+        if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; }
+        nband = ncomp;
+    }
+    (void)nband;
+    __syncthreads();
+    if (misc[6]) { if (tid == 0) slow_flag[n] = (u32)misc[6]; return; }      // a crowded mailbox
+    if (geo.stop == 10) return;
+
+    // ================================ opened area plane =============================================================
+    // tile rows 0 .. R + 1 = image rows y0 - 1 .. y0 + R (one halo row above and below: vertex planes, Euler number)
+    {
+        const u64* A = area_all + fo;
+#pragma unroll
+        for (int t = 0; t < R; ++t) {
+            const int y = y0 + t;
+            Bw[t + 1] = (act && y < H) ? (A[(int64_t)y * WW + j] | ~vm) : ~0ull;
+        }
+        if (act) {                                       // my last 5 rows, my first 5 rows
+#pragma unroll
+            for (int k = 0; k < 5; ++k) hx[(size_t)k * NBW + bj] = Bw[R - 5 + k + 1];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) hx[(size_t)(5 + k) * NBW + bj] = Bw[k + 1];
+        }
+        __syncthreads();
+        u64 e5[4] = {~0ull, ~0ull, ~0ull, ~0ull}, d5[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int q = 0; q < R + 10; ++q) {
+            const int r = q - 5;                         // source row relative to y0
+            u64 v;
+            if (r < 0) v = hasu ? hx[(size_t)(5 + r) * NBW + bj - WW] : ~0ull;
+            else if (r < R) v = Bw[r + 1];
+            else v = hasd ? hx[(size_t)(5 + r - R) * NBW + bj + WW] : ~0ull;
+            // vertical erosion over 5 rows -> row r - 2 (nothing outside the image), horizontal erosion
+            u64 ve = v & e5[0] & e5[1] & e5[2] & e5[3];
+            e5[3] = e5[2]; e5[2] = e5[1]; e5[1] = e5[0]; e5[0] = v;
+            const int ye = y0 + r - 2;
+            ve = hwin<5, true>(ve, hasl, hasr);
+            ve = (act && ye >= 0 && ye < H) ? (ve & vm) : 0ull;
+            // vertical dilation over 5 rows -> row r - 4, horizontal dilation
+            const u64 vd = ve | d5[0] | d5[1] | d5[2] | d5[3];
+            d5[3] = d5[2]; d5[2] = d5[1]; d5[1] = d5[0]; d5[0] = ve;
+            const int t = r - 4 + 1;                     // tile row of image row y0 + r - 4
+            if (t >= 0 && t <= R + 1) {
+                const u64 o = hwin<5, false>(vd, hasl, hasr);
+                const int y = y0 + r - 4;
+                Bw[t] = (act && y >= 0 && y < H) ? (o & vm) : 0ull;             // :195  morphologyEx(MORPH_OPEN, 5x5)
+            }
+        }
+    }
+    u32 lm, rm;                                          // bit t: bit 63 of the left / bit 0 of the right word in tile row t
+    {
+        u32 mym = 0, myl = 0;
+#pragma unroll
+        for (int t = 0; t <= R + 1; ++t) { mym |= (u32)(Bw[t] >> 63) << t; myl |= ((u32)Bw[t] & 1u) << t; }
+        lm = dpp_shr1(mym); rm = dpp_shl1(myl);
+        if (!hasl) lm = 0;
+        if (!hasr) rm = 0;
+    }
+    if (tid == 0) { misc[0] = 0; misc[4] = 0; misc[5] = 0; }
+    {
+        // bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the zero-padded image; a
+        // word counts the windows whose top row is its row (image row 0 also the padding row above it)
+        int e4 = 0;
+#pragma unroll
+        for (int t = 1; t <= R; ++t) {
+            const u64 B = Bw[t];
             const bool top = (y0 + t - 1) == 0;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
@@ -145,384 +542,177 @@ __device__ __forceinline__ int stage_label(const u64 (&Bw)[R + 2], u32 lm, u32 r
                 }
             }
         }
+        __syncthreads();                                 // exchange rows read; counters cleared
+        if (e4) atomicAdd(&misc[0], e4);
     }
-    if (MODE == 1 && e4) atomicAdd(&misc[0], e4);
-    // prefix sum over the word columns of each row block (lanes g WW .. g WW + WW - 1), two rows per register
-    u32 inc[NP];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) inc[k] = cpk[k];
-    for (int d = 1; d < WW; d <<= 1) {                   // (uniform trip count)
-#pragma unroll
-        for (int k = 0; k < NP; ++k) {
-            const u32 tv = (u32)__shfl_up((int)inc[k], d);
-            if (j >= d) inc[k] += tv;
-        }
-    }
-    if (act && j == WW - 1) {
-#pragma unroll
-        for (int t = 1; t <= R; ++t) rowb[y0 + t - 1] = (unsigned short)((inc[t >> 1] >> ((t & 1) * 16)) & 0xFFFFu);
-    }
-    __syncthreads();
-    u32 total;
-    {
-        const int NROWS = geo.NB * R, K = (NROWS + ST_NT - 1) / ST_NT;
-        const int i0 = min(tid * K, NROWS), i1 = min(i0 + K, NROWS);
-        u32 s = 0;
-        for (int i = i0; i < i1; ++i) s += rowb[i];
-        u32 ex = ccl_scan(s, tmp, &total);
-        for (int i = i0; i < i1; ++i) { const u32 c = rowb[i]; rowb[i] = (unsigned short)ex; ex += c; }
-    }
-    total_out = total;
-    if (total > geo.node_cap) return 1;                  // workgroup-uniform
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-        u32 rb = 0;
-        const int ya = y0 + 2 * k - 1, yb = ya + 1;
-        if (act && ya >= 0) rb = rowb[ya];
-        if (act && 2 * k + 1 <= R) rb |= (u32)rowb[yb] << 16;
-        wbp[k] = inc[k] - cpk[k] + rb;                   // (16-bit halves: no carry, every sum < 32768)
-    }
-    if (geo.stop == 2) return 0;
-
-    // ---- B: parents, pointer jumping, the remaining links ----------------------------------------------------------
-    CclLists L;
-    L.pairs = reinterpret_cast<u32*>(accb);
-    L.npairs = &misc[5];
-    L.pair_cap = (int)geo.pair_cap;
-    L.roots = MODE == 1 ? reinterpret_cast<u32*>(accb + CCL_MOM_COMPS * NMOM * 8 + CCL_OPEN_COMPS * 4) : nullptr;
-    L.nroots = &misc[4];
-    bool ovf = false;
-#pragma unroll
-    for (int t = 1; t <= R; ++t) {
-        const u64 B = Bw[t];
-        if (!__any(B != 0ull)) continue;                 // (wave-uniform)
-        if (B) {
-            const u32 pos0 = (u32)(y0 + t - 1) * (u32)W + 64u * (u32)j;
-            ovf |= ccl_link_word<MODE, 0>(P, B, Bw[t - 1], (lm >> t) & 1u, (lm >> (t - 1)) & 1u, (rm >> (t - 1)) & 1u, WB(t),
-                                          WB(t - 1), pos0, L);
-        }
-    }
-    if (ovf) misc[6] = 1;                                // the pair list is full: hand the frame on
-    __syncthreads();
-    if (misc[6]) return 2;
-    if (geo.stop == 7) return 0;
-    // pointer jumping: every node ends on the root of its tree (parents only ever move to an ancestor, so the
-    // unsynchronised reads inside a round are harmless); three flags in turn: the one cleared in round r was last read
-    // before the barrier of round r - 1
-    for (int f = 0;; f = f == 2 ? 0 : f + 1) {
-        if (tid == 0) misc[1 + (f == 2 ? 0 : f + 1)] = 0;
-        bool ch = false;
-        for (u32 i = tid; i < total; i += ST_NT) {
-            const u32 p = P[i], pp = P[p];
-            if (pp != p) { P[i] = (unsigned short)pp; ch = true; }
-        }
-        if (ch) misc[1 + f] = 1;
-        __syncthreads();
-        if (!misc[1 + f]) break;
-    }
-    if (geo.stop == 8) return 0;
-    {   // the further links, densely: one pair per thread
-        const int np = misc[5];
-        for (int i = tid; i < np; i += ST_NT) { const u32 pr = L.pairs[i]; ccl_union(P, pr >> 16, pr & 0xFFFFu); }
-    }
-    __syncthreads();
-    if (geo.stop == 3) return 0;
-
-    // ---- C: flatten, rank the roots in raster order, resolve every node to its component id ---------------------
-    for (u32 i = tid; i < total; i += ST_NT) {
-        u32 x = i, p;
-        while ((p = ((volatile unsigned short*)P)[x]) != x) x = p;
-        if (x != i) P[i] = (unsigned short)x;
-    }
-    __syncthreads();
-    const u32 K2 = (total + ST_NT - 1) / ST_NT;
-    const u32 r0 = min((u32)tid * K2, total), r1 = min(r0 + K2, total);
-    u32 nroot = 0;
-    for (u32 i = r0; i < r1; ++i) nroot += (P[i] == i);
+    if (geo.stop == 11) return;
     u32 ncomp;
-    u32 cid0 = ccl_scan(nroot, tmp, &ncomp);
-    ncomp_out = ncomp;
-    if (ncomp > (u32)geo.maxm || ncomp > (MODE == 0 ? 1024u : (u32)CCL_OPEN_COMPS)) return 3;
-    if (MODE == 1 && (int)ncomp - misc[0] / 4 != 0) return 4;       // holes: RETR_EXTERNAL needs the fill passes of the general path
-    if (MODE == 1 && misc[4] > CCL_ROOT_LIST) return 5;
-    for (u32 i = r0; i < r1; ++i)
-        if (P[i] == i) P[i] = (unsigned short)(0x8000u | cid0++);
-    __syncthreads();
-    for (u32 i = tid; i < total; i += ST_NT) {
-        const u32 v = P[i];
-        if (!(v & 0x8000u)) P[i] = (unsigned short)(P[v] & 0x7FFFu);
-    }
-    __syncthreads();
-    return 0;
-}
-
-struct BandEntry { u32 cid, cnt, sx, sy; };
-
-__device__ __forceinline__ void band_flush(BandEntry& e, u32* acnt, u64* asx, u64* asy) {
-    if (e.cnt) { atomicAdd(&acnt[e.cid], e.cnt); atomicAdd(&asx[e.cid], (u64)e.sx); atomicAdd(&asy[e.cid], (u64)e.sy); }
-    e.cnt = 0; e.sx = 0; e.sy = 0;
-}
-
-struct MomEntry { u32 cid; int m[10]; };                 // moments of order 0 - 3 about the component's first pixel
-
-__device__ __forceinline__ void mom_flush(MomEntry& e, u64* acc) {
-    if (e.cid != NONE32) {
-        u64* a = acc + e.cid * NMOM;
-#pragma unroll
-        for (int q = 0; q < 10; ++q)
-            if (e.m[q]) atomicAdd(&a[q], (u64)(i64)e.m[q]);
-    }
-    e.cid = NONE32;
-#pragma unroll
-    for (int q = 0; q < 10; ++q) e.m[q] = 0;
-}
-
-template <int R, int NS>
-__global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask_all, const u64* __restrict__ area_all,
-                                                    u32* __restrict__ ncomp_all, u64* __restrict__ band_sums,
-                                                    u32* __restrict__ area_first, i64* __restrict__ area_sums,
-                                                    unsigned short* __restrict__ probe_all, u32* __restrict__ fstat,
-                                                    u32* __restrict__ slow_flag, StageGeom geo) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [node_cap]
-    unsigned short* rowb = reinterpret_cast<unsigned short*>(smem + geo.off_rowb);        // [NB R + 1] nodes before a row
-    unsigned char* accb = smem + geo.off_acc;                                            // band sums | pairs | moments ..
-    u32* mb_cnt = reinterpret_cast<u32*>(smem + geo.off_mb);                              // [ST_NT] probe requests
-    u32* mb_req = mb_cnt + ST_NT;                                                         // [ST_NT][ST_MB_CAP]
-    u32* tmp = reinterpret_cast<u32*>(smem + geo.off_tmp);                                // [32]
-    int* misc = reinterpret_cast<int*>(tmp + 32);                                         // [16]
-    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = geo.H, W = geo.W, WW = geo.WW, G = geo.G, maxm = geo.maxm;
-    const int g = lane / WW, j = lane - g * WW;
-    const bool act = g < G;
-    const int blk = wave * G + g, y0 = blk * R;
-    const bool hasl = j > 0, hasr = j + 1 < WW;
-    const u64 vm = act ? valid_mask(j, W) : 0ull;
-    constexpr int NP = (R + 2) / 2;
-    constexpr int LO = -(NS / 2);
-    if (tid < 16) misc[tid] = 0;     // [0] Euler sum, [1..3] jumping flags, [4] roots, [5] pairs, [6] hand the frame on
-    mb_cnt[tid] = 0;
-    const int64_t fo = (int64_t)n * H * WW;
-    u64 Bw[R + 2];
-    u32 wbp[NP];
-    u32 lm, rm;
-    // ================================ band plane ====================================================================
     {
-        const u64* M = mask_all + fo;
-        {
-            u64 a[R + NS];                               // source rows y0 - 1 + LO ..; outside the image: ones (ignored)
+        // ---- walk 1: segments of the opened mask (8-connectivity), one {id, first pixel} record per segment -------------
+        u64 pm[SG_KO];
+        u32 sid[SG_KO];
 #pragma unroll
-            for (int t = 0; t < R + NS; ++t) {
-                const int ys = y0 - 1 + LO + t;
-                a[t] = (act && ys >= 0 && ys < H) ? (M[(int64_t)ys * WW + j] | ~vm) : ~0ull;
-            }
-            vwin<NS, R + NS, true>(a);                   // a[t] = rows of the window of tile row t, t = 0 .. R
-#pragma unroll
-            for (int t = 0; t <= R; ++t) Bw[t] = hwin<NS, true>(a[t], hasl, hasr);
-        }
-#pragma unroll
-        for (int t = 0; t <= R; ++t) {
-            const int y = y0 - 1 + t;
-            const u64 mc = (act && y >= 0 && y < H) ? M[(int64_t)y * WW + j] : 0ull;
-            Bw[t] = mc & ~Bw[t] & vm;                    // :171-174  maxima = mask & (window holds a 0)
-        }
-        Bw[R + 1] = 0;
-    }
-    {
-        u32 mym = 0, myl = 0;
-#pragma unroll
-        for (int t = 0; t <= R + 1; ++t) { mym |= (u32)(Bw[t] >> 63) << t; myl |= ((u32)Bw[t] & 1u) << t; }
-        lm = dpp_shr1(mym); rm = dpp_shl1(myl);
-        if (!hasl) lm = 0;
-        if (!hasr) rm = 0;
-    }
-    __syncthreads();                                     // misc / mailbox cleared
-    if (geo.stop == 1) return;
-    u32 total, ncomp;
-    if (const int why = stage_label<R, 0>(Bw, lm, rm, wbp, P, rowb, accb, tmp, misc, geo, y0, j, act, total, ncomp)) {
-        if (tid == 0) slow_flag[n] = (u32)why;           // (the value says why: vbs_stage_tables)
-        return;
-    }
-    if (geo.stop && geo.stop < 10) return;
-    {
-        // ---- D (band): count, sum x, sum y (center_of_mass :181) ------------------------------------------------
-        u32* acnt = reinterpret_cast<u32*>(accb);                                        // [maxm]
-        u64* asx = reinterpret_cast<u64*>(accb + 8 * ((maxm + 1) / 2));                   // [maxm]
-        u64* asy = asx + maxm;                                                           // [maxm]
-        for (u32 c = tid; c < ncomp; c += ST_NT) { acnt[c] = 0; asx[c] = 0; asy[c] = 0; }
-        __syncthreads();
-        BandEntry e0 = {0, 0, 0, 0}, e1 = {0, 0, 0, 0};
+        for (int k = 0; k < SG_KO; ++k) { pm[k] = 0; sid[k] = 0; }
+        u32 nseg = 0, la = NONE16, lb = NONE16, p63 = NONE16, prs0 = NONE16;
+        bool fail = false;
 #pragma unroll
         for (int t = 1; t <= R; ++t) {
             const u64 B = Bw[t];
-            if (!__any(B != 0ull)) continue;
-            if (B) {
-                const u64 stB = ccl_starts(B, (lm >> t) & 1u);
-                const u32 bc = WB(t), y = (u32)(y0 + t - 1);
-                u64 mB = B;
-                bool firstrun = true;
-                while (mB) {
-                    const u64 lowbit = mB & (~mB + 1ull);
-                    const u64 t2 = mB + lowbit;
-                    const u64 gg = mB & ~t2;
-                    mB &= t2;
-                    const u32 cid = P[bc + (u32)__popcll(stB & ((lowbit << 1) - 1ull)) - 1u] & 0x7FFFu;
-                    const u32 len = (u32)__popcll(gg), x0 = 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
-                    const u32 sx = len * x0 + len * (len - 1) / 2;
-                    if (firstrun) {
-                        if (e0.cid != cid) { band_flush(e0, acnt, asx, asy); e0.cid = cid; }
-                        e0.cnt += len; e0.sx += sx; e0.sy += len * y;
-                    } else {
-                        if (e1.cid != cid) { band_flush(e1, acnt, asx, asy); e1.cid = cid; }
-                        e1.cnt += len; e1.sx += sx; e1.sy += len * y;
+            bool live = false;
+#pragma unroll
+            for (int k = 0; k < SG_KO; ++k) live |= pm[k] != 0ull;
+            if (!__any(B != 0ull || live)) { p63 = NONE16; prs0 = NONE16; continue; }
+            const u64 rB = brev64(B);
+            u64 Rn[SG_KO];
+            const u64 claimed = seg_update<SG_KO, true, true>(B, rB, pm, sid, Rn, Q);
+#pragma unroll
+            for (int k = 0; k < SG_KO; ++k) pm[k] = Rn[k];
+            u64 N = B & ~claimed;
+            while (N) {
+                const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                N &= t2;
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < SG_KO; ++k) {
+                    if (!done && pm[k] == 0ull) {
+                        if (nseg < SG_SEGMAX) {
+                            sid[k] = sbase + nseg; P[sbase + nseg] = (unsigned short)(sbase + nseg);
+                            const int r = atomicAdd(&misc[4], 1);
+                            if (r < SG_REC) {
+                                rec_sid[r] = (unsigned short)(sbase + nseg);
+                                rec_pos[r] = (u32)(y0 + t - 1) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
+                            } else fail = true;
+                        } else fail = true;
+                        ++nseg;
+                        pm[k] = gg;
+                        done = true;
                     }
-                    firstrun = false;
                 }
+                if (!done) fail = true;
             }
+            seg_hlinks<SG_KO, true>(pm, sid, hasr, p63, prs0, la, lb, Q);
         }
-        band_flush(e0, acnt, asx, asy);
-        band_flush(e1, acnt, asx, asy);
+#pragma unroll
+        for (int k = 0; k < SG_KO; ++k)
+            if (act) { bot_mask[(size_t)k * NBW + bj] = pm[k]; bot_sid[(size_t)k * NBW + bj] = (unsigned short)sid[k]; }
+        if (fail) misc[6] = SLOW_SLOTS;
         __syncthreads();
-        // the sums go out; the probe requests (2x2 pixel cell around every centroid) go to the segments that own the pixels
-        u64* bs = band_sums + (int64_t)n * maxm * 4;
-        unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
-        for (u32 c = tid; c < ncomp; c += ST_NT) {
-            const u32 cn_ = acnt[c];
-            const u64 sx = asx[c], sy = asy[c];
-            bs[c * 4 + 0] = cn_; bs[c * 4 + 1] = sx; bs[c * 4 + 2] = sy;
-            const double cn = (double)cn_;
-            const float xf = (float)((double)sx / cn), yf = (float)((double)sy / cn);
-            const int ix = (int)floorf(xf), iy = (int)floorf(yf);
+        if (misc[6]) { if (tid == 0) slow_flag[n] = 16u + (u32)misc[6]; return; }
+        if (geo.stop == 12) return;
+        // first row of the tile against the last row of the tile above, with the diagonal neighbours across the word edges
+        if (hasu && Bw[1]) {
+            u64 N = Bw[1];
+            u32 i = 0;
+            while (N) {
+                const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                N &= t2;
+                const u64 ga = gg | (gg << 1) | (gg >> 1);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int px = ix + (q & 1), py = iy + (q >> 1);
-                if (px < 0 || py < 0 || px >= W || py >= H) { pr[c * 4 + q] = (unsigned short)NONE16; continue; }
-                // one request per row and word: the pixel (ix + 1, py) rides along when it lies in the same word
-                const bool pair = (q & 1) == 0 && px + 1 < W && (px & 63) != 63;
-                if ((q & 1) && px > 0 && (px & 63) != 0) continue;                   // rode along with (ix, py)
-                const int ob = py / R, oi = py - ob * R + 1, ow = ob / G, og = ob - ow * G;
-                const int owner = ow * 64 + og * WW + (px >> 6);
-                const u32 slot = atomicAdd(&mb_cnt[owner], 1u);
-                if (slot < ST_MB_CAP)
-                    mb_req[owner * ST_MB_CAP + slot] = c | ((u32)q << 10) | ((u32)oi << 12) | ((u32)(px & 63) << 17) | ((u32)pair << 23);
-                else misc[6] = 1;
+                for (int k = 0; k < SG_KO; ++k) {
+                    if (ga & bot_mask[(size_t)k * NBW + bj - WW]) pq_push(Q, sbase + i, bot_sid[(size_t)k * NBW + bj - WW]);
+                    if ((gg & 1ull) && hasl && (bot_mask[(size_t)k * NBW + bj - WW - 1] >> 63))
+                        pq_push(Q, sbase + i, bot_sid[(size_t)k * NBW + bj - WW - 1]);
+                    if ((gg >> 63) && hasr && (bot_mask[(size_t)k * NBW + bj - WW + 1] & 1ull))
+                        pq_push(Q, sbase + i, bot_sid[(size_t)k * NBW + bj - WW + 1]);
+                }
+                ++i;
             }
         }
-        if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; }
+        __syncthreads();
+        if (geo.stop == 13) return;
+        const u32 nrec = (u32)misc[4];
+        ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, comp_pos, cidmap, tmp,
+                            min((u32)maxm, (u32)CCL_OPEN_COMPS), Q);
+        if (misc[5] > SG_PQ) { if (tid == 0) slow_flag[n] = 16u + SLOW_SLOTS; return; }
+        if (ncomp == NONE32) { if (tid == 0) slow_flag[n] = 16u + SLOW_NCOMP; return; }
+        if ((int)ncomp - misc[0] / 4 != 0) {             // holes: RETR_EXTERNAL needs the fill passes of the general path
+            if (tid == 0) slow_flag[n] = 16u + SLOW_HOLES;
+            return;
+        }
     }
-    __syncthreads();
-    if (misc[6]) {                                       // a crowded mailbox (many tiny band components in one segment)
-        if (tid == 0) slow_flag[n] = 8;
-        return;
-    }
-    if (geo.stop == 10) return;
-    const u32 nband = ncomp;
-    (void)nband;
-
-    // ================================ opened area plane =============================================================
+    if (geo.stop == 14) return;
+    // ---- the component's first pixel (the moments' origin) -------------------------------------------------------------
+    u32* anchor = reinterpret_cast<u32*>(accb);                                          // [CCL_OPEN_COMPS]  (y << 16) | x
+    u64* acc = reinterpret_cast<u64*>(accb + 4 * CCL_OPEN_COMPS);                         // [CCL_MOM_COMPS][NMOM]
     {
-        const u64* A = area_all + fo;
-        u64 a[R + 10];                                   // source rows y0 - 5 .. y0 + R + 4
-#pragma unroll
-        for (int t = 0; t < R + 10; ++t) {
-            const int ys = y0 - 5 + t;
-            a[t] = (act && ys >= 0 && ys < H) ? (A[(int64_t)ys * WW + j] | ~vm) : ~0ull;
-        }
-        vwin<5, R + 10, true>(a);                        // a[t] = 5-row AND about row y0 - 3 + t, t = 0 .. R + 5
-#pragma unroll
-        for (int t = 0; t < R + 6; ++t) {
-            const int ye = y0 - 3 + t;
-            const u64 e = hwin<5, true>(a[t], hasl, hasr);
-            a[t] = (act && ye >= 0 && ye < H) ? (e & vm) : 0ull;         // eroded rows; nothing outside the image
-        }
-        u64 (&d)[R + 10] = a;
-        {   // 5-row OR about row y0 - 1 + t over eroded rows t .. t + 4 (only the first R + 6 entries are eroded rows)
-#pragma unroll
-            for (int t = 0; t + 1 < R + 6; ++t) d[t] |= d[t + 1];
-#pragma unroll
-            for (int t = 0; t + 3 < R + 6; ++t) d[t] |= d[t + 2];
-#pragma unroll
-            for (int t = 0; t + 4 < R + 6; ++t) d[t] |= d[t + 1];
-        }
-#pragma unroll
-        for (int t = 0; t <= R + 1; ++t) {
-            const int y = y0 - 1 + t;
-            const u64 o = hwin<5, false>(d[t], hasl, hasr);
-            Bw[t] = (act && y >= 0 && y < H) ? (o & vm) : 0ull;          // :195  morphologyEx(MORPH_OPEN, 5x5)
+        u32* first = area_first + (int64_t)n * maxm;
+        for (u32 c = tid; c < ncomp; c += ST_NT) {
+            const u32 pos = comp_pos[c], cid = cidmap[c], py = pos / (u32)W;
+            anchor[cid] = (py << 16) | (pos - py * (u32)W);
+            first[cid] = pos;
         }
     }
-    {
-        u32 mym = 0, myl = 0;
-#pragma unroll
-        for (int t = 0; t <= R + 1; ++t) { mym |= (u32)(Bw[t] >> 63) << t; myl |= ((u32)Bw[t] & 1u) << t; }
-        lm = dpp_shr1(mym); rm = dpp_shl1(myl);
-        if (!hasl) lm = 0;
-        if (!hasr) rm = 0;
-    }
-    if (tid < 6) misc[tid] = 0;                          // (not [6]: a late reader of the check above must still see 0)
-    __syncthreads();
-    if (geo.stop == 11) return;
-    if (const int why = stage_label<R, 1>(Bw, lm, rm, wbp, P, rowb, accb, tmp, misc, geo, y0, j, act, total, ncomp)) {
-        if (tid == 0) slow_flag[n] = 16u + (u32)why;
-        return;
-    }
-    if (geo.stop && geo.stop < 20) return;
-
-    // ---- D (open) 0: the component's first pixel = start of its root run (the moments' origin), from the root list ---
-    u32* anchor = reinterpret_cast<u32*>(accb + CCL_MOM_COMPS * NMOM * 8);               // [CCL_OPEN_COMPS]  (y << 16) | x
-    const u32* roots = reinterpret_cast<const u32*>(accb + CCL_MOM_COMPS * NMOM * 8 + CCL_OPEN_COMPS * 4);
-    u32* first = area_first + (int64_t)n * maxm;
-    for (int i = tid; i < misc[4]; i += ST_NT) {
-        const u32 v = P[roots[2 * i]];
-        if (v & 0x8000u) {
-            const u32 pos = roots[2 * i + 1], py = pos / (u32)W;
-            anchor[v & 0x7FFFu] = (py << 16) | (pos - py * (u32)W);
-            first[v & 0x7FFFu] = pos;
-        }
-    }
-    // this segment's probe requests: which of its rows have any
+    // this thread's probe requests: which of its rows have any
     u32 rowmask = 0;
     const u32 nreq = min(mb_cnt[tid], (u32)ST_MB_CAP);
     for (u32 q = 0; q < nreq; ++q) rowmask |= 1u << ((mb_req[tid * ST_MB_CAP + q] >> 12) & 31u);
     unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
-    u64* acc = reinterpret_cast<u64*>(accb);
     i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
-    // ---- D (open) 1: contour-vertex moments, 256 components per pass ---------------------------------------------
+    // ---- walk 2: the same segments again, now with their components: contour-vertex moments, 256 components per pass ----
     for (u32 c0 = 0; c0 < ncomp; c0 += CCL_MOM_COMPS) {
         const u32 nc = min((u32)CCL_MOM_COMPS, ncomp - c0);
         for (u32 c = tid; c < nc * NMOM; c += ST_NT) acc[c] = 0;
         __syncthreads();
-        MomEntry e0, e1;
-        e0.cid = NONE32; e1.cid = NONE32;
+        u64 pm[SG_KO];
+        u32 sid[SG_KO], cidk[SG_KO], anc[SG_KO];
+        MomEntry ent[SG_KO];
 #pragma unroll
-        for (int q = 0; q < 10; ++q) { e0.m[q] = 0; e1.m[q] = 0; }
+        for (int k = 0; k < SG_KO; ++k) {
+            pm[k] = 0; sid[k] = 0; cidk[k] = NONE32; anc[k] = 0;
+#pragma unroll
+            for (int q = 0; q < 10; ++q) ent[k].m[q] = 0;
+        }
+        u32 nseg = 0;
+        u32 why = 0;
 #pragma unroll
         for (int t = 1; t <= R; ++t) {
             const u64 B = Bw[t];
-            if (!__any(B != 0ull || ((rowmask >> t) & 1u))) continue;
-            const u32 pB = (lm >> t) & 1u;
-            const u64 stB = ccl_starts(B, pB);
-            const u32 bc = WB(t);
-            const int y = y0 + t - 1;
+            bool live = false;
+#pragma unroll
+            for (int k = 0; k < SG_KO; ++k) live |= pm[k] != 0ull;
+            if (!__any(B != 0ull || live || ((rowmask >> t) & 1u))) continue;
+            const u64 rB = brev64(B);
+            u64 Rn[SG_KO];
+            const u64 claimed = seg_update<SG_KO, true, false>(B, rB, pm, sid, Rn, Q);
+#pragma unroll
+            for (int k = 0; k < SG_KO; ++k) pm[k] = Rn[k];
+            u64 N = B & ~claimed;
+            while (N) {
+                const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                N &= t2;
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < SG_KO; ++k) {
+                    if (!done && pm[k] == 0ull) {
+                        if (cidk[k] != NONE32) mom_flush(ent[k], cidk[k], acc);
+                        const u32 c = (u32)cidmap[P[sbase + nseg] & 0x7FFFu];
+                        ++nseg;
+                        anc[k] = anchor[c];
+                        cidk[k] = c - c0 < nc ? c - c0 : NONE32;   // (another pass's component)
+                        sid[k] = c;                       // (the replay unites nothing: the slot's component id will do)
+                        pm[k] = gg;
+                        done = true;
+                    }
+                }
+            }
             if (c0 == 0 && ((rowmask >> t) & 1u)) {      // probes: component id of a pixel of this row
                 for (u32 q = 0; q < nreq; ++q) {
                     const u32 rq = mb_req[tid * ST_MB_CAP + q];
                     if (((rq >> 12) & 31u) != (u32)t) continue;
                     const u32 q0 = (rq >> 10) & 3u;
                     for (u32 d = 0; d <= ((rq >> 23) & 1u); ++d) {
-                        const u32 k = ((rq >> 17) & 63u) + d;
+                        const u32 kb = ((rq >> 17) & 63u) + d;
                         u32 cid = NONE16;
-                        if ((B >> k) & 1ull) {
-                            const u64 below = (k == 63) ? ~0ull : ((1ull << (k + 1)) - 1ull);
-                            cid = P[bc + (u32)__popcll(stB & below) - 1u] & 0x7FFFu;
-                        }
+#pragma unroll
+                        for (int k = 0; k < SG_KO; ++k)
+                            if ((pm[k] >> kb) & 1ull) cid = sid[k];
                         pr[(rq & 1023u) * 4 + q0 + d] = (unsigned short)cid;
                     }
                 }
             }
-            if (!B) continue;
+            if (!__any(B != 0ull)) continue;
             // the eight neighbour planes: bit k = the neighbour of pixel k in chain direction d is foreground
+            const u32 pB = (lm >> t) & 1u;
             const u64 An = Bw[t - 1], Sn = Bw[t + 1];
             const u64 D0 = (B >> 1) | ((u64)((rm >> t) & 1u) << 63), D4 = (B << 1) | (u64)pB;
             const u64 D2 = An, D1 = (An >> 1) | ((u64)((rm >> (t - 1)) & 1u) << 63), D3 = (An << 1) | (u64)((lm >> (t - 1)) & 1u);
@@ -540,115 +730,96 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
             const u64 iso = ~(D0 | D1 | D2 | D3 | D4 | D5 | D6 | D7);    // an isolated pixel is written once
             // V1 / V2 / V3: at least one / two / three of the nine planes
             u64 V1 = k0, V2 = 0, V3 = 0;
-#define ADDP(K) { V3 |= V2 & (K); V2 |= V1 & (K); V1 |= (K); }
+#define ADDP(Kp) { V3 |= V2 & (Kp); V2 |= V1 & (Kp); V1 |= (Kp); }
             ADDP(k1) ADDP(k2) ADDP(k3) ADDP(k4) ADDP(k5) ADDP(k6) ADDP(k7) ADDP(iso)
 #undef ADDP
             V1 &= B; V2 &= B; V3 &= B;
-            if (V3) misc[6] = 1;                         // multiplicity > 2: impossible after a 5x5 opening; general path
-            if (!V1) continue;
-            bool firstrun = true;
-            u64 mB = B;
-            while (mB) {
-                const u64 lowbit = mB & (~mB + 1ull);
-                const u64 t2 = mB + lowbit;
-                const u64 gg = mB & ~t2;
-                mB &= t2;
-                u64 vg = gg & V1;
-                if (!vg) continue;
-                const u32 cid = (P[bc + (u32)__popcll(stB & ((lowbit << 1) - 1ull)) - 1u] & 0x7FFFu) - c0;
-                if (cid >= nc) continue;                 // another pass's component
-                const u32 fp = anchor[cid + c0];
-                const int dy = y - (int)(fp >> 16), dx0 = 64 * j - (int)(fp & 0xFFFFu);
-                u64* a = acc + cid * NMOM;
-                if (dx0 >= -150 && dx0 + 63 <= 150 && abs(dy) <= 150) {
-                    // row sums s_a = sum mult dx^a (24-bit multiplies: every factor < 2^23, every product < 2^31)
-                    int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-                    i64 s4 = 0;
-                    while (vg) {
-                        const int k = __ffsll((long long)vg) - 1;
-                        vg &= vg - 1;
-                        const int dx = dx0 + k, sh = (int)((V2 >> k) & 1ull);
-                        const int mx = sh ? 2 * dx : dx, x2 = __mul24(dx, dx), mxx = __mul24(mx, dx);
-                        s0 += 1 << sh; s1 += mx; s2 += mxx; s3 += __mul24(mx, x2);
-                        s4 += (i64)__mul24(mxx, x2);
-                    }
-                    const int dy2 = __mul24(dy, dy), dy3 = __mul24(dy2, dy);
-                    auto apply = [&](MomEntry& e) {
-                        if (e.cid != cid || e.m[0] > 256) { mom_flush(e, acc); e.cid = cid; }
+            if (V3) why = SLOW_VERTEX;                    // multiplicity > 2: impossible after a 5x5 opening; general path
+            const int y = y0 + t - 1;
+#pragma unroll
+            for (int k = 0; k < SG_KO; ++k) {
+                u64 vg = V1 & pm[k];
+                if (!__any(vg != 0ull)) continue;
+                if (vg && cidk[k] != NONE32) {
+                    const u32 fp = anc[k];
+                    const int dy = y - (int)(fp >> 16), dx0 = 64 * j - (int)(fp & 0xFFFFu);
+                    if (dx0 >= -150 && dx0 + 63 <= 150 && abs(dy) <= 150) {
+                        // row sums s_a = sum mult dx^a (24-bit multiplies: every factor < 2^23, every product < 2^31)
+                        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+                        i64 s4 = 0;
+                        while (vg) {
+                            const int kb = __ffsll((long long)vg) - 1;
+                            vg &= vg - 1;
+                            const int dx = dx0 + kb, two = (int)((V2 >> kb) & 1ull);
+                            const int mx = two ? 2 * dx : dx, x2 = __mul24(dx, dx), mxx = __mul24(mx, dx);
+                            s0 += 1 + two; s1 += mx; s2 += mxx; s3 += __mul24(mx, x2);
+                            s4 += (i64)__mul24(mxx, x2);
+                        }
+                        const int dy2 = __mul24(dy, dy), dy3 = __mul24(dy2, dy);
+                        MomEntry& e = ent[k];
+                        if (e.m[0] > 256) mom_flush(e, cidk[k], acc);           // (orders <= 3 stay below 2^31)
                         e.m[0] += s0;                  e.m[1] += s1;                  e.m[2] += __mul24(s0, dy);
                         e.m[3] += s2;                  e.m[4] += __mul24(s1, dy);     e.m[5] += __mul24(s0, dy2);
                         e.m[6] += s3;                  e.m[7] += __mul24(s2, dy);     e.m[8] += __mul24(s1, dy2);
                         e.m[9] += __mul24(s0, dy3);
-                    };
-                    if (firstrun) apply(e0); else apply(e1);
-                    atomicAdd(&a[10], (u64)s4);
-                    if (dy) {
-                        atomicAdd(&a[11], (u64)((i64)s3 * dy));
-                        atomicAdd(&a[12], (u64)((i64)s2 * dy2));
-                        atomicAdd(&a[13], (u64)((i64)s1 * dy3));
-                        atomicAdd(&a[14], (u64)((i64)__mul24(s0, dy2) * dy2));
-                    }
-                } else {
-                    while (vg) {                         // a large component: 64-bit terms, one vertex at a time
-                        const int k = __ffsll((long long)vg) - 1;
-                        vg &= vg - 1;
-                        const i64 ml_ = 1 + (i64)((V2 >> k) & 1ull), dl_ = dx0 + k, el_ = dy, x2 = dl_ * dl_, y2 = el_ * el_;
-                        atomicAdd(&a[0], (u64)ml_);
-                        atomicAdd(&a[1], (u64)(ml_ * dl_));             atomicAdd(&a[2], (u64)(ml_ * el_));
-                        atomicAdd(&a[3], (u64)(ml_ * x2));              atomicAdd(&a[4], (u64)(ml_ * dl_ * el_));
-                        atomicAdd(&a[5], (u64)(ml_ * y2));              atomicAdd(&a[6], (u64)(ml_ * x2 * dl_));
-                        atomicAdd(&a[7], (u64)(ml_ * x2 * el_));        atomicAdd(&a[8], (u64)(ml_ * dl_ * y2));
-                        atomicAdd(&a[9], (u64)(ml_ * y2 * el_));        atomicAdd(&a[10], (u64)(ml_ * x2 * x2));
-                        atomicAdd(&a[11], (u64)(ml_ * x2 * dl_ * el_)); atomicAdd(&a[12], (u64)(ml_ * x2 * y2));
-                        atomicAdd(&a[13], (u64)(ml_ * dl_ * el_ * y2)); atomicAdd(&a[14], (u64)(ml_ * y2 * y2));
+                        u64* a = acc + cidk[k] * NMOM;
+                        atomicAdd(&a[10], (u64)s4);
+                        if (dy) {
+                            atomicAdd(&a[11], (u64)((i64)s3 * dy));
+                            atomicAdd(&a[12], (u64)((i64)s2 * dy2));
+                            atomicAdd(&a[13], (u64)((i64)s1 * dy3));
+                            atomicAdd(&a[14], (u64)((i64)__mul24(s0, dy2) * dy2));
+                        }
+                    } else {
+                        why = SLOW_LARGE;
                     }
                 }
-                firstrun = false;
             }
         }
-        mom_flush(e0, acc);
-        mom_flush(e1, acc);
+#pragma unroll
+        for (int k = 0; k < SG_KO; ++k)
+            if (cidk[k] != NONE32) mom_flush(ent[k], cidk[k], acc);
+        if (why) misc[6] = (int)why;
         __syncthreads();
         for (u32 c = tid; c < nc * NMOM; c += ST_NT) as[(c0 + c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
         __syncthreads();
     }
-    if (misc[6]) {                                       // (set before the last barrier above by whoever saw it)
-        if (tid == 0) slow_flag[n] = 9;
-        return;
-    }
+    if (misc[6]) { if (tid == 0) slow_flag[n] = 16u + (u32)misc[6]; return; }
     if (tid == 0) { ncomp_all[n * 2 + 1] = ncomp; fstat[n * 8 + 6] = ncomp; fstat[n * 8 + 4] = 0; }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-// rows per segment the kernel is compiled for; 0 = geometry outside the fused path (the round-2 kernels take it)
+// rows per thread the kernel is compiled for; 0 = geometry outside the fused path (the round-2 kernels take it)
 static int stage_rows(const vbs_handle* h, StageGeom* g, size_t* lds_bytes) {
     if (h->WW > 32) return 0;
     const int G = 64 / h->WW, NB = 16 * G;
     const int need = (h->H + NB - 1) / NB;
-    const int R = need <= 6 ? 6 : need <= 12 ? 12 : need <= 22 ? 22 : 0;
+    const bool ns14 = h->bp.ns == 14;
+    // (a block's windows must not reach past the neighbouring block: R >= 7 for the 14-row window, >= 5 for the opening)
+    const int R = (need <= 6 && !ns14) ? 6 : need <= 12 ? 12 : need <= 22 ? 22 : 0;
     if (!R || h->W > 4096 || h->H > 2048 || h->maxm > 1024) return 0;
     g->H = h->H; g->W = h->W; g->WW = h->WW; g->G = G; g->NB = NB; g->maxm = h->maxm;
     g->stop = VBS_KNOB("VBS_STAGE_STOP");
-    const size_t rowb = ((size_t)(NB * R + 2) * 2 + 15) / 16 * 16;
-    const size_t acc_band = ((size_t)(8 * ((h->maxm + 1) / 2)) + 16 * (size_t)h->maxm + 15) / 16 * 16;
-    const size_t acc_open = (size_t)CCL_MOM_COMPS * NMOM * 8 + (size_t)CCL_OPEN_COMPS * 4 + (size_t)CCL_ROOT_LIST * 8;
-    const size_t acc = acc_band > acc_open ? acc_band : acc_open;
-    const size_t mb = (size_t)ST_NT * 4 * (1 + ST_MB_CAP);
+    const size_t NBW = (size_t)NB * h->WW;
+    auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
+    const size_t exch = up16((size_t)(h->bp.ns - 1 > 10 ? h->bp.ns - 1 : 10) * NBW * 8);
+    const size_t par = up16((size_t)ST_NT * SG_SEGMAX * 2);
+    const size_t rec = up16((size_t)SG_REC * 18);
+    const size_t bot = up16((size_t)SG_KB * NBW * 10);
+    const size_t acc_band = up16((size_t)(8 * ((h->maxm + 1) / 2)) + 16 * (size_t)h->maxm);
+    const size_t acc_open = up16((size_t)4 * CCL_OPEN_COMPS + (size_t)CCL_MOM_COMPS * NMOM * 8);
+    const size_t comp = 4096 + 2048 + (acc_band > acc_open ? acc_band : acc_open);
+    const size_t botc = bot > comp ? bot : comp;
+    const size_t x = exch > par + rec + botc ? exch : par + rec + botc;      // the exchange rows and the tables share a region
+    const size_t mb = (size_t)ST_NT * 4 * (1 + ST_MB_CAP), pq = (size_t)SG_PQ * 4;
     const size_t misc = 32 * 4 + 16 * 4;
-    const size_t fixed = rowb + acc + mb + misc;
-    const size_t full = 160 * 1024;
-    if (fixed + 4096 > full) return 0;
-    size_t cap = (full - fixed) / 2 / 8 * 8;
-    if (cap > CCL_NODE_MAX) cap = CCL_NODE_MAX / 8 * 8;
-    const size_t want = (size_t)h->H * h->W / 24;        // far above a marker frame's runs (1280x1024: band 13.9 k)
-    if (cap > want && want >= 4096) cap = want / 8 * 8;
-    g->node_cap = (u32)cap;
-    g->off_rowb = (u32)(2 * cap);
-    g->off_acc = (u32)(g->off_rowb + rowb);
-    g->off_mb = (u32)(g->off_acc + acc);
-    g->off_tmp = (u32)(g->off_mb + mb);
-    g->pair_cap = (u32)((size_t)CCL_MOM_COMPS * NMOM * 8 / 4);     // the list borrows the moment accumulators' area
-    *lds_bytes = g->off_tmp + misc;
+    g->off_rec = (u32)par;
+    g->off_bot = (u32)(par + rec);
+    g->off_pq = (u32)x;
+    g->off_mb = (u32)(x + pq);
+    g->off_tmp = (u32)(x + pq + mb);
+    *lds_bytes = x + pq + mb + misc;
+    if (*lds_bytes > 160 * 1024) return 0;
     return R;
 }
 
@@ -681,7 +852,7 @@ bool launch_stage(vbs_handle* h, int nb, hipStream_t s) {
     if (!R) return false;
     const bool ns14 = h->bp.ns == 14;
     switch (R) {
-        case 6: return ns14 ? stage_launch_t<6, 14>(h, nb, g, lds, s) : stage_launch_t<6, 8>(h, nb, g, lds, s);
+        case 6: return stage_launch_t<6, 8>(h, nb, g, lds, s);
         case 12: return ns14 ? stage_launch_t<12, 14>(h, nb, g, lds, s) : stage_launch_t<12, 8>(h, nb, g, lds, s);
         default: return ns14 ? stage_launch_t<22, 14>(h, nb, g, lds, s) : stage_launch_t<22, 8>(h, nb, g, lds, s);
     }
