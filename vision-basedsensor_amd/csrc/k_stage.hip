@@ -1,46 +1,43 @@
 // a9-a13, fused fast path (marker_detection.py:170-196): band = mask & ~erode(mask) and the 5x5 opening of the area
 // mask, the connected components of both (4- / 8-connectivity) and the per-component sums k_finalize needs, in ONE
 // kernel per pass, one workgroup of 1024 threads per frame.  Nothing but the two input bit planes is read from memory
-// (every row once) and neither the band / opened planes nor any list of pixels or runs is written: a frame's planes
-// live in the registers of its workgroup.
+// and neither the band / opened planes nor any list of pixels or runs is written.
 //
-// A thread owns a SEGMENT OF A WORD COLUMN: word column j (64 px) x R consecutive rows (R = 22 at 1280x1024: 2 VGPRs
-// per row).  A wave holds G = 64 / WW row blocks side by side (lane = g * WW + j): the words left and right of a lane's
-// word are in the neighbouring lanes (DPP moves), the rows above / below it are its own registers.  Every pass over the
-// rows is unrolled.
-//   morph   the rows of the neighbouring row blocks that a block's windows reach come through LDS (each thread publishes
-//           its first / last rows once).  The rows stream through register delay lines (vertical 14- / 5-row AND / OR by
-//           doubling: 2, 4, 8, 14 rows); results lag their sources, so they overwrite the tile in place.  The horizontal
-//           windows work on 64-bit words by doubling with the neighbour lane's word (v_alignbit funnel shifts).
-//   label   NOT run by run: a thread labels its own 64 x R tile in registers.  It keeps up to K "slots"; a slot is a
-//           tile-local piece of a component ("segment") = the mask of its pixels in the previous row.  The pixels of a
-//           segment in the next row are the runs that touch that mask, found for all runs at once with two carry chains
-//           (add the seeds to the row: the carry fills each run upwards from its lowest seed; the same on the reversed
-//           word fills downwards).  Runs no slot reaches start new segments.  Only what crosses a tile goes through the
-//           union-find in LDS (uint16 parents over <= 8 segments per thread): two segments that meet in a run, the
+// A thread owns a SEGMENT OF A WORD COLUMN: word column j (64 px) x R consecutive rows (R = 22 at 1280x1024), and streams
+// down it: a row is loaded (a few rows ahead), passes through register delay lines and is labelled and summed on the spot;
+// no plane is ever held.  A wave holds G = 64 / WW row blocks side by side (lane = g * WW + j): the words left and right
+// of a lane's word are in the neighbouring lanes (DPP moves).  One rolled loop per plane.
+//   morph   vertical 14- / 5-row AND / OR by doubling (2, 4, 8, 14 rows) in the delay lines; a thread simply starts a
+//           window's reach above its first row and runs that far past its last one.  The horizontal windows work on 64-bit
+//           words by doubling with the neighbour lane's word (v_alignbit funnel shifts).
+//   label   NOT run by run: a thread labels its own 64 x R tile.  It keeps up to K "slots"; a slot is a tile-local piece
+//           of a component ("segment") = the mask of its pixels in the previous row.  The pixels of a segment in the next
+//           row are the runs that touch that mask, found for all runs at once with two carry chains (add the seeds to the
+//           row: the carry fills each run upwards from its lowest seed; the same on the reversed word fills downwards).
+//           Runs no slot reaches start new segments.  Only what crosses a tile goes through the union-find in LDS (uint16
+//           parents over <= 8 segments per thread), and only as a queued pair: two segments that meet in a run, the
 //           segment holding bit 63 of a row with the one holding bit 0 of the word to the right (ids by DPP;
-//           8-connectivity: also the rows above / below), and after the walk the first row of a tile with the last row
-//           of the tile above.
-//   sums    band: count / sum x / sum y per slot in registers (sum of bit positions by six masked popcounts), one record
-//           per segment; records -> components once the union-find is resolved.
-//           open: the labelling walk is replayed once the components and their first pixels are known;
-//           CHAIN_APPROX_SIMPLE vertex multiplicity BIT-PARALLEL (the 256-entry table as boolean functions of the eight
-//           shifted neighbour planes: an arc of background neighbours that starts at direction a counts unless it has no
-//           4-neighbour or is exactly {a, a+1, a+2}), so only real vertices are visited; per slot and row
-//           s_a = sum mult dx^a, the 15 moments as s_a dy^b: orders 0-3 in registers until the slot is reused, order 4
-//           by LDS atomics per row
+//           8-connectivity: also the rows above / below), and after the walk the first row of a tile with the last row of
+//           the tile above.  The unions run densely after the walk.
+//   sums    per slot in registers, one record per segment, records -> components once the union-find is resolved.
+//           band: count / sum x / sum y (sum of bit positions by six masked popcounts).
+//           open: CHAIN_APPROX_SIMPLE vertex multiplicity BIT-PARALLEL (the 256-entry table as boolean functions of the
+//           eight shifted neighbour planes: an arc of background neighbours that starts at direction a counts unless it has
+//           no 4-neighbour or is exactly {a, a+1, a+2}), so only real vertices are visited; the 15 moments up to order 4
+//           about the TILE'S CENTRE (small numbers: int32), as s_a t^b from the row sums s_a = sum mult dx^a; a dense pass
+//           shifts every record to its component's first pixel (exact, int64) and adds it to the component.
 //   order   components are ranked by their first pixel (ndimage.label's order; reversed: cv2.findContours')
-//   probes  component ids of the 2x2 pixel cell around every band centroid, answered during the replay by the thread
-//           that owns the pixel (requests posted through a small LDS mailbox)
-// Frames the fast path cannot take (more than K segments alive in a tile or 8 in all, too many records / components, a
-// component that reaches more than 150 px from its first pixel, holes in the opened mask, a vertex of multiplicity > 2,
-// a crowded mailbox) set their slow flag (the value says why): k_morph and k_label (k_label.hip) redo them.
+//   probes  component ids of the 2x2 pixel cell around every band centroid: the thread that owns the pixel notes the
+//           segment that holds it (requests posted through a small LDS mailbox); ids follow once the components are known
+// Frames the fast path cannot take (more than K segments alive in a tile or 8 in all, too many records / pairs /
+// components, holes in the opened mask, a vertex of multiplicity > 2, a crowded mailbox) set their slow flag (the value
+// says why): k_morph and k_label (k_label.hip) redo them.
 #include "ccl_common.h"
 
 #define ST_NT 1024
 #define ST_MB_CAP 8                // probe requests a thread can hold (one per centroid, row and word)
 #define SG_KB 4                    // slots of the band walk (a ring crosses a tile as two arcs)
-#define SG_KO 3                    // slots of the opened-mask walks
+#define SG_KO 2                    // slots of the opened-mask walk
 #define SG_SEGMAX 8                // segments a thread can start; segment id = 8 tid + i
 #define SG_REC 2048                // segment records per frame
 #define SG_PQ 4096                 // segment pairs waiting to be united
@@ -51,11 +48,11 @@
 #define SLOW_MAILBOX 3
 #define SLOW_HOLES 4
 #define SLOW_VERTEX 5              // a contour vertex of multiplicity > 2
-#define SLOW_LARGE 6               // a component reaches more than 150 px from its first pixel
 
 struct StageGeom {
-    int H, W, WW, G, NB, maxm;      // G row blocks per wave, NB = 16 G row blocks of R rows
-    u32 off_rec, off_bot, off_pq, off_mb, off_tmp;       // byte offsets into the dynamic LDS (parents / row exchange at 0)
+    int H, W, WW, G, NB, R, maxm;   // G row blocks per wave, NB = 16 G row blocks of R rows
+    u32 off_rec, off_bot, off_pq, off_mb, off_tmp;       // byte offsets into the dynamic LDS (segment parents at 0)
+    u32 mrec_cap, mrec_stride;      // moment records per frame (global scratch), dwords between two frames' records
     int stop;                       // debug builds: leave after phase `stop`
 };
 
@@ -232,48 +229,62 @@ __device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nse
     return ncomp;
 }
 
-struct MomEntry { int m[10]; };                          // moments of order 0 - 3 about the component's first pixel
-
-__device__ __forceinline__ void mom_flush(MomEntry& e, u32 cid, u64* acc) {
-    if (e.m[0]) {
-        u64* a = acc + cid * NMOM;
-#pragma unroll
-        for (int q = 0; q < 10; ++q)
-            if (e.m[q]) atomicAdd(&a[q], (u64)(i64)e.m[q]);
-    }
-#pragma unroll
-    for (int q = 0; q < 10; ++q) e.m[q] = 0;
+// exact shift of the moments m[a][b] (a + b <= 4, about the point o) to the point o - (dx, dy): sum (x + dx)^a (y + dy)^b
+__device__ __forceinline__ void shift_moments_i64(const i64 (&m)[NMOM], i64 dx, i64 dy, i64 (&out)[NMOM]) {
+    // index of (a, b): 0:(0,0) 1:(1,0) 2:(0,1) 3:(2,0) 4:(1,1) 5:(0,2) 6:(3,0) 7:(2,1) 8:(1,2) 9:(0,3) 10:(4,0) 11:(3,1) 12:(2,2) 13:(1,3) 14:(0,4)
+    const i64 dx2 = dx * dx, dx3 = dx2 * dx, dx4 = dx2 * dx2, dy2 = dy * dy, dy3 = dy2 * dy, dy4 = dy2 * dy2;
+    // x first: T[a][k] = sum_i C(a,i) dx^(a-i) m[i][k]
+    const i64 T00 = m[0], T01 = m[2], T02 = m[5], T03 = m[9], T04 = m[14];
+    const i64 T10 = m[1] + dx * m[0], T11 = m[4] + dx * m[2], T12 = m[8] + dx * m[5], T13 = m[13] + dx * m[9];
+    const i64 T20 = m[3] + 2 * dx * m[1] + dx2 * m[0], T21 = m[7] + 2 * dx * m[4] + dx2 * m[2], T22 = m[12] + 2 * dx * m[8] + dx2 * m[5];
+    const i64 T30 = m[6] + 3 * dx * m[3] + 3 * dx2 * m[1] + dx3 * m[0], T31 = m[11] + 3 * dx * m[7] + 3 * dx2 * m[4] + dx3 * m[2];
+    const i64 T40 = m[10] + 4 * dx * m[6] + 6 * dx2 * m[3] + 4 * dx3 * m[1] + dx4 * m[0];
+    // then y: out[a][b] = sum_k C(b,k) dy^(b-k) T[a][k]
+    out[0] = T00;
+    out[1] = T10;
+    out[2] = T01 + dy * T00;
+    out[3] = T20;
+    out[4] = T11 + dy * T10;
+    out[5] = T02 + 2 * dy * T01 + dy2 * T00;
+    out[6] = T30;
+    out[7] = T21 + dy * T20;
+    out[8] = T12 + 2 * dy * T11 + dy2 * T10;
+    out[9] = T03 + 3 * dy * T02 + 3 * dy2 * T01 + dy3 * T00;
+    out[10] = T40;
+    out[11] = T31 + dy * T30;
+    out[12] = T22 + 2 * dy * T21 + dy2 * T20;
+    out[13] = T13 + 3 * dy * T12 + 3 * dy2 * T11 + dy3 * T10;
+    out[14] = T04 + 4 * dy * T03 + 6 * dy2 * T02 + 4 * dy3 * T01 + dy4 * T00;
 }
 
-template <int R, int NS>
+template <int NS>
 __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask_all, const u64* __restrict__ area_all,
                                                     u32* __restrict__ ncomp_all, u64* __restrict__ band_sums,
                                                     u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                     unsigned short* __restrict__ probe_all, u32* __restrict__ fstat,
-                                                    u32* __restrict__ slow_flag, StageGeom geo) {
+                                                    u32* __restrict__ slow_flag, u32* __restrict__ mrec_all, StageGeom geo) {
     extern __shared__ __align__(16) unsigned char smem[];
-    u64* hx = reinterpret_cast<u64*>(smem);                                               // row exchange of the morph steps
     unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [8 ST_NT] segment parents
     unsigned char* recb = smem + geo.off_rec;                                            // segment records
     unsigned char* botb = smem + geo.off_bot;                                            // last-row slots | component tables
-    u32* mb_cnt = reinterpret_cast<u32*>(smem + geo.off_mb);                              // [ST_NT] probe requests
-    u32* mb_req = mb_cnt + ST_NT;                                                         // [ST_NT][ST_MB_CAP]
     PairQ Q;
     Q.q = reinterpret_cast<u32*>(smem + geo.off_pq);                                      // [SG_PQ]
+    u32* mb_cnt = reinterpret_cast<u32*>(smem + geo.off_mb);                              // [ST_NT] probe requests
+    u32* mb_req = mb_cnt + ST_NT;                                                         // [ST_NT][ST_MB_CAP]
     u32* tmp = reinterpret_cast<u32*>(smem + geo.off_tmp);                                // [32]
     int* misc = reinterpret_cast<int*>(tmp + 32);                                         // [16]
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int H = geo.H, W = geo.W, WW = geo.WW, G = geo.G, maxm = geo.maxm;
+    const int H = geo.H, W = geo.W, WW = geo.WW, G = geo.G, R = geo.R, maxm = geo.maxm;
     const int g = lane / WW, j = lane - g * WW;
     const bool act = g < G;
     const int blk = wave * G + g, y0 = blk * R;
     const bool hasl = j > 0, hasr = act && j + 1 < WW;
     const u64 vm = act ? valid_mask(j, W) : 0ull;
     const int NBW = geo.NB * WW, bj = act ? blk * WW + j : 0;
-    const bool hasu = act && blk > 0, hasd = act && blk + 1 < geo.NB;
+    const bool hasu = act && blk > 0;
     const u32 sbase = (u32)tid * SG_SEGMAX;
     Q.n = &misc[5];
-    if (tid < 16) misc[tid] = 0;     // [0] Euler sum, [4] records, [5] queued pairs, [6] hand the frame on (why)
+    if (tid < 16) misc[tid] = 0;     // [0] Euler sum, [4] records, [5] queued pairs, [6] hand the frame on (why), [7] moment records
     mb_cnt[tid] = 0;
     const int64_t fo = (int64_t)n * H * WW;
     unsigned short* rec_sid = reinterpret_cast<unsigned short*>(recb);                   // [SG_REC] records, by column
@@ -287,34 +298,53 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
     u32* comp_pos = reinterpret_cast<u32*>(botb);                                         // [1024] first pixel of a component
     unsigned short* cidmap = reinterpret_cast<unsigned short*>(botb + 4096);              // [1024] its rank = component id
     unsigned char* accb = botb + 4096 + 2048;                                            // band sums | anchors + moments
-    u64 Bw[R + 2];
+    __syncthreads();
 
     // ================================ band plane ====================================================================
     {
         constexpr int NA = NS / 2, NBL = NS / 2 - 1;     // rows of the window above / below its row
         const u64* M = mask_all + fo;
+        // rows in flight: RAW loads (nothing touches a loaded value before its step, so the wait for it sits there, four
+        // steps after the load was issued); rows outside the image are loaded from a clamped address and replaced at use
+        auto ldraw = [&](int r) -> u64 {
+            const int y = min(max(y0 + r, 0), H - 1);
+            return M[(int64_t)y * WW + (act ? j : 0)];
+        };
+        auto rowval = [&](u64 raw, int r) -> u64 {       // source row y0 + r; outside the image: ones (ignored by the erosion)
+            const int y = y0 + r;
+            return (act && y >= 0 && y < H) ? (raw | ~vm) : ~0ull;
+        };
+        u64 pf[4];
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const int y = y0 + t;
-            Bw[t] = (act && y < H) ? (M[(int64_t)y * WW + j] | ~vm) : ~0ull;    // outside the image: ones (ignored)
-        }
-        if (act) {                                       // what the neighbouring row blocks' windows reach
+        for (int i = 0; i < 4; ++i) pf[i] = ldraw(-NA + i);
+        u64 cr[NBL + 1];                                 // the last NBL + 1 source rows (the window's own row is NBL back)
 #pragma unroll
-            for (int k = 0; k < NA; ++k) hx[(size_t)k * NBW + bj] = Bw[R - NA + k];
-#pragma unroll
-            for (int k = 0; k < NBL; ++k) hx[(size_t)(NA + k) * NBW + bj] = Bw[k];
-        }
-        __syncthreads();
-        // the rows stream through the delay lines: h1 = the row before, a2[i] = AND of 2 rows ending i + 1 rows back, ..
+        for (int i = 0; i <= NBL; ++i) cr[i] = ~0ull;
+        // delay lines: h1 = the row before, a2[i] = AND of the 2 rows ending i + 1 rows back, a4 / a8 likewise
         u64 h1 = ~0ull, a2[2] = {~0ull, ~0ull}, a4[4] = {~0ull, ~0ull, ~0ull, ~0ull};
         u64 a8[6] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
+        u64 pm[SG_KB];
+        u32 sid[SG_KB], cnt[SG_KB], sy[SG_KB], sk[SG_KB], pos[SG_KB];
 #pragma unroll
+        for (int k = 0; k < SG_KB; ++k) { pm[k] = 0; sid[k] = 0; cnt[k] = 0; sy[k] = 0; sk[k] = 0; pos[k] = 0; }
+        u32 nseg = 0, la = NONE16, lb = NONE16, p63 = NONE16, prs0 = NONE16;
+        bool fail = false;
+        u64 firstB = 0;
+        auto emit = [&](u32 sid_, u32 pos_, u32 cnt_, u32 sk_, u32 sy_) {
+            const int r = atomicAdd(&misc[4], 1);
+            if (r < SG_REC) {
+                rec_sid[r] = (unsigned short)sid_; rec_pos[r] = pos_; rec_cnt[r] = cnt_;
+                rec_sx[r] = 64u * (u32)j * cnt_ + sk_; rec_sy[r] = sy_;
+            } else fail = true;
+        };
+#pragma unroll 1
         for (int q = 0; q < R + NS - 1; ++q) {
-            const int r = q - NA;                        // source row relative to y0
-            u64 v;
-            if (r < 0) v = hasu ? hx[(size_t)(NA + r) * NBW + bj - WW] : ~0ull;
-            else if (r < R) v = Bw[r];
-            else v = hasd ? hx[(size_t)(NA + r - R) * NBW + bj + WW] : ~0ull;
+            const int r = q - NA;                        // source row of this step
+            const u64 v = rowval(pf[0], r);
+            pf[0] = pf[1]; pf[1] = pf[2]; pf[2] = pf[3]; pf[3] = ldraw(r + 4);
+#pragma unroll
+            for (int i = NBL; i > 0; --i) cr[i] = cr[i - 1];
+            cr[0] = v;
             const u64 n2 = h1 & v, n4 = a2[1] & n2;
             u64 e;
             if (NS == 14) {
@@ -328,33 +358,10 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
             a2[1] = a2[0]; a2[0] = n2;
             h1 = v;
             const int t = r - NBL;                       // the row whose window ends at r
-            if (t >= 0 && t < R) {
-                const u64 eh = hwin<NS, true>(e, hasl, hasr);
-                Bw[t] = (act && y0 + t < H) ? (Bw[t] & ~eh & vm) : 0ull;        // :171-174  maxima = mask & (window holds a 0)
-            }
-        }
-    }
-    __syncthreads();                                     // the exchange rows are read: their place becomes the parent table
-    if (geo.stop == 1) return;
-    u32 nband = 0;
-    {
-        u64 pm[SG_KB];
-        u32 sid[SG_KB], cnt[SG_KB], sy[SG_KB], sk[SG_KB], pos[SG_KB];
-#pragma unroll
-        for (int k = 0; k < SG_KB; ++k) { pm[k] = 0; sid[k] = 0; cnt[k] = 0; sy[k] = 0; sk[k] = 0; pos[k] = 0; }
-        u32 nseg = 0, la = NONE16, lb = NONE16, p63 = NONE16, prs0 = NONE16;
-        bool fail = false;
-        const u32 first_row = (u32)Bw[0], first_row_hi = (u32)(Bw[0] >> 32);
-        auto emit = [&](u32 sid_, u32 pos_, u32 cnt_, u32 sk_, u32 sy_) {
-            const int r = atomicAdd(&misc[4], 1);
-            if (r < SG_REC) {
-                rec_sid[r] = (unsigned short)sid_; rec_pos[r] = pos_; rec_cnt[r] = cnt_;
-                rec_sx[r] = 64u * (u32)j * cnt_ + sk_; rec_sy[r] = sy_;
-            } else fail = true;
-        };
-#pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const u64 B = Bw[t];
+            if (t < 0) continue;                         // (uniform)
+            const u64 eh = hwin<NS, true>(e, hasl, hasr);
+            const u64 B = (act && y0 + t < H) ? (cr[NBL] & ~eh & vm) : 0ull;      // :171-174  maxima = mask & (window holds a 0)
+            if (t == 0) firstB = B;
             bool live = false;
 #pragma unroll
             for (int k = 0; k < SG_KB; ++k) live |= pm[k] != 0ull;
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
         if (geo.stop == 2) return;
         // the first row of the tile against the last row of the tile above (its runs are segments sbase + 0, 1, .. in order)
         if (hasu) {
-            u64 N = mk64(first_row, first_row_hi);
+            u64 N = firstB;
             u32 i = 0;
             while (N) {
                 const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
@@ -452,156 +459,239 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
                 // one request per row and word: the pixel (ix + 1, py) rides along when it lies in the same word
                 const bool pair = (q & 1) == 0 && px + 1 < W && (px & 63) != 63;
                 if ((q & 1) && px > 0 && (px & 63) != 0) continue;                   // rode along with (ix, py)
-                const int ob = py / R, oi = py - ob * R + 1, ow = ob / G, og = ob - ow * G;
+                const int ob = py / R, oi = py - ob * R, ow = ob / G, og = ob - ow * G;
                 const int owner = ow * 64 + og * WW + (px >> 6);
                 const u32 slot = atomicAdd(&mb_cnt[owner], 1u);
                 if (slot < ST_MB_CAP)
-                    mb_req[owner * ST_MB_CAP + slot] = c | ((u32)q << 10) | ((u32)oi << 12) | ((u32)(px & 63) << 17) | ((u32)pair << 23);
+                    mb_req[owner * ST_MB_CAP + slot] = c | ((u32)q << 10) | ((u32)oi << 12) | ((u32)(px & 63) << 19) | ((u32)pair << 25);
                 else misc[6] = SLOW_MAILBOX;
             }
         }
-        if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; }
-        nband = ncomp;
+        if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; misc[0] = 0; misc[4] = 0; misc[5] = 0; }
+        __syncthreads();
+        if (misc[6]) { if (tid == 0) slow_flag[n] = (u32)misc[6]; return; }      // a crowded mailbox
+        if (geo.stop == 10) return;
     }
-    (void)nband;
-    __syncthreads();
-    if (misc[6]) { if (tid == 0) slow_flag[n] = (u32)misc[6]; return; }      // a crowded mailbox
-    if (geo.stop == 10) return;
 
     // ================================ opened area plane =============================================================
-    // tile rows 0 .. R + 1 = image rows y0 - 1 .. y0 + R (one halo row above and below: vertex planes, Euler number)
+    const u32 nband = ncomp_all[n * 2 + 0];
+    u32 ncomp;
+    u32* mrec = mrec_all + (size_t)n * geo.mrec_stride;                                  // [mrec_cap][16]  segment id, 15 moments
+    unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
     {
         const u64* A = area_all + fo;
+        auto ldraw = [&](int r) -> u64 {
+            const int y = min(max(y0 + r, 0), H - 1);
+            return A[(int64_t)y * WW + (act ? j : 0)];
+        };
+        auto rowval = [&](u64 raw, int r) -> u64 {
+            const int y = y0 + r;
+            return (act && y >= 0 && y < H) ? (raw | ~vm) : ~0ull;
+        };
+        u64 pf[4];
 #pragma unroll
-        for (int t = 0; t < R; ++t) {
-            const int y = y0 + t;
-            Bw[t + 1] = (act && y < H) ? (A[(int64_t)y * WW + j] | ~vm) : ~0ull;
-        }
-        if (act) {                                       // my last 5 rows, my first 5 rows
-#pragma unroll
-            for (int k = 0; k < 5; ++k) hx[(size_t)k * NBW + bj] = Bw[R - 5 + k + 1];
-#pragma unroll
-            for (int k = 0; k < 5; ++k) hx[(size_t)(5 + k) * NBW + bj] = Bw[k + 1];
-        }
-        __syncthreads();
+        for (int i = 0; i < 4; ++i) pf[i] = ldraw(-5 + i);
         u64 e5[4] = {~0ull, ~0ull, ~0ull, ~0ull}, d5[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int q = 0; q < R + 10; ++q) {
-            const int r = q - 5;                         // source row relative to y0
-            u64 v;
-            if (r < 0) v = hasu ? hx[(size_t)(5 + r) * NBW + bj - WW] : ~0ull;
-            else if (r < R) v = Bw[r + 1];
-            else v = hasd ? hx[(size_t)(5 + r - R) * NBW + bj + WW] : ~0ull;
-            // vertical erosion over 5 rows -> row r - 2 (nothing outside the image), horizontal erosion
-            u64 ve = v & e5[0] & e5[1] & e5[2] & e5[3];
-            e5[3] = e5[2]; e5[2] = e5[1]; e5[1] = e5[0]; e5[0] = v;
-            const int ye = y0 + r - 2;
-            ve = hwin<5, true>(ve, hasl, hasr);
-            ve = (act && ye >= 0 && ye < H) ? (ve & vm) : 0ull;
-            // vertical dilation over 5 rows -> row r - 4, horizontal dilation
-            const u64 vd = ve | d5[0] | d5[1] | d5[2] | d5[3];
-            d5[3] = d5[2]; d5[2] = d5[1]; d5[1] = d5[0]; d5[0] = ve;
-            const int t = r - 4 + 1;                     // tile row of image row y0 + r - 4
-            if (t >= 0 && t <= R + 1) {
-                const u64 o = hwin<5, false>(vd, hasl, hasr);
-                const int y = y0 + r - 4;
-                Bw[t] = (act && y >= 0 && y < H) ? (o & vm) : 0ull;             // :195  morphologyEx(MORPH_OPEN, 5x5)
-            }
-        }
-    }
-    u32 lm, rm;                                          // bit t: bit 63 of the left / bit 0 of the right word in tile row t
-    {
-        u32 mym = 0, myl = 0;
-#pragma unroll
-        for (int t = 0; t <= R + 1; ++t) { mym |= (u32)(Bw[t] >> 63) << t; myl |= ((u32)Bw[t] & 1u) << t; }
-        lm = dpp_shr1(mym); rm = dpp_shl1(myl);
-        if (!hasl) lm = 0;
-        if (!hasr) rm = 0;
-    }
-    if (tid == 0) { misc[0] = 0; misc[4] = 0; misc[5] = 0; }
-    {
-        // bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the zero-padded image; a
-        // word counts the windows whose top row is its row (image row 0 also the padding row above it)
-        int e4 = 0;
-#pragma unroll
-        for (int t = 1; t <= R; ++t) {
-            const u64 B = Bw[t];
-            const bool top = (y0 + t - 1) == 0;
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                if (q == 1 && !top) continue;
-                const u64 a = q ? 0ull : B, bq = q ? B : Bw[t + 1];
-                const u32 an = q ? 0u : ((rm >> t) & 1u), bn = q ? ((rm >> t) & 1u) : ((rm >> (t + 1)) & 1u);
-                if (a | bq | an | bn) {
-                    const u64 a1 = (a >> 1) | ((u64)an << 63), b1 = (bq >> 1) | ((u64)bn << 63);
-                    const u64 x2 = (a ^ a1) ^ (bq ^ b1);
-                    const u64 pairs = (a & a1) | (a & bq) | (a & b1) | (a1 & bq) | (a1 & b1) | (bq & b1);
-                    const u64 qd = (a & b1 & ~a1 & ~bq) | (a1 & bq & ~a & ~b1);
-                    e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
-                    if (j == 0) e4 += (int)((a ^ bq) & 1ull);                   // window x = -1: only (0,y), (0,y+1)
-                }
-            }
-        }
-        __syncthreads();                                 // exchange rows read; counters cleared
-        if (e4) atomicAdd(&misc[0], e4);
-    }
-    if (geo.stop == 11) return;
-    u32 ncomp;
-    {
-        // ---- walk 1: segments of the opened mask (8-connectivity), one {id, first pixel} record per segment -------------
+        u64 o1 = 0, o2 = 0;                              // the opened rows before the newest one
+        u32 l1 = 0, l2 = 0, r1 = 0, r2 = 0;              // bit 63 of the word to the left / bit 0 of the word to the right in those rows
+        // this thread's probe requests: which of its rows have any
+        u64 rowmask = 0;
+        const u32 nreq = min(mb_cnt[tid], (u32)ST_MB_CAP);
+        for (u32 q = 0; q < nreq; ++q) rowmask |= 1ull << ((mb_req[tid * ST_MB_CAP + q] >> 12) & 127u);
         u64 pm[SG_KO];
         u32 sid[SG_KO];
+        int mo[SG_KO][NMOM];                             // vertex moments about the tile's centre
 #pragma unroll
-        for (int k = 0; k < SG_KO; ++k) { pm[k] = 0; sid[k] = 0; }
+        for (int k = 0; k < SG_KO; ++k) {
+            pm[k] = 0; sid[k] = 0;
+#pragma unroll
+            for (int q = 0; q < NMOM; ++q) mo[k][q] = 0;
+        }
         u32 nseg = 0, la = NONE16, lb = NONE16, p63 = NONE16, prs0 = NONE16;
-        bool fail = false;
+        u32 why = 0;
+        u64 firstB = 0;
+        int e4 = 0;
+        const int tch = R >> 1;
+        const int mthr = 900;                            // vertices (with multiplicity) an entry may hold: its sums stay below 2^31
+        auto emit_mom = [&](u32 sid_, int (&m)[NMOM]) {
+            const int r = atomicAdd(&misc[7], 1);
+            if ((u32)r < geo.mrec_cap) {
+                uint4* dst = reinterpret_cast<uint4*>(mrec + (size_t)r * 16);
+                dst[0] = make_uint4(sid_, (u32)m[0], (u32)m[1], (u32)m[2]);
+                dst[1] = make_uint4((u32)m[3], (u32)m[4], (u32)m[5], (u32)m[6]);
+                dst[2] = make_uint4((u32)m[7], (u32)m[8], (u32)m[9], (u32)m[10]);
+                dst[3] = make_uint4((u32)m[11], (u32)m[12], (u32)m[13], (u32)m[14]);
+            } else why = SLOW_SLOTS;
 #pragma unroll
-        for (int t = 1; t <= R; ++t) {
-            const u64 B = Bw[t];
+            for (int q = 0; q < NMOM; ++q) m[q] = 0;
+        };
+#pragma unroll 1
+        for (int q = 0; q < R + 10; ++q) {
+            const int r = q - 5;                         // source row of this step
+            const u64 v = rowval(pf[0], r);
+            pf[0] = pf[1]; pf[1] = pf[2]; pf[2] = pf[3]; pf[3] = ldraw(r + 4);
+            // vertical erosion over 5 rows -> row r - 2, horizontal erosion; nothing outside the image
+            u64 ve = v & e5[0] & e5[1] & e5[2] & e5[3];
+            e5[3] = e5[2]; e5[2] = e5[1]; e5[1] = e5[0]; e5[0] = v;
+            u64 er = 0;
+            if (r >= -1) {                               // (uniform: the eroded rows the tile's output rows reach)
+                const int ye = y0 + r - 2;
+                er = hwin<5, true>(ve, hasl, hasr);
+                er = (act && ye >= 0 && ye < H) ? (er & vm) : 0ull;
+            }
+            // vertical dilation over 5 rows -> row r - 4, horizontal dilation
+            const u64 vd = er | d5[0] | d5[1] | d5[2] | d5[3];
+            d5[3] = d5[2]; d5[2] = d5[1]; d5[1] = d5[0]; d5[0] = er;
+            const int rho = r - 4;                       // the opened row this step completes (relative to y0)
+            if (rho < -1) continue;                      // (uniform)
+            u64 o0 = hwin<5, false>(vd, hasl, hasr);
+            {
+                const int y = y0 + rho;
+                o0 = (act && y >= 0 && y < H) ? (o0 & vm) : 0ull;               // :195  morphologyEx(MORPH_OPEN, 5x5)
+            }
+            u32 l0 = dpp_shr1((u32)(o0 >> 63)), r0 = dpp_shl1((u32)o0 & 1u);
+            if (!hasl) l0 = 0;
+            if (!hasr) r0 = 0;
+            const int c = rho - 1;                       // the row to label now: its neighbours above and below are known
             bool live = false;
 #pragma unroll
             for (int k = 0; k < SG_KO; ++k) live |= pm[k] != 0ull;
-            if (!__any(B != 0ull || live)) { p63 = NONE16; prs0 = NONE16; continue; }
-            const u64 rB = brev64(B);
-            u64 Rn[SG_KO];
-            const u64 claimed = seg_update<SG_KO, true, true>(B, rB, pm, sid, Rn, Q);
+            // ---- Euler number by bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the
+            //      zero-padded image; a word counts the windows whose top row is its row (image row 0 also the padding row)
+            if (c >= 0) {
+                const bool top = (y0 + c) == 0;
 #pragma unroll
-            for (int k = 0; k < SG_KO; ++k) pm[k] = Rn[k];
-            u64 N = B & ~claimed;
-            while (N) {
-                const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
-                N &= t2;
-                bool done = false;
-#pragma unroll
-                for (int k = 0; k < SG_KO; ++k) {
-                    if (!done && pm[k] == 0ull) {
-                        if (nseg < SG_SEGMAX) {
-                            sid[k] = sbase + nseg; P[sbase + nseg] = (unsigned short)(sbase + nseg);
-                            const int r = atomicAdd(&misc[4], 1);
-                            if (r < SG_REC) {
-                                rec_sid[r] = (unsigned short)(sbase + nseg);
-                                rec_pos[r] = (u32)(y0 + t - 1) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
-                            } else fail = true;
-                        } else fail = true;
-                        ++nseg;
-                        pm[k] = gg;
-                        done = true;
+                for (int qq = 0; qq < 2; ++qq) {
+                    if (qq == 1 && !top) continue;
+                    const u64 a = qq ? 0ull : o1, bq = qq ? o1 : o0;
+                    const u32 an = qq ? 0u : r1, bn = qq ? r1 : r0;
+                    if (a | bq | an | bn) {
+                        const u64 a1 = (a >> 1) | ((u64)an << 63), b1 = (bq >> 1) | ((u64)bn << 63);
+                        const u64 x2 = (a ^ a1) ^ (bq ^ b1);
+                        const u64 pairs = (a & a1) | (a & bq) | (a & b1) | (a1 & bq) | (a1 & b1) | (bq & b1);
+                        const u64 qd = (a & b1 & ~a1 & ~bq) | (a1 & bq & ~a & ~b1);
+                        e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
+                        if (j == 0) e4 += (int)((a ^ bq) & 1ull);           // window x = -1: only (0,y), (0,y+1)
                     }
                 }
-                if (!done) fail = true;
             }
-            seg_hlinks<SG_KO, true>(pm, sid, hasr, p63, prs0, la, lb, Q);
+            if (c >= 0 && __any(o1 != 0ull || live || ((rowmask >> c) & 1ull))) {
+                const u64 B = o1;
+                if (c == 0) firstB = B;
+                // ---- segments ---------------------------------------------------------------------------------------------
+                const u64 rB = brev64(B);
+                u64 Rn[SG_KO];
+                const u64 claimed = seg_update<SG_KO, true, true>(B, rB, pm, sid, Rn, Q);
+#pragma unroll
+                for (int k = 0; k < SG_KO; ++k) pm[k] = Rn[k];
+                u64 N = B & ~claimed;
+                while (N) {
+                    const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                    N &= t2;
+                    bool done = false;
+#pragma unroll
+                    for (int k = 0; k < SG_KO; ++k) {
+                        if (!done && pm[k] == 0ull) {
+                            if (mo[k][0]) emit_mom(sid[k], mo[k]);
+                            if (nseg < SG_SEGMAX) {
+                                sid[k] = sbase + nseg; P[sbase + nseg] = (unsigned short)(sbase + nseg);
+                                const int rr = atomicAdd(&misc[4], 1);
+                                if (rr < SG_REC) {
+                                    rec_sid[rr] = (unsigned short)(sbase + nseg);
+                                    rec_pos[rr] = (u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
+                                } else why = SLOW_SLOTS;
+                            } else why = SLOW_SLOTS;
+                            ++nseg;
+                            pm[k] = gg;
+                            done = true;
+                        }
+                    }
+                    if (!done) why = SLOW_SLOTS;
+                }
+                seg_hlinks<SG_KO, true>(pm, sid, hasr, p63, prs0, la, lb, Q);
+                // ---- probes: the segment that holds a pixel of this row ---------------------------------------------------
+                if ((rowmask >> c) & 1ull) {
+                    for (u32 qq = 0; qq < nreq; ++qq) {
+                        const u32 rq = mb_req[tid * ST_MB_CAP + qq];
+                        if (((rq >> 12) & 127u) != (u32)c) continue;
+                        const u32 q0 = (rq >> 10) & 3u;
+                        for (u32 d = 0; d <= ((rq >> 25) & 1u); ++d) {
+                            const u32 kb = ((rq >> 19) & 63u) + d;
+                            u32 s = NONE16;
+#pragma unroll
+                            for (int k = 0; k < SG_KO; ++k)
+                                if ((pm[k] >> kb) & 1ull) s = sid[k];
+                            pr[(rq & 1023u) * 4 + q0 + d] = (unsigned short)s;
+                        }
+                    }
+                }
+                // ---- contour vertices -------------------------------------------------------------------------------------
+                if (__any(B != 0ull)) {
+                    // the eight neighbour planes: bit k = the neighbour of pixel k in chain direction d is foreground
+                    const u64 D0 = (B >> 1) | ((u64)r1 << 63), D4 = (B << 1) | (u64)l1;
+                    const u64 D2 = o2, D1 = (o2 >> 1) | ((u64)r2 << 63), D3 = (o2 << 1) | (u64)l2;
+                    const u64 D6 = o0, D7 = (o0 >> 1) | ((u64)r0 << 63), D5 = (o0 << 1) | (u64)l0;
+                    // a vertex per maximal arc of background neighbours that starts at direction a (a background, a - 1
+                    // foreground), holds a 4-neighbour and is not exactly {a, a + 1, a + 2} (the border passes straight through)
+#define KEPT_EVEN(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ((Dp1) | (Dp2) | ~(Dp3)))
+#define KEPT_ODD(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ~(Dp1) & ((Dp2) | ~(Dp3)))
+                    const u64 k0 = KEPT_EVEN(D0, D7, D1, D2, D3), k1 = KEPT_ODD(D1, D0, D2, D3, D4);
+                    const u64 k2 = KEPT_EVEN(D2, D1, D3, D4, D5), k3 = KEPT_ODD(D3, D2, D4, D5, D6);
+                    const u64 k4 = KEPT_EVEN(D4, D3, D5, D6, D7), k5 = KEPT_ODD(D5, D4, D6, D7, D0);
+                    const u64 k6 = KEPT_EVEN(D6, D5, D7, D0, D1), k7 = KEPT_ODD(D7, D6, D0, D1, D2);
+#undef KEPT_EVEN
+#undef KEPT_ODD
+                    const u64 iso = ~(D0 | D1 | D2 | D3 | D4 | D5 | D6 | D7);    // an isolated pixel is written once
+                    // V1 / V2 / V3: at least one / two / three of the nine planes
+                    u64 V1 = k0, V2 = 0, V3 = 0;
+#define ADDP(Kp) { V3 |= V2 & (Kp); V2 |= V1 & (Kp); V1 |= (Kp); }
+                    ADDP(k1) ADDP(k2) ADDP(k3) ADDP(k4) ADDP(k5) ADDP(k6) ADDP(k7) ADDP(iso)
+#undef ADDP
+                    V1 &= B; V2 &= B; V3 &= B;
+                    if (V3) why = SLOW_VERTEX;            // multiplicity > 2: impossible after a 5x5 opening; general path
+                    const int tc = c - tch, tc2 = __mul24(tc, tc), tc3 = __mul24(tc2, tc), tc4 = __mul24(tc2, tc2);
+#pragma unroll
+                    for (int k = 0; k < SG_KO; ++k) {
+                        u64 vg = V1 & pm[k];
+                        if (!__any(vg != 0ull)) continue;
+                        if (vg) {
+                            // row sums s_a = sum mult dx^a about the word's centre (24-bit multiplies)
+                            int s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+                            while (vg) {
+                                const int kb = __ffsll((long long)vg) - 1;
+                                vg &= vg - 1;
+                                const int dx = kb - 32, two = (int)((V2 >> kb) & 1ull);
+                                const int mx = two ? 2 * dx : dx, x2 = __mul24(dx, dx), mxx = __mul24(mx, dx);
+                                s0 += 1 + two; s1 += mx; s2 += mxx; s3 += __mul24(mx, x2); s4 += __mul24(mxx, x2);
+                            }
+                            int (&m)[NMOM] = mo[k];
+                            if (m[0] > mthr) emit_mom(sid[k], m);
+                            m[0] += s0;                    m[1] += s1;                    m[2] += __mul24(s0, tc);
+                            m[3] += s2;                    m[4] += __mul24(s1, tc);       m[5] += __mul24(s0, tc2);
+                            m[6] += s3;                    m[7] += __mul24(s2, tc);       m[8] += __mul24(s1, tc2);
+                            m[9] += __mul24(s0, tc3);      m[10] += s4;                   m[11] += s3 * tc;
+                            m[12] += __mul24(s2, tc2);     m[13] += __mul24(s1, tc3);     m[14] += __mul24(s0, tc4);
+                        }
+                    }
+                }
+            } else if (c >= 0) {
+                p63 = NONE16; prs0 = NONE16;             // an empty row: nothing to link the next one with
+            }
+            o2 = o1; o1 = o0; l2 = l1; l1 = l0; r2 = r1; r1 = r0;
         }
 #pragma unroll
-        for (int k = 0; k < SG_KO; ++k)
+        for (int k = 0; k < SG_KO; ++k) {
+            if (mo[k][0]) emit_mom(sid[k], mo[k]);
             if (act) { bot_mask[(size_t)k * NBW + bj] = pm[k]; bot_sid[(size_t)k * NBW + bj] = (unsigned short)sid[k]; }
-        if (fail) misc[6] = SLOW_SLOTS;
+        }
+        if (e4) atomicAdd(&misc[0], e4);
+        if (why) misc[6] = (int)why;
         __syncthreads();
         if (misc[6]) { if (tid == 0) slow_flag[n] = 16u + (u32)misc[6]; return; }
         if (geo.stop == 12) return;
         // first row of the tile against the last row of the tile above, with the diagonal neighbours across the word edges
-        if (hasu && Bw[1]) {
-            u64 N = Bw[1];
+        if (hasu && firstB) {
+            u64 N = firstB;
             u32 i = 0;
             while (N) {
                 const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
@@ -642,167 +732,53 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
             first[cid] = pos;
         }
     }
-    // this thread's probe requests: which of its rows have any
-    u32 rowmask = 0;
-    const u32 nreq = min(mb_cnt[tid], (u32)ST_MB_CAP);
-    for (u32 q = 0; q < nreq; ++q) rowmask |= 1u << ((mb_req[tid * ST_MB_CAP + q] >> 12) & 31u);
-    unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
+    // ---- segment moments -> component moments about its first pixel, 256 components per pass -----------------------------
     i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
-    // ---- walk 2: the same segments again, now with their components: contour-vertex moments, 256 components per pass ----
+    const u32 nmrec = (u32)misc[7];
     for (u32 c0 = 0; c0 < ncomp; c0 += CCL_MOM_COMPS) {
         const u32 nc = min((u32)CCL_MOM_COMPS, ncomp - c0);
         for (u32 c = tid; c < nc * NMOM; c += ST_NT) acc[c] = 0;
         __syncthreads();
-        u64 pm[SG_KO];
-        u32 sid[SG_KO], cidk[SG_KO], anc[SG_KO];
-        MomEntry ent[SG_KO];
+        for (u32 r = tid; r < nmrec; r += ST_NT) {
+            const uint4* src = reinterpret_cast<const uint4*>(mrec + (size_t)r * 16);
+            const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+            const u32 s = w0.x, cid = (u32)cidmap[P[s] & 0x7FFFu] - c0;
+            if (cid >= nc) continue;                     // another pass's component
+            const u32 ot = s / SG_SEGMAX, ol = ot & 63u, og = ol / (u32)WW;             // the thread that wrote it: its tile
+            const int ox = 64 * (int)(ol - og * (u32)WW) + 32, oy = (int)((ot >> 6) * (u32)G + og) * R + (R >> 1);
+            const u32 fp = anchor[cid + c0];
+            const i64 m[NMOM] = {(int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w, (int)w2.x,
+                                 (int)w2.y, (int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y, (int)w3.z, (int)w3.w};
+            i64 o[NMOM];
+            shift_moments_i64(m, (i64)(ox - (int)(fp & 0xFFFFu)), (i64)(oy - (int)(fp >> 16)), o);
+            u64* a = acc + cid * NMOM;
 #pragma unroll
-        for (int k = 0; k < SG_KO; ++k) {
-            pm[k] = 0; sid[k] = 0; cidk[k] = NONE32; anc[k] = 0;
-#pragma unroll
-            for (int q = 0; q < 10; ++q) ent[k].m[q] = 0;
+            for (int q = 0; q < NMOM; ++q)
+                if (o[q]) atomicAdd(&a[q], (u64)o[q]);
         }
-        u32 nseg = 0;
-        u32 why = 0;
-#pragma unroll
-        for (int t = 1; t <= R; ++t) {
-            const u64 B = Bw[t];
-            bool live = false;
-#pragma unroll
-            for (int k = 0; k < SG_KO; ++k) live |= pm[k] != 0ull;
-            if (!__any(B != 0ull || live || ((rowmask >> t) & 1u))) continue;
-            const u64 rB = brev64(B);
-            u64 Rn[SG_KO];
-            const u64 claimed = seg_update<SG_KO, true, false>(B, rB, pm, sid, Rn, Q);
-#pragma unroll
-            for (int k = 0; k < SG_KO; ++k) pm[k] = Rn[k];
-            u64 N = B & ~claimed;
-            while (N) {
-                const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
-                N &= t2;
-                bool done = false;
-#pragma unroll
-                for (int k = 0; k < SG_KO; ++k) {
-                    if (!done && pm[k] == 0ull) {
-                        if (cidk[k] != NONE32) mom_flush(ent[k], cidk[k], acc);
-                        const u32 c = (u32)cidmap[P[sbase + nseg] & 0x7FFFu];
-                        ++nseg;
-                        anc[k] = anchor[c];
-                        cidk[k] = c - c0 < nc ? c - c0 : NONE32;   // (another pass's component)
-                        sid[k] = c;                       // (the replay unites nothing: the slot's component id will do)
-                        pm[k] = gg;
-                        done = true;
-                    }
-                }
-            }
-            if (c0 == 0 && ((rowmask >> t) & 1u)) {      // probes: component id of a pixel of this row
-                for (u32 q = 0; q < nreq; ++q) {
-                    const u32 rq = mb_req[tid * ST_MB_CAP + q];
-                    if (((rq >> 12) & 31u) != (u32)t) continue;
-                    const u32 q0 = (rq >> 10) & 3u;
-                    for (u32 d = 0; d <= ((rq >> 23) & 1u); ++d) {
-                        const u32 kb = ((rq >> 17) & 63u) + d;
-                        u32 cid = NONE16;
-#pragma unroll
-                        for (int k = 0; k < SG_KO; ++k)
-                            if ((pm[k] >> kb) & 1ull) cid = sid[k];
-                        pr[(rq & 1023u) * 4 + q0 + d] = (unsigned short)cid;
-                    }
-                }
-            }
-            if (!__any(B != 0ull)) continue;
-            // the eight neighbour planes: bit k = the neighbour of pixel k in chain direction d is foreground
-            const u32 pB = (lm >> t) & 1u;
-            const u64 An = Bw[t - 1], Sn = Bw[t + 1];
-            const u64 D0 = (B >> 1) | ((u64)((rm >> t) & 1u) << 63), D4 = (B << 1) | (u64)pB;
-            const u64 D2 = An, D1 = (An >> 1) | ((u64)((rm >> (t - 1)) & 1u) << 63), D3 = (An << 1) | (u64)((lm >> (t - 1)) & 1u);
-            const u64 D6 = Sn, D7 = (Sn >> 1) | ((u64)((rm >> (t + 1)) & 1u) << 63), D5 = (Sn << 1) | (u64)((lm >> (t + 1)) & 1u);
-            // a vertex per maximal arc of background neighbours that starts at direction a (a background, a - 1 foreground),
-            // holds a 4-neighbour and is not exactly {a, a + 1, a + 2} (then the border passes straight through)
-#define KEPT_EVEN(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ((Dp1) | (Dp2) | ~(Dp3)))
-#define KEPT_ODD(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ~(Dp1) & ((Dp2) | ~(Dp3)))
-            const u64 k0 = KEPT_EVEN(D0, D7, D1, D2, D3), k1 = KEPT_ODD(D1, D0, D2, D3, D4);
-            const u64 k2 = KEPT_EVEN(D2, D1, D3, D4, D5), k3 = KEPT_ODD(D3, D2, D4, D5, D6);
-            const u64 k4 = KEPT_EVEN(D4, D3, D5, D6, D7), k5 = KEPT_ODD(D5, D4, D6, D7, D0);
-            const u64 k6 = KEPT_EVEN(D6, D5, D7, D0, D1), k7 = KEPT_ODD(D7, D6, D0, D1, D2);
-#undef KEPT_EVEN
-#undef KEPT_ODD
-            const u64 iso = ~(D0 | D1 | D2 | D3 | D4 | D5 | D6 | D7);    // an isolated pixel is written once
-            // V1 / V2 / V3: at least one / two / three of the nine planes
-            u64 V1 = k0, V2 = 0, V3 = 0;
-#define ADDP(Kp) { V3 |= V2 & (Kp); V2 |= V1 & (Kp); V1 |= (Kp); }
-            ADDP(k1) ADDP(k2) ADDP(k3) ADDP(k4) ADDP(k5) ADDP(k6) ADDP(k7) ADDP(iso)
-#undef ADDP
-            V1 &= B; V2 &= B; V3 &= B;
-            if (V3) why = SLOW_VERTEX;                    // multiplicity > 2: impossible after a 5x5 opening; general path
-            const int y = y0 + t - 1;
-#pragma unroll
-            for (int k = 0; k < SG_KO; ++k) {
-                u64 vg = V1 & pm[k];
-                if (!__any(vg != 0ull)) continue;
-                if (vg && cidk[k] != NONE32) {
-                    const u32 fp = anc[k];
-                    const int dy = y - (int)(fp >> 16), dx0 = 64 * j - (int)(fp & 0xFFFFu);
-                    if (dx0 >= -150 && dx0 + 63 <= 150 && abs(dy) <= 150) {
-                        // row sums s_a = sum mult dx^a (24-bit multiplies: every factor < 2^23, every product < 2^31)
-                        int s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-                        i64 s4 = 0;
-                        while (vg) {
-                            const int kb = __ffsll((long long)vg) - 1;
-                            vg &= vg - 1;
-                            const int dx = dx0 + kb, two = (int)((V2 >> kb) & 1ull);
-                            const int mx = two ? 2 * dx : dx, x2 = __mul24(dx, dx), mxx = __mul24(mx, dx);
-                            s0 += 1 + two; s1 += mx; s2 += mxx; s3 += __mul24(mx, x2);
-                            s4 += (i64)__mul24(mxx, x2);
-                        }
-                        const int dy2 = __mul24(dy, dy), dy3 = __mul24(dy2, dy);
-                        MomEntry& e = ent[k];
-                        if (e.m[0] > 256) mom_flush(e, cidk[k], acc);           // (orders <= 3 stay below 2^31)
-                        e.m[0] += s0;                  e.m[1] += s1;                  e.m[2] += __mul24(s0, dy);
-                        e.m[3] += s2;                  e.m[4] += __mul24(s1, dy);     e.m[5] += __mul24(s0, dy2);
-                        e.m[6] += s3;                  e.m[7] += __mul24(s2, dy);     e.m[8] += __mul24(s1, dy2);
-                        e.m[9] += __mul24(s0, dy3);
-                        u64* a = acc + cidk[k] * NMOM;
-                        atomicAdd(&a[10], (u64)s4);
-                        if (dy) {
-                            atomicAdd(&a[11], (u64)((i64)s3 * dy));
-                            atomicAdd(&a[12], (u64)((i64)s2 * dy2));
-                            atomicAdd(&a[13], (u64)((i64)s1 * dy3));
-                            atomicAdd(&a[14], (u64)((i64)__mul24(s0, dy2) * dy2));
-                        }
-                    } else {
-                        why = SLOW_LARGE;
-                    }
-                }
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < SG_KO; ++k)
-            if (cidk[k] != NONE32) mom_flush(ent[k], cidk[k], acc);
-        if (why) misc[6] = (int)why;
         __syncthreads();
         for (u32 c = tid; c < nc * NMOM; c += ST_NT) as[(c0 + c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
         __syncthreads();
     }
-    if (misc[6]) { if (tid == 0) slow_flag[n] = 16u + (u32)misc[6]; return; }
+    // ---- probes: segment -> component ----------------------------------------------------------------------------------
+    for (u32 e = tid; e < nband * 4; e += ST_NT) {
+        const u32 v = pr[e];
+        if (v != NONE16) pr[e] = cidmap[P[v] & 0x7FFFu];
+    }
     if (tid == 0) { ncomp_all[n * 2 + 1] = ncomp; fstat[n * 8 + 6] = ncomp; fstat[n * 8 + 4] = 0; }
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
-// rows per thread the kernel is compiled for; 0 = geometry outside the fused path (the round-2 kernels take it)
-static int stage_rows(const vbs_handle* h, StageGeom* g, size_t* lds_bytes) {
-    if (h->WW > 32) return 0;
-    const int G = 64 / h->WW, NB = 16 * G;
-    const int need = (h->H + NB - 1) / NB;
-    const bool ns14 = h->bp.ns == 14;
-    // (a block's windows must not reach past the neighbouring block: R >= 7 for the 14-row window, >= 5 for the opening)
-    const int R = (need <= 6 && !ns14) ? 6 : need <= 12 ? 12 : need <= 22 ? 22 : 0;
-    if (!R || h->W > 4096 || h->H > 2048 || h->maxm > 1024) return 0;
-    g->H = h->H; g->W = h->W; g->WW = h->WW; g->G = G; g->NB = NB; g->maxm = h->maxm;
+// false = geometry outside the fused path (the round-2 kernels take it)
+static bool stage_geom(const vbs_handle* h, StageGeom* g, size_t* lds_bytes) {
+    if (h->W > 4096 || h->H > 2048 || h->maxm > 1024) return false;
+    const int G = 64 / h->WW, NB = 16 * G;               // (WW <= 64: vbs_create)
+    const int R = (h->H + NB - 1) / NB;
+    if (R > 64 || R < 1) return false;                   // (row bit masks; int32 moments about the tile's centre)
+    g->H = h->H; g->W = h->W; g->WW = h->WW; g->G = G; g->NB = NB; g->R = R; g->maxm = h->maxm;
     g->stop = VBS_KNOB("VBS_STAGE_STOP");
     const size_t NBW = (size_t)NB * h->WW;
     auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
-    const size_t exch = up16((size_t)(h->bp.ns - 1 > 10 ? h->bp.ns - 1 : 10) * NBW * 8);
     const size_t par = up16((size_t)ST_NT * SG_SEGMAX * 2);
     const size_t rec = up16((size_t)SG_REC * 18);
     const size_t bot = up16((size_t)SG_KB * NBW * 10);
@@ -810,37 +786,38 @@ static int stage_rows(const vbs_handle* h, StageGeom* g, size_t* lds_bytes) {
     const size_t acc_open = up16((size_t)4 * CCL_OPEN_COMPS + (size_t)CCL_MOM_COMPS * NMOM * 8);
     const size_t comp = 4096 + 2048 + (acc_band > acc_open ? acc_band : acc_open);
     const size_t botc = bot > comp ? bot : comp;
-    const size_t x = exch > par + rec + botc ? exch : par + rec + botc;      // the exchange rows and the tables share a region
-    const size_t mb = (size_t)ST_NT * 4 * (1 + ST_MB_CAP), pq = (size_t)SG_PQ * 4;
-    const size_t misc = 32 * 4 + 16 * 4;
+    const size_t pq = (size_t)SG_PQ * 4, mb = (size_t)ST_NT * 4 * (1 + ST_MB_CAP), misc = 32 * 4 + 16 * 4;
     g->off_rec = (u32)par;
     g->off_bot = (u32)(par + rec);
-    g->off_pq = (u32)x;
-    g->off_mb = (u32)(x + pq);
-    g->off_tmp = (u32)(x + pq + mb);
-    *lds_bytes = x + pq + mb + misc;
-    if (*lds_bytes > 160 * 1024) return 0;
-    return R;
+    g->off_pq = (u32)(par + rec + botc);
+    g->off_mb = (u32)(g->off_pq + pq);
+    g->off_tmp = (u32)(g->off_mb + mb);
+    *lds_bytes = g->off_tmp + misc;
+    // moment records live in the frame's slice of the general path's word table (idle on the fast path)
+    g->mrec_stride = 2u * (u32)h->H * (u32)h->WW;
+    g->mrec_cap = g->mrec_stride / 16u < (u32)SG_REC ? g->mrec_stride / 16u : (u32)SG_REC;
+    return *lds_bytes <= 160 * 1024;
 }
 
 bool stage_supported(const vbs_handle* h) {
     StageGeom g;
     size_t lds;
-    return stage_rows(h, &g, &lds) != 0;
+    return stage_geom(h, &g, &lds);
 }
 
-template <int R, int NS>
+template <int NS>
 static bool stage_launch_t(vbs_handle* h, int nb, const StageGeom& g, size_t lds, hipStream_t s) {
     if (lds > h->stage_lds_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage<R, NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        // (both instances: a handle runs only one of them)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
         h->stage_lds_set = lds;
     }
-    VBS_LAUNCH(h, s, "k_stage", (k_stage<R, NS>), dim3(nb), dim3(ST_NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
-               h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, g);
+    VBS_LAUNCH(h, s, "k_stage", (k_stage<NS>), dim3(nb), dim3(ST_NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
+               h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, h->wbase, g);
     return true;
 }
 
@@ -848,12 +825,6 @@ static bool stage_launch_t(vbs_handle* h, int nb, const StageGeom& g, size_t lds
 bool launch_stage(vbs_handle* h, int nb, hipStream_t s) {
     StageGeom g;
     size_t lds = 0;
-    const int R = stage_rows(h, &g, &lds);
-    if (!R) return false;
-    const bool ns14 = h->bp.ns == 14;
-    switch (R) {
-        case 6: return stage_launch_t<6, 8>(h, nb, g, lds, s);
-        case 12: return ns14 ? stage_launch_t<12, 14>(h, nb, g, lds, s) : stage_launch_t<12, 8>(h, nb, g, lds, s);
-        default: return ns14 ? stage_launch_t<22, 14>(h, nb, g, lds, s) : stage_launch_t<22, 8>(h, nb, g, lds, s);
-    }
+    if (!stage_geom(h, &g, &lds)) return false;
+    return h->bp.ns == 14 ? stage_launch_t<14>(h, nb, g, lds, s) : stage_launch_t<8>(h, nb, g, lds, s);
 }
