@@ -1,7 +1,7 @@
 """Phase timing of the fused labelling kernel (k_stage): runs the fused path with the debug library (libvbs_dbg.so, built
 with -DVBS_DEBUG_KNOBS) and VBS_STAGE_STOP set, printing the live per-kernel times (us per frame).
-stops: 1 band morph | 2 + band walk (labels + sums) | 3 + tile links | 4 + components | 10 + sums out, probe requests |
-11 + open morph, Euler | 12 + walk 1 (labels) | 13 + tile links | 14 + components | 0 + walk 2 (moments, probes).  usage: gpu_stage_phase.py [frames] [c3|c5]"""
+stops (STOPS=.. selects): 2 band loop (morph, labels, sums) | 3 + tile links | 4 + components | 10 + sums out, probe requests |
+12 + open loop (morph, Euler, labels, vertex moments, probes) | 13 + tile links | 14 + components | 0 + moment shift, probe ids.  usage: gpu_stage_phase.py [frames] [c3|c5]"""
 import os, sys, json, subprocess
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -23,7 +23,7 @@ if len(sys.argv) > 3 and sys.argv[3] == "child":
 else:
     n = sys.argv[1] if len(sys.argv) > 1 else "512"
     w = sys.argv[2] if len(sys.argv) > 2 else "c3"
-    for stop in (1, 2, 3, 4, 10, 11, 12, 13, 14, 0):
+    for stop in [int(x) for x in os.environ.get('STOPS', '2,3,4,10,12,13,14,0').split(',')]:
         env = dict(os.environ, VBS_STAGE_STOP=str(stop))
         r = subprocess.run([sys.executable, __file__, n, w, "child"], env=env, capture_output=True, text=True, timeout=300)
         print("stop", stop, r.stdout.strip(), r.stderr.strip()[-300:] if r.returncode else "", flush=True)

@@ -164,7 +164,8 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(area_first, B * max_markers); ALLOC(area_sums, B * max_markers * VBS_AREA_SUMS);
     ALLOC(ell, B * max_markers * 8); ALLOC(det64, B * max_markers * 6);
     ALLOC(cnt, B);
-    ALLOC(probe, B * max_markers * 4); ALLOC(slow_flag, B); ALLOC(ncc_tot, 4);
+    ALLOC(probe, B * max_markers * 4); ALLOC(slow_total, B + 4); ALLOC(ncc_tot, 4);
+    h->slow_flag = h->slow_total + 4;                    // (one memset clears both)
     ALLOC(lut, 256);
     ALLOC(blur_frags, frags.size() / 4);
     std::vector<u32> nfrags = ncc_mfma_fragments(h->ncc, bp.ncc_l);

@@ -83,7 +83,8 @@ struct vbs_handle {
     int32_t* cnt;      // [maxb]
     unsigned short* probe;   // [maxb][maxm][4]  component ids of the 2x2 cell around every band centroid
     u64* ncc_tot;      // [4]  running NCC decision counters (vbs_ncc_counters)
-    u32* slow_flag;    // [maxb]  1 = the fast labelling path handed the frame on
+    u32* slow_total;   // [1]  frames of this pass the fused kernel handed on (lets the general kernels leave at once)
+    u32* slow_flag;    // [maxb]  non-zero = the fast labelling path handed the frame on (the value says why)
     size_t stage_lds_set = 0, ccl_lds_set[2] = {0, 0};   // dynamic LDS declared for k_stage / k_ccl<0|1> through this handle
     int stage_impl = 0;             // vbs_set_option(VBS_OPT_STAGE_IMPL): 0 fused k_stage, 1 the round-2 kernels (k_morph + k_ccl)
     int gray_bits = 15;             // BGR2GRAY fixed-point coefficient set: 15 (OpenCV 4) | 14 (OpenCV <= 3.4.1)

@@ -106,8 +106,10 @@ __device__ __forceinline__ u64 hmorph(u64 wl, u64 wc, u64 wr, int lo, int hi) {
 template <int NS14>                                      // ns = 14 (large frames) or 8 (small)
 __global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits, const u64* __restrict__ abits,
                                                u64* __restrict__ band, u64* __restrict__ opn, const u32* __restrict__ only,
+                                               const u32* __restrict__ nslow,
                                                int nb, int H, int W, int WW, int G, int strips, int rows_per_strip,
                                                int waves_per_frame) {
+    if (nslow && *nslow == 0) return;                    // the fused kernel handed no frame on
     const int lane = threadIdx.x & 63;
     const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
     const int n = gw / waves_per_frame;
@@ -202,10 +204,10 @@ static void launch_morph(vbs_handle* h, int nb, const u32* only, hipStream_t s) 
     dim3 grid((waves + 3) / 4);
     if (h->bp.ns == 14)
         VBS_LAUNCH(h, s, "k_morph", k_morph<14>, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits, h->open_bits,
-                   only, nb, h->H, h->W, h->WW, G, strips, rps, wpf);
+                   only, only ? h->slow_total : nullptr, nb, h->H, h->W, h->WW, G, strips, rps, wpf);
     else
         VBS_LAUNCH(h, s, "k_morph", k_morph<8>, grid, dim3(256), 0, s, h->mask_bits, h->area_bits, h->band_bits, h->open_bits,
-                   only, nb, h->H, h->W, h->WW, G, strips, rps, wpf);
+                   only, only ? h->slow_total : nullptr, nb, h->H, h->W, h->WW, G, strips, rps, wpf);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -486,8 +488,9 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                                                 u32* __restrict__ band_first, u64* __restrict__ band_sums,
                                                 u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                 u32* __restrict__ fstat, const u8* __restrict__ lut_g,
-                                                const u32* __restrict__ slow_flag, unsigned short* __restrict__ probe_all,
-                                                int nb, int all, int H, int W, int WW, int maxm, int stop) {
+                                                const u32* __restrict__ slow_flag, const u32* __restrict__ nslow,
+                                                unsigned short* __restrict__ probe_all, int nb, int all, int H, int W, int WW,
+                                                int maxm, int stop) {
     __shared__ u32 parent[VBS_RUN_CAP];                // union-find parents; later [m=1] the moment accumulators
     __shared__ u64 bnd_w[16][64];                      // last row of every strip: words,
     __shared__ u32 bnd_base[16][64], bnd_cin[16][64];  //   first-node indices, entering nodes
@@ -501,6 +504,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     // frame through the four stages in turn - label the band mask, label the opened mask, fill its holes (if any),
     // relabel it (if any was filled) - and then writes the probes k_finalize's polygon test reads.  Every exit of a
     // stage's body is workgroup-uniform, so it is a `continue` of the stage loop.
+    if (nslow && *nslow == 0) return;                    // the fused kernel handed no frame on
     for (int n = blockIdx.x; n < nb; n += gridDim.x) {
     if (!all && !slow_flag[n]) continue;
     for (int stage = 0; stage < 4; ++stage) {
@@ -867,17 +871,19 @@ bool launch_stage(vbs_handle* h, int nb, hipStream_t s);  // false: geometry out
 // flagged frame and exit).  Geometries outside the fused path - and VBS_OPT_STAGE_IMPL = 1 - take the round-2 kernels:
 // k_morph over every frame, k_ccl<0|1>, the general kernel over what those hand on.
 void launch_labelling(vbs_handle* h, int nb, hipStream_t s) {
-    (void)hipMemsetAsync(h->slow_flag, 0, (size_t)nb * sizeof(u32), s);
+    (void)hipMemsetAsync(h->slow_total, 0, (size_t)(nb + 4) * sizeof(u32), s);     // the counter and the flags
     int all = 0;
+    const u32* nslow = nullptr;
     if (h->stage_impl == 0 && launch_stage(h, nb, s)) {
         launch_morph(h, nb, h->slow_flag, s);
+        nslow = h->slow_total;
     } else {
         launch_morph(h, nb, nullptr, s);
         all = launch_ccl(h, nb, s) ? 0 : 1;
     }
     VBS_LAUNCH(h, s, "k_label", k_label, dim3(nb < 64 ? nb : 64), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
                h->node_pos, h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first, h->area_sums, h->fstat,
-               h->lut, h->slow_flag, h->probe, nb, all, h->H, h->W, h->WW, h->maxm, VBS_KNOB("VBS_LABEL_STOP"));
+               h->lut, h->slow_flag, nslow, h->probe, nb, all, h->H, h->W, h->WW, h->maxm, VBS_KNOB("VBS_LABEL_STOP"));
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -1,9 +1,9 @@
 // a9-a13, fused fast path (marker_detection.py:170-196): band = mask & ~erode(mask) and the 5x5 opening of the area
 // mask, the connected components of both (4- / 8-connectivity) and the per-component sums k_finalize needs, in ONE
-// kernel per pass, one workgroup of 1024 threads per frame.  Nothing but the two input bit planes is read from memory
+// kernel per pass, one workgroup of 768 threads per frame.  Nothing but the two input bit planes is read from memory
 // and neither the band / opened planes nor any list of pixels or runs is written.
 //
-// A thread owns a SEGMENT OF A WORD COLUMN: word column j (64 px) x R consecutive rows (R = 22 at 1280x1024), and streams
+// A thread owns a SEGMENT OF A WORD COLUMN: word column j (64 px) x R consecutive rows (R = 29 at 1280x1024), and streams
 // down it: a row is loaded (a few rows ahead), passes through register delay lines and is labelled and summed on the spot;
 // no plane is ever held.  A wave holds G = 64 / WW row blocks side by side (lane = g * WW + j): the words left and right
 // of a lane's word are in the neighbouring lanes (DPP moves).  One rolled loop per plane.
@@ -34,10 +34,10 @@
 // says why): k_morph and k_label (k_label.hip) redo them.
 #include "ccl_common.h"
 
-#define ST_NT 1024
+#define ST_NT 768                  // threads per frame: 12 waves, three per SIMD, so that a thread may use 168 registers
 #define ST_MB_CAP 8                // probe requests a thread can hold (one per centroid, row and word)
 #define SG_KB 4                    // slots of the band walk (a ring crosses a tile as two arcs)
-#define SG_KO 2                    // slots of the opened-mask walk
+#define SG_KO 3                    // slots of the opened-mask walk
 #define SG_SEGMAX 8                // segments a thread can start; segment id = 8 tid + i
 #define SG_REC 2048                // segment records per frame
 #define SG_PQ 4096                 // segment pairs waiting to be united
@@ -50,7 +50,7 @@
 #define SLOW_VERTEX 5              // a contour vertex of multiplicity > 2
 
 struct StageGeom {
-    int H, W, WW, G, NB, R, maxm;   // G row blocks per wave, NB = 16 G row blocks of R rows
+    int H, W, WW, G, NB, R, maxm;   // G row blocks per wave, NB = 8 G row blocks of R rows
     u32 off_rec, off_bot, off_pq, off_mb, off_tmp;       // byte offsets into the dynamic LDS (segment parents at 0)
     u32 mrec_cap, mrec_stride;      // moment records per frame (global scratch), dwords between two frames' records
     int stop;                       // debug builds: leave after phase `stop`
@@ -185,6 +185,35 @@ __device__ __forceinline__ void seg_hlinks(const u64 (&pm)[K], const u32 (&sid)[
     p63 = s63; prs0 = rs0;
 }
 
+// exclusive prefix sum over the ST_NT threads; tmp holds >= 17 words
+__device__ __forceinline__ u32 st_scan(u32 v, u32* tmp, u32* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    if (wave == 0) {
+        const u32 t = lane < ST_NT / 64 ? tmp[lane] : 0u;
+        u32 ti = t;
+#pragma unroll
+        for (int d = 1; d < ST_NT / 64; d <<= 1) {
+            const u32 o = __shfl_up(ti, d);
+            if (lane >= d) ti += o;
+        }
+        if (lane < ST_NT / 64) tmp[lane] = ti - t;
+        if (lane == ST_NT / 64 - 1) tmp[16] = ti;
+    }
+    __syncthreads();
+    const u32 ex = inc - v + tmp[wave];
+    *total = tmp[16];
+    __syncthreads();
+    return ex;
+}
+
 // After a walk: the queued unions, then the components of the segments.  The roots (P[s] == s after flattening) are numbered, every segment's
 // entry becomes the number of its root (bit 15 marks the root), comp_pos[c] = first pixel of component c in raster order
 // (minimum over its segments' first pixels), cidmap[c] = rank of that pixel = the component's id.  Workgroup-uniform
@@ -207,7 +236,7 @@ __device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nse
     u32 nroot = 0;
     for (u32 i = 0; i < nseg; ++i) nroot += (P[sbase + i] == sbase + i);
     u32 ncomp;
-    u32 c0 = ccl_scan(nroot, tmp, &ncomp);
+    u32 c0 = st_scan(nroot, tmp, &ncomp);
     if (ncomp > limit) return NONE32;
     for (u32 i = 0; i < nseg; ++i)
         if (P[sbase + i] == sbase + i) { comp_pos[c0] = NONE32; P[sbase + i] = (unsigned short)(0x8000u | c0++); }
@@ -258,11 +287,12 @@ __device__ __forceinline__ void shift_moments_i64(const i64 (&m)[NMOM], i64 dx, 
 }
 
 template <int NS>
-__global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask_all, const u64* __restrict__ area_all,
+__global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask_all, const u64* __restrict__ area_all,
                                                     u32* __restrict__ ncomp_all, u64* __restrict__ band_sums,
                                                     u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                     unsigned short* __restrict__ probe_all, u32* __restrict__ fstat,
-                                                    u32* __restrict__ slow_flag, u32* __restrict__ mrec_all, StageGeom geo) {
+                                                    u32* __restrict__ slow_flag, u32* __restrict__ slow_total,
+                                                    u32* __restrict__ mrec_all, StageGeom geo) {
     extern __shared__ __align__(16) unsigned char smem[];
     unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [8 ST_NT] segment parents
     unsigned char* recb = smem + geo.off_rec;                                            // segment records
@@ -298,6 +328,9 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
     u32* comp_pos = reinterpret_cast<u32*>(botb);                                         // [1024] first pixel of a component
     unsigned short* cidmap = reinterpret_cast<unsigned short*>(botb + 4096);              // [1024] its rank = component id
     unsigned char* accb = botb + 4096 + 2048;                                            // band sums | anchors + moments
+    auto hand_on = [&](u32 why) {                        // (called by every thread, workgroup-uniformly)
+        if (tid == 0) { slow_flag[n] = why; atomicAdd(slow_total, 1u); }
+    };
     __syncthreads();
 
     // ================================ band plane ====================================================================
@@ -408,7 +441,7 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
         }
         if (fail) misc[6] = SLOW_SLOTS;
         __syncthreads();
-        if (misc[6]) { if (tid == 0) slow_flag[n] = (u32)misc[6]; return; }
+        if (misc[6]) { hand_on((u32)misc[6]); return; }
         if (geo.stop == 2) return;
         // the first row of the tile against the last row of the tile above (its runs are segments sbase + 0, 1, .. in order)
         if (hasu) {
@@ -428,8 +461,8 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
         const u32 nrec = (u32)misc[4];
         const u32 ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, comp_pos, cidmap, tmp,
                                       min((u32)maxm, 1024u), Q);
-        if (misc[5] > SG_PQ) { if (tid == 0) slow_flag[n] = SLOW_SLOTS; return; }
-        if (ncomp == NONE32) { if (tid == 0) slow_flag[n] = SLOW_NCOMP; return; }
+        if (misc[5] > SG_PQ) { hand_on(SLOW_SLOTS); return; }
+        if (ncomp == NONE32) { hand_on(SLOW_NCOMP); return; }
         if (geo.stop == 4) return;
         // ---- component sums (center_of_mass :181) ----------------------------------------------------------------------
         u32* acnt = reinterpret_cast<u32*>(accb);                                        // [maxm]
@@ -469,7 +502,7 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
         }
         if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; misc[0] = 0; misc[4] = 0; misc[5] = 0; }
         __syncthreads();
-        if (misc[6]) { if (tid == 0) slow_flag[n] = (u32)misc[6]; return; }      // a crowded mailbox
+        if (misc[6]) { hand_on((u32)misc[6]); return; }      // a crowded mailbox
         if (geo.stop == 10) return;
     }
 
@@ -495,9 +528,13 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
         u64 o1 = 0, o2 = 0;                              // the opened rows before the newest one
         u32 l1 = 0, l2 = 0, r1 = 0, r2 = 0;              // bit 63 of the word to the left / bit 0 of the word to the right in those rows
         // this thread's probe requests: which of its rows have any
-        u64 rowmask = 0;
+        u64 rowm[2] = {0, 0};                            // (R <= 128)
         const u32 nreq = min(mb_cnt[tid], (u32)ST_MB_CAP);
-        for (u32 q = 0; q < nreq; ++q) rowmask |= 1ull << ((mb_req[tid * ST_MB_CAP + q] >> 12) & 127u);
+        for (u32 q = 0; q < nreq; ++q) {
+            const u32 rr = (mb_req[tid * ST_MB_CAP + q] >> 12) & 127u;
+            if (rr < 64) rowm[0] |= 1ull << rr; else rowm[1] |= 1ull << (rr - 64);
+        }
+        auto row_asked = [&](int c) -> bool { return ((c < 64 ? rowm[0] >> c : rowm[1] >> (c - 64)) & 1ull) != 0; };
         u64 pm[SG_KO];
         u32 sid[SG_KO];
         int mo[SG_KO][NMOM];                             // vertex moments about the tile's centre
@@ -512,7 +549,7 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
         u64 firstB = 0;
         int e4 = 0;
         const int tch = R >> 1;
-        const int mthr = 900;                            // vertices (with multiplicity) an entry may hold: its sums stay below 2^31
+        const int mthr = R <= 64 ? 900 : 56;             // vertices (with multiplicity) an entry may hold: its sums stay below 2^31
         auto emit_mom = [&](u32 sid_, int (&m)[NMOM]) {
             const int r = atomicAdd(&misc[7], 1);
             if ((u32)r < geo.mrec_cap) {
@@ -575,7 +612,7 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
                     }
                 }
             }
-            if (c >= 0 && __any(o1 != 0ull || live || ((rowmask >> c) & 1ull))) {
+            if (c >= 0 && __any(o1 != 0ull || live || row_asked(c))) {
                 const u64 B = o1;
                 if (c == 0) firstB = B;
                 // ---- segments ---------------------------------------------------------------------------------------------
@@ -610,7 +647,7 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
                 }
                 seg_hlinks<SG_KO, true>(pm, sid, hasr, p63, prs0, la, lb, Q);
                 // ---- probes: the segment that holds a pixel of this row ---------------------------------------------------
-                if ((rowmask >> c) & 1ull) {
+                if (row_asked(c)) {
                     for (u32 qq = 0; qq < nreq; ++qq) {
                         const u32 rq = mb_req[tid * ST_MB_CAP + qq];
                         if (((rq >> 12) & 127u) != (u32)c) continue;
@@ -649,7 +686,7 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
 #undef ADDP
                     V1 &= B; V2 &= B; V3 &= B;
                     if (V3) why = SLOW_VERTEX;            // multiplicity > 2: impossible after a 5x5 opening; general path
-                    const int tc = c - tch, tc2 = __mul24(tc, tc), tc3 = __mul24(tc2, tc), tc4 = __mul24(tc2, tc2);
+                    const int tc = c - tch, tc2 = __mul24(tc, tc), tc3 = __mul24(tc2, tc), tc4 = tc2 * tc2;
 #pragma unroll
                     for (int k = 0; k < SG_KO; ++k) {
                         u64 vg = V1 & pm[k];
@@ -670,7 +707,7 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
                             m[3] += s2;                    m[4] += __mul24(s1, tc);       m[5] += __mul24(s0, tc2);
                             m[6] += s3;                    m[7] += __mul24(s2, tc);       m[8] += __mul24(s1, tc2);
                             m[9] += __mul24(s0, tc3);      m[10] += s4;                   m[11] += s3 * tc;
-                            m[12] += __mul24(s2, tc2);     m[13] += __mul24(s1, tc3);     m[14] += __mul24(s0, tc4);
+                            m[12] += __mul24(s2, tc2);     m[13] += __mul24(s1, tc3);     m[14] += s0 * tc4;
                         }
                     }
                 }
@@ -687,7 +724,7 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
         if (e4) atomicAdd(&misc[0], e4);
         if (why) misc[6] = (int)why;
         __syncthreads();
-        if (misc[6]) { if (tid == 0) slow_flag[n] = 16u + (u32)misc[6]; return; }
+        if (misc[6]) { hand_on(16u + (u32)misc[6]); return; }
         if (geo.stop == 12) return;
         // first row of the tile against the last row of the tile above, with the diagonal neighbours across the word edges
         if (hasu && firstB) {
@@ -713,10 +750,10 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
         const u32 nrec = (u32)misc[4];
         ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, comp_pos, cidmap, tmp,
                             min((u32)maxm, (u32)CCL_OPEN_COMPS), Q);
-        if (misc[5] > SG_PQ) { if (tid == 0) slow_flag[n] = 16u + SLOW_SLOTS; return; }
-        if (ncomp == NONE32) { if (tid == 0) slow_flag[n] = 16u + SLOW_NCOMP; return; }
+        if (misc[5] > SG_PQ) { hand_on(16u + SLOW_SLOTS); return; }
+        if (ncomp == NONE32) { hand_on(16u + SLOW_NCOMP); return; }
         if ((int)ncomp - misc[0] / 4 != 0) {             // holes: RETR_EXTERNAL needs the fill passes of the general path
-            if (tid == 0) slow_flag[n] = 16u + SLOW_HOLES;
+            hand_on(16u + SLOW_HOLES);
             return;
         }
     }
@@ -772,9 +809,9 @@ __global__ __launch_bounds__(ST_NT, 4) void k_stage(const u64* __restrict__ mask
 // false = geometry outside the fused path (the round-2 kernels take it)
 static bool stage_geom(const vbs_handle* h, StageGeom* g, size_t* lds_bytes) {
     if (h->W > 4096 || h->H > 2048 || h->maxm > 1024) return false;
-    const int G = 64 / h->WW, NB = 16 * G;               // (WW <= 64: vbs_create)
+    const int G = 64 / h->WW, NB = (ST_NT / 64) * G;     // (WW <= 64: vbs_create)
     const int R = (h->H + NB - 1) / NB;
-    if (R > 64 || R < 1) return false;                   // (row bit masks; int32 moments about the tile's centre)
+    if (R > 128 || R < 1) return false;                  // (row bit masks; int32 moments about the tile's centre)
     g->H = h->H; g->W = h->W; g->WW = h->WW; g->G = G; g->NB = NB; g->R = R; g->maxm = h->maxm;
     g->stop = VBS_KNOB("VBS_STAGE_STOP");
     const size_t NBW = (size_t)NB * h->WW;
@@ -817,7 +854,7 @@ static bool stage_launch_t(vbs_handle* h, int nb, const StageGeom& g, size_t lds
         h->stage_lds_set = lds;
     }
     VBS_LAUNCH(h, s, "k_stage", (k_stage<NS>), dim3(nb), dim3(ST_NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
-               h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, h->wbase, g);
+               h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, h->slow_total, h->wbase, g);
     return true;
 }
 
