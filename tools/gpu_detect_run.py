@@ -3,6 +3,9 @@ handed to rocprofv3 PMC passes (filter with --kernel-include-regex).  usage: gpu
 import os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vbs_amd.synth as S
+from vbs_amd import _lib as L
+if os.environ.get("VBS_LIB") == "dbg":                  # the library with the phase-timing knobs (VBS_STAGE_STOP, ..)
+    L.LIB_PATH = L.LIB_PATH.replace("libvbs.so", "libvbs_dbg.so")
 from vbs_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3

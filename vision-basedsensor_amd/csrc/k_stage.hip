@@ -219,8 +219,8 @@ __device__ __forceinline__ u32 st_scan(u32 v, u32* tmp, u32* total) {
 // (minimum over its segments' first pixels), cidmap[c] = rank of that pixel = the component's id.  Workgroup-uniform
 // return: components, or NONE32 when there are more than `limit`.
 __device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nseg, const unsigned short* rec_sid,
-                                           const u32* rec_pos, u32 nrec, u32* comp_pos, unsigned short* cidmap, u32* tmp,
-                                           u32 limit, const PairQ& Q) {
+                                           const u32* rec_pos, u32 nrec, const u32* seg_pos, u32* comp_pos,
+                                           unsigned short* cidmap, u32* tmp, u32 limit, const PairQ& Q) {
     const int tid = threadIdx.x;
     {
         const int np = min(*Q.n, SG_PQ);
@@ -246,7 +246,8 @@ __device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nse
         if (!(v & 0x8000u)) P[sbase + i] = (unsigned short)(P[v] & 0x7FFFu);
     }
     __syncthreads();
-    for (u32 r = tid; r < nrec; r += ST_NT) atomicMin(&comp_pos[P[rec_sid[r]] & 0x7FFFu], rec_pos[r]);
+    if (seg_pos) { for (u32 i = 0; i < nseg; ++i) atomicMin(&comp_pos[P[sbase + i] & 0x7FFFu], seg_pos[sbase + i]); }
+    else { for (u32 r = tid; r < nrec; r += ST_NT) atomicMin(&comp_pos[P[rec_sid[r]] & 0x7FFFu], rec_pos[r]); }
     __syncthreads();
     for (u32 c = tid; c < ncomp; c += ST_NT) {           // rank by first pixel (positions are distinct)
         const u32 p = comp_pos[c];
@@ -322,6 +323,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
     u32* rec_cnt = rec_pos + SG_REC;
     u32* rec_sx = rec_cnt + SG_REC;
     u32* rec_sy = rec_sx + SG_REC;
+    u32* seg_pos = reinterpret_cast<u32*>(recb);                                          // [8 ST_NT] opened mask: first pixel by segment id
     // last-row slots of every tile; the component tables take their place once the tiles are linked
     u64* bot_mask = reinterpret_cast<u64*>(botb);                                         // [K][NBW]
     unsigned short* bot_sid = reinterpret_cast<unsigned short*>(botb + (size_t)8 * SG_KB * NBW);   // [K][NBW]
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                 }
                 if (!done) fail = true;
             }
-            seg_hlinks<SG_KB, false>(pm, sid, hasr, p63, prs0, la, lb, Q);
+            if (__any(((B >> 63) | B) & 1ull)) seg_hlinks<SG_KB, false>(pm, sid, hasr, p63, prs0, la, lb, Q);    // (wave-uniform)
         }
 #pragma unroll
         for (int k = 0; k < SG_KB; ++k) {
@@ -459,7 +461,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         __syncthreads();
         if (geo.stop == 3) return;
         const u32 nrec = (u32)misc[4];
-        const u32 ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, comp_pos, cidmap, tmp,
+        const u32 ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, nullptr, comp_pos, cidmap, tmp,
                                       min((u32)maxm, 1024u), Q);
         if (misc[5] > SG_PQ) { hand_on(SLOW_SLOTS); return; }
         if (ncomp == NONE32) { hand_on(SLOW_NCOMP); return; }
@@ -632,11 +634,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                             if (mo[k][0]) emit_mom(sid[k], mo[k]);
                             if (nseg < SG_SEGMAX) {
                                 sid[k] = sbase + nseg; P[sbase + nseg] = (unsigned short)(sbase + nseg);
-                                const int rr = atomicAdd(&misc[4], 1);
-                                if (rr < SG_REC) {
-                                    rec_sid[rr] = (unsigned short)(sbase + nseg);
-                                    rec_pos[rr] = (u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
-                                } else why = SLOW_SLOTS;
+                                seg_pos[sbase + nseg] = (u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
                             } else why = SLOW_SLOTS;
                             ++nseg;
                             pm[k] = gg;
@@ -645,7 +643,8 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                     }
                     if (!done) why = SLOW_SLOTS;
                 }
-                seg_hlinks<SG_KO, true>(pm, sid, hasr, p63, prs0, la, lb, Q);
+                if (__any(((B >> 63) | B) & 1ull)) seg_hlinks<SG_KO, true>(pm, sid, hasr, p63, prs0, la, lb, Q);
+                else { p63 = NONE16; prs0 = NONE16; }    // (no pixel at a word edge in this row: nothing for the next row to meet)
                 // ---- probes: the segment that holds a pixel of this row ---------------------------------------------------
                 if (row_asked(c)) {
                     for (u32 qq = 0; qq < nreq; ++qq) {
@@ -747,8 +746,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         }
         __syncthreads();
         if (geo.stop == 13) return;
-        const u32 nrec = (u32)misc[4];
-        ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, comp_pos, cidmap, tmp,
+        ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), nullptr, nullptr, 0, seg_pos, comp_pos, cidmap, tmp,
                             min((u32)maxm, (u32)CCL_OPEN_COMPS), Q);
         if (misc[5] > SG_PQ) { hand_on(16u + SLOW_SLOTS); return; }
         if (ncomp == NONE32) { hand_on(16u + SLOW_NCOMP); return; }
