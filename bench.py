@@ -100,13 +100,17 @@ def _host_cpus():
 
 def cpu_baseline(spec, seed, cam, single_frames, max_workers, per_worker, warm=2):
     """BASELINE.md 3: (i) single process, default FFT/BLAS threading, fps over >= 32 frames after 2 warm-ups;
-    (ii) one worker process per physical core over disjoint frame ranges (bounded by the CPUs this job may use: a
-    one-GPU box grants a 16-CPU share of the host)."""
+    (ii) one worker process per physical core over disjoint frame ranges: min(physical cores, CPUs this process may run
+    on) workers; `max_workers` > 0 caps that (a shared box that grants fewer CPUs than its affinity mask shows), and the
+    record then says how many of the available cores were used."""
     import multiprocessing as mp
     import vbs_amd.synth as S
     from oracle import stages as O
     logical, physical, usable, model = _host_cpus()
-    workers = max(1, min(physical, usable, max_workers))
+    available = max(1, min(physical, usable))
+    workers = min(available, max_workers) if max_workers > 0 else available
+    for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):       # one worker = one core
+        os.environ.setdefault(var, "1")
     f0 = S.make_frames(spec, [0], seed=seed)[0]
     m0, a0 = O.find_markers(f0)
     ref = O.process_first_frame(O.marker_center(m0, a0), 5, "full", "optimal")
@@ -122,14 +126,15 @@ def cpu_baseline(spec, seed, cam, single_frames, max_workers, per_worker, warm=2
     wall = time.perf_counter() - t0
     busy = max(r[0] for r in res)
     total = sum(r[1] for r in res)
-    return {"value": round(total / busy, 3), "unit": "frames/s", "cores": workers, "kind": "port",
+    return {"value": round(total / busy, 3), "unit": "frames/s", "cores": workers, "cores_available": available, "kind": "port",
             "single_process": {"value": round(single_fps, 3), "frames": n_single, "warmup_frames": warm,
                                "threads": "default FFT/BLAS threading"},
             "host": {"logical_cpus": logical, "physical_cores": physical, "usable_cpus": usable, "model": model},
             "sample": f"oracle/stages.py end to end (find_markers+marker_center+track+3D) on the benchmark's "
                       f"{spec.width}x{spec.height} frames: single process {n_single} frames after {warm} warm-ups = "
-                      f"{single_fps:.3f} frames/s; {workers} worker processes (one per physical core this job may use: "
-                      f"{physical} physical / {usable} usable / {logical} logical CPUs) x {per_worker} frames after "
+                      f"{single_fps:.3f} frames/s; {workers} single-threaded worker processes on {available} available cores "
+                      f"(min of {physical} physical cores and {usable} CPUs in the affinity mask; {logical} logical"
+                      f"{', capped by --cpu-workers' if workers < available else ''}) x {per_worker} frames after "
                       f"{warm} warm-ups each = value; pool wall incl. spawn {wall:.1f}s"}
 
 
@@ -170,7 +175,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the BGR and host-path side measurements")
     ap.add_argument("--cpu-single-frames", type=int, default=32)
-    ap.add_argument("--cpu-workers", type=int, default=16, help="upper bound; one per physical core the job may use")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="0 (default) = one worker per physical core in the affinity mask (BASELINE.md 3); > 0 caps the workers")
     ap.add_argument("--cpu-frames-per-worker", type=int, default=3)
     ap.add_argument("--host-frames", type=int, default=512)
     ap.add_argument("--seed", type=int, default=0)

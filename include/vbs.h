@@ -42,6 +42,7 @@ extern "C" {
 #define VBS_FLAG_XYZ     2  /* table col 0 bit: the 3-D solve succeeded                           */
 #define VBS_DISP_COLS   5   /* flag, dX, dY, dZ, |d|                                              */
 #define VBS_PLANE_COLS  5   /* n_used, a, b, c, tilt_deg                                          */
+#define VBS_DEVPLANE_COLS 9 /* n_common, a, b, c, tilt_deg, mean k*dX, mean k*dY, mean k*dZ, mean |d| */
 
 typedef struct vbs_handle vbs_handle;
 
@@ -218,6 +219,19 @@ int vbs_displacement_f64(int device, const double* table, int n, int m_ref, int 
 /* fit_plane_least_squares (ForceDistribution.py:138-162): per frame Z = aX + bY + c over the rows
  * with VBS_FLAG_XYZ, tilt = atan(sqrt(a^2+b^2)) in degrees.  plane [dev] float32 [n,VBS_PLANE_COLS]. */
 int vbs_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane, void* stream);
+
+/* The deviation field and its plane (ForceDistribution.py: process_marker_data :168-208, visualize_deviations :218-243,
+ * :262-268, :274): for every marker with a 3-D point (VBS_FLAG_XYZ) in all four table rows - start / end of the vertical
+ * loading, start / end of the tilted one - deviation = (tilt_end - tilt_start) - (vert_end - vert_start) (:196-204); the
+ * plane Z = aX + bY + c is fitted over the END POINTS ref + scale * deviation (:229-243; shell_mode 0 = 'plane': Z starts
+ * at 0, 1 = 'shell': at the reference Z, :222), tilt = atan(sqrt(a^2 + b^2)); out also carries the mean of the scaled
+ * deviation vectors (:263) and the mean magnitude of the deviations (:274).
+ *   vert_start .. tilt_end [dev] float32 [m_ref][VBS_TABLE_COLS]: one frame's rows of a table each (same slot order)
+ *   ref_xyz [dev] float32 [m_ref][3] reference positions (the embedded MARKER_REF_DATA :29-95 in the reference)
+ *   deviation [dev] float32 [m_ref][4] = (1 | 0 common, dX, dY, dZ); out [dev] float32 [VBS_DEVPLANE_COLS] */
+int vbs_deviation_plane(vbs_handle* h, const float* vert_start, const float* vert_end, const float* tilt_start,
+                        const float* tilt_end, const float* ref_xyz, int m_ref, int shell_mode, double scale,
+                        float* deviation, float* out, void* stream);
 
 /* Frame-0 identity assignment on the device — `MarkerTracker._process_first_frame`
  * (marker_detection.py:275-347; inlined again at tracking.py:106-178): the marker nearest the mean is (0,0), the

@@ -775,6 +775,26 @@ def fit_plane(X, Y, Z) -> Tuple[float, float, float, float]:
     return float(a), float(b), float(c), float(np.degrees(np.arctan(np.sqrt(a * a + b * b))))
 
 
+def deviation_plane(vert_start, vert_end, tilt_start, tilt_end, ref_xyz, mode="plane", scale=1.0):
+    """Deviation field and its plane, `ForceDistribution.py`: `process_marker_data` :196-204 (deviation = d_tilt - d_vert
+    over the markers common to both loadings and the reference table), `visualize_deviations` :218-243 (end points =
+    reference position + scale * deviation, Z from 0 in 'plane' mode :222; plane over the END points), :263 (mean scaled
+    deviation), :274 (mean magnitude).  The four inputs are [M,4] arrays (present, X, Y, Z), one row per marker id.
+    Returns (common [M] bool, deviation [M,3], (a, b, c, tilt_deg), mean_vec [3], mean_mag)."""
+    vs, ve, ts, te = (np.asarray(t, dtype=np.float64) for t in (vert_start, vert_end, tilt_start, tilt_end))
+    ref = np.asarray(ref_xyz, dtype=np.float64)
+    common = (vs[:, 0] != 0) & (ve[:, 0] != 0) & (ts[:, 0] != 0) & (te[:, 0] != 0)
+    d_vert = ve[:, 1:4] - vs[:, 1:4]
+    d_tilt = te[:, 1:4] - ts[:, 1:4]
+    deviation = np.where(common[:, None], d_tilt - d_vert, 0.0)
+    z_start = ref[:, 2] if mode == "shell" else np.zeros_like(ref[:, 2])
+    end = np.stack([ref[:, 0], ref[:, 1], z_start], axis=1) + scale * deviation
+    plane = fit_plane(end[common, 0], end[common, 1], end[common, 2])
+    mean_vec = (scale * deviation[common]).mean(axis=0)
+    mean_mag = float(np.linalg.norm(deviation[common], axis=1).mean())
+    return common, deviation, plane, mean_vec, mean_mag
+
+
 # ------------------------------------------------------------------------------------------------
 # a2 / f3  frame undistortion                                      marker_detection.py:93-109 (cv2)
 # ------------------------------------------------------------------------------------------------

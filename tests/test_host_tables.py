@@ -125,3 +125,22 @@ def test_contour_lut_simple_shapes():
     line = np.zeros((5, 9), np.uint8)
     line[2, 1:8] = 1
     assert lut_vertices(line, lut) == {(1, 2): 1, (7, 2): 1}
+
+
+def test_moment_terms_of_the_24_bit_branch_fit_its_operand_range():
+    """`k_ccl<1>` / `k_label` form the contour-vertex moment terms with 24-bit multiplies (`v_mul_i32_i24`: operands are
+    sign-extended from 24 bits) while |dx|, |dy| <= 150.  With the largest multiplicity the vertex table holds, every
+    OPERAND the kernels form must stay below 2^23 and every product below 2^31 (the order of the factors in
+    `csrc/k_ccl.hip` is chosen for that: (mult dx) dy first, then x^2)."""
+    lut = (C.c_uint8 * 256)()
+    assert L.lib().vbs_contour_lut(lut) == 0
+    mult, d = max(lut), 150
+    assert mult == 4
+    operands = [mult * d,            # mx, my
+                d * d,               # x2, y2
+                mult * d * d,        # mx dx, my dy, mx dy, mult x2
+                ]
+    products = [mult * d ** 3,       # mx x2 (a result only: never an operand of a further 24-bit multiply)
+                mult * d ** 4]       # (mx dy) x2, (mult x2) x2, ...
+    assert max(operands) < 2 ** 23 and max(products) < 2 ** 31
+    assert mult * d ** 3 >= 2 ** 23  # which is why mx x2 must not be multiplied on: the association matters

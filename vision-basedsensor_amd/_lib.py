@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvbs.so")
 
 VBS_OK, VBS_EINVAL, VBS_ECAPACITY, VBS_EHIP, VBS_ENOMEM = 0, -1, -2, -3, -4
-DET_COLS, TABLE_COLS, DISP_COLS, PLANE_COLS = 6, 10, 5, 5
+DET_COLS, TABLE_COLS, DISP_COLS, PLANE_COLS, DEVPLANE_COLS = 6, 10, 5, 5, 9
 FLAG_TRACKED, FLAG_XYZ = 1, 2
 OPT_GRAY_COEFFS, OPT_FORCE_SEQ_MATCH, OPT_GRAY_SIDE_STREAM, OPT_NCC_MARGIN, OPT_STAGE_IMPL = 1, 2, 3, 4, 5
 
@@ -16,7 +16,7 @@ SYMBOLS = ("vbs_create", "vbs_destroy", "vbs_last_error", "vbs_version", "vbs_co
            "vbs_profile", "vbs_profile_read", "vbs_frame_stats", "vbs_undistort_points", "vbs_calculate_3d", "vbs_marker_center",
            "vbs_track", "vbs_solve3d", "vbs_track_to_3d", "vbs_displacement", "vbs_displacement_range", "vbs_displacement_f64",
            "vbs_plane_fit", "vbs_assign_ids", "vbs_set_option", "vbs_bgr2gray", "vbs_ncc_counters", "vbs_normxcorr2_general",
-           "vbs_stage_tables")
+           "vbs_stage_tables", "vbs_deviation_plane")
 
 
 class Camera(C.Structure):
@@ -75,6 +75,7 @@ def lib():
         "vbs_ncc_counters": (i32, [vp, vp, i32]),
         "vbs_normxcorr2_general": (i32, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp]),
         "vbs_stage_tables": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
+        "vbs_deviation_plane": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, vp, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)            # AttributeError here = stale library

@@ -286,6 +286,16 @@ struct GrayPipe {
         HIPCHK(h, hipEventRecord(h->ev_free[k & 1], s));
         return VBS_OK;
     }
+    // an error return in the middle of the passes: the conversion already running on the side stream is joined into `s`
+    // (an un-joined fork would break a caller's stream capture and leave a kernel writing the gray planes unordered
+    // against the next call); returns rc unchanged
+    int fail(int rc) {
+        if (on) {
+            (void)hipEventRecord(h->ev_gray[0], h->side);
+            (void)hipStreamWaitEvent(s, h->ev_gray[0], 0);
+        }
+        return rc;
+    }
 };
 
 extern "C" int vbs_find_markers(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
@@ -304,11 +314,11 @@ extern "C" int vbs_find_markers(vbs_handle* h, const uint8_t* frames, int n, int
     for (int k = 0; gp.pass_off(k) < n; ++k) {
         const int off = gp.pass_off(k), nb = gp.pass_len(k);
         const u8* plane;
-        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return rc;
+        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return gp.fail(rc);
         rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row,
                          mask ? mask + off * hw : nullptr, area_mask ? area_mask + off * hw : nullptr, nullptr, s, plane);
-        if (rc != VBS_OK) return rc;
-        if ((rc = gp.release(k)) != VBS_OK) return rc;
+        if (rc != VBS_OK) return gp.fail(rc);
+        if ((rc = gp.release(k)) != VBS_OK) return gp.fail(rc);
     }
     return VBS_OK;
 }
@@ -338,11 +348,11 @@ extern "C" int vbs_ncc_map(vbs_handle* h, const uint8_t* frames, int n, int chan
     for (int k = 0; gp.pass_off(k) < n; ++k) {
         const int off = gp.pass_off(k), nb = gp.pass_len(k);
         const u8* plane;
-        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return rc;
+        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return gp.fail(rc);
         rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr, nullptr,
                          ncc + off * hw, s, plane);
-        if (rc != VBS_OK) return rc;
-        if ((rc = gp.release(k)) != VBS_OK) return rc;
+        if (rc != VBS_OK) return gp.fail(rc);
+        if ((rc = gp.release(k)) != VBS_OK) return gp.fail(rc);
     }
     return VBS_OK;
 }
@@ -573,11 +583,11 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
     for (int k = 0; gp.pass_off(k) < n; ++k) {
         const int off = gp.pass_off(k), nb = gp.pass_len(k);
         const u8* plane;
-        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return rc;
+        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return gp.fail(rc);
         rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr, nullptr, nullptr,
                          s, plane);
-        if (rc != VBS_OK) return rc;
-        if ((rc = gp.release(k)) != VBS_OK) return rc;
+        if (rc != VBS_OK) return gp.fail(rc);
+        if ((rc = gp.release(k)) != VBS_OK) return gp.fail(rc);
         launch_labelling(h, nb, s);
         launch_finalize(h, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr,
                         counts ? counts + off : nullptr, s);
@@ -585,7 +595,7 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
             launch_track_fused(h, nb, ref_xy, m_ref, min_dist, table + (size_t)off * m_ref * VBS_TABLE_COLS, cam,
                                min_marker_size_px, s);
         rc = check_launch(h);
-        if (rc != VBS_OK) return rc;
+        if (rc != VBS_OK) return gp.fail(rc);
     }
     return VBS_OK;
 }
@@ -631,6 +641,21 @@ extern "C" int vbs_plane_fit(vbs_handle* h, const float* table, int n, int m_ref
     if (!table || !plane || n < 0 || m_ref < 1) { h->err = "vbs_plane_fit: bad argument"; return VBS_EINVAL; }
     HIPCHK(h, hipSetDevice(h->device));
     if (n) launch_plane_fit(h, table, n, m_ref, plane, (hipStream_t)stream);
+    return check_launch(h);
+}
+
+extern "C" int vbs_deviation_plane(vbs_handle* h, const float* vert_start, const float* vert_end, const float* tilt_start,
+                                   const float* tilt_end, const float* ref_xyz, int m_ref, int shell_mode, double scale,
+                                   float* deviation, float* out, void* stream) {
+    if (!h) return VBS_EINVAL;
+    if (!vert_start || !vert_end || !tilt_start || !tilt_end || !ref_xyz || !deviation || !out || m_ref < 1 ||
+        (shell_mode != 0 && shell_mode != 1)) {
+        h->err = "vbs_deviation_plane: bad argument";
+        return VBS_EINVAL;
+    }
+    HIPCHK(h, hipSetDevice(h->device));
+    launch_deviation_plane(h, vert_start, vert_end, tilt_start, tilt_end, ref_xyz, m_ref, shell_mode, scale, deviation, out,
+                           (hipStream_t)stream);
     return check_launch(h);
 }
 

@@ -141,6 +141,8 @@ void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, in
                          double min_size, double max_disp, int f0, int f1, float* disp, hipStream_t s);
 void launch_plane_fit(vbs_handle* h, const float* table, int n, int m_ref, float* plane,
                       hipStream_t s);
+void launch_deviation_plane(vbs_handle* h, const float* vs, const float* ve, const float* ts, const float* te, const float* ref,
+                            int m_ref, int shell, double scale, float* dev, float* out, hipStream_t s);
 void launch_assign_ids(vbs_handle* h, const double* det, const int32_t* count, int num_layers, int full_mode,
                        int32_t* ids_out, double* xy_out, int cap, int32_t* m_out, hipStream_t s);
 void make_contour_lut(u8 out[256]);

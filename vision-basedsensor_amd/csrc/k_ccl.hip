@@ -439,7 +439,8 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
             const int dy = y - (int)(fp >> 16), dx = x - (int)(fp & 0xFFFFu);
             u64* a = acc + cid * NMOM;
             atomicAdd(&a[0], (u64)mult);
-            if (max(abs(dx), abs(dy)) <= 150) {          // 4 * 150^4 < 2^31 and every factor < 2^24: 24-bit multiplies
+            if (max(abs(dx), abs(dy)) <= 150) {          // 24-bit multiplies: every OPERAND below 2^23 (|mult d^2| <= 4 * 150^2,
+                                                         // |d^2| <= 150^2), every product below 2^31 (4 * 150^4)
                 const int x2 = __mul24(dx, dx), y2 = __mul24(dy, dy), mx = __mul24(mult, dx), my = __mul24(mult, dy);
                 if (dx) {
                     atomicAdd(&a[1], (u64)(i64)mx);
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(CCL_NT, 8) void k_ccl(const u64* __restrict__ bits_
                     atomicAdd(&a[4], (u64)(i64)__mul24(mx, dy));
                     atomicAdd(&a[7], (u64)(i64)__mul24(my, x2));
                     atomicAdd(&a[8], (u64)(i64)__mul24(mx, y2));
-                    atomicAdd(&a[11], (u64)(i64)__mul24(__mul24(mx, x2), dy));
+                    atomicAdd(&a[11], (u64)(i64)__mul24(__mul24(mx, dy), x2));       // (mx x2 alone would pass 2^23 for mult >= 3)
                     atomicAdd(&a[12], (u64)(i64)__mul24(__mul24(mult, x2), y2));
                     atomicAdd(&a[13], (u64)(i64)__mul24(__mul24(mx, dy), y2));
                 }

@@ -5,6 +5,7 @@
 //   k_solve3d      3d_reconstruction.py:185-238 (_undistort_points, _calculate_3d_position)
 //   k_displacement 3d_reconstruction.py:240-316 (_track_markers)
 //   k_plane_fit    ForceDistribution.py:138-162 (fit_plane_least_squares)
+//   k_deviation_plane  ForceDistribution.py:168-208 (deviation field), :218-243 (end points + plane), :262-268, :274
 #include "common.h"
 
 struct CamD {
@@ -225,6 +226,71 @@ __global__ __launch_bounds__(64) void k_plane_fit(const float* __restrict__ tabl
             o[1] = o[2] = o[3] = o[4] = 0.f;
         }
     }
+}
+
+// The deviation field between a tilted and a vertical loading (process_marker_data :196-204) and the plane through its end
+// points (visualize_deviations :218-243): per marker present in all four rows, deviation = (tilt_end - tilt_start) -
+// (vert_end - vert_start); end point = reference position (Z = 0 in 'plane' mode :222) + scale * deviation; plane and tilt
+// over the end points as fit_plane_least_squares; mean scaled deviation (:263) and mean magnitude (:274).  One wave.
+__global__ __launch_bounds__(64) void k_deviation_plane(const float* __restrict__ vs, const float* __restrict__ ve,
+                                                        const float* __restrict__ ts, const float* __restrict__ te,
+                                                        const float* __restrict__ ref, int m_ref, int shell, double scale,
+                                                        float* __restrict__ dev, float* __restrict__ out) {
+    const int lane = threadIdx.x;
+    auto row_ok = [](const float* r) { return ((int)r[0] & VBS_FLAG_XYZ) != 0; };
+    double s[8] = {0, 0, 0, 0, 0, 0, 0, 0};              // n, end X, end Y, end Z, dX, dY, dZ, |d|
+    for (int r = lane; r < m_ref; r += 64) {
+        const float *a = vs + r * VBS_TABLE_COLS, *b = ve + r * VBS_TABLE_COLS, *c = ts + r * VBS_TABLE_COLS, *d = te + r * VBS_TABLE_COLS;
+        float* o = dev + r * 4;
+        if (row_ok(a) && row_ok(b) && row_ok(c) && row_ok(d)) {
+            const double dx = ((double)d[6] - c[6]) - ((double)b[6] - a[6]);
+            const double dy = ((double)d[7] - c[7]) - ((double)b[7] - a[7]);
+            const double dz = ((double)d[8] - c[8]) - ((double)b[8] - a[8]);
+            o[0] = 1.f; o[1] = (float)dx; o[2] = (float)dy; o[3] = (float)dz;
+            s[0] += 1;
+            s[1] += ref[r * 3 + 0] + scale * dx; s[2] += ref[r * 3 + 1] + scale * dy;
+            s[3] += (shell ? (double)ref[r * 3 + 2] : 0.0) + scale * dz;
+            s[4] += scale * dx; s[5] += scale * dy; s[6] += scale * dz;
+            s[7] += sqrt(dx * dx + dy * dy + dz * dz);
+        } else {
+            o[0] = o[1] = o[2] = o[3] = 0.f;
+        }
+    }
+    for (int q = 0; q < 8; ++q)
+        for (int off = 32; off >= 1; off >>= 1) s[q] += __shfl_xor(s[q], off);
+    const double cnt = s[0];
+    const double mxv = cnt > 0 ? s[1] / cnt : 0, myv = cnt > 0 ? s[2] / cnt : 0, mzv = cnt > 0 ? s[3] / cnt : 0;
+    __syncthreads();                                     // (dev[] rows written above are read again below)
+    double c[5] = {0, 0, 0, 0, 0};                       // xx, xy, yy, xz, yz of the end points (centred)
+    for (int r = lane; r < m_ref; r += 64) {
+        const float* o = dev + r * 4;
+        if (o[0] != 0.f) {
+            const double x = ref[r * 3 + 0] + scale * o[1] - mxv, y = ref[r * 3 + 1] + scale * o[2] - myv;
+            const double z = (shell ? (double)ref[r * 3 + 2] : 0.0) + scale * o[3] - mzv;
+            c[0] += x * x; c[1] += x * y; c[2] += y * y; c[3] += x * z; c[4] += y * z;
+        }
+    }
+    for (int q = 0; q < 5; ++q)
+        for (int off = 32; off >= 1; off >>= 1) c[q] += __shfl_xor(c[q], off);
+    if (lane == 0) {
+        const double det = c[0] * c[2] - c[1] * c[1];
+        out[0] = (float)cnt;
+        if (cnt >= 3 && fabs(det) > 1e-300) {
+            const double a = (c[3] * c[2] - c[4] * c[1]) / det, b = (c[4] * c[0] - c[3] * c[1]) / det;
+            out[1] = (float)a; out[2] = (float)b; out[3] = (float)(mzv - a * mxv - b * myv);
+            out[4] = (float)(atan(sqrt(a * a + b * b)) * 57.29577951308232);
+        } else {
+            out[1] = out[2] = out[3] = out[4] = 0.f;
+        }
+        out[5] = cnt > 0 ? (float)(s[4] / cnt) : 0.f; out[6] = cnt > 0 ? (float)(s[5] / cnt) : 0.f;
+        out[7] = cnt > 0 ? (float)(s[6] / cnt) : 0.f; out[8] = cnt > 0 ? (float)(s[7] / cnt) : 0.f;
+    }
+}
+
+void launch_deviation_plane(vbs_handle* h, const float* vs, const float* ve, const float* ts, const float* te, const float* ref,
+                            int m_ref, int shell, double scale, float* dev, float* out, hipStream_t s) {
+    VBS_LAUNCH(h, s, "k_deviation_plane", k_deviation_plane, dim3(1), dim3(64), 0, s, vs, ve, ts, te, ref, m_ref, shell, scale,
+               dev, out);
 }
 
 // float64 point interfaces: which = 0 undistort [n,2] -> [n,2]; which = 1 (u,v,d) [n,3] -> xyz [n,3], ok [n]

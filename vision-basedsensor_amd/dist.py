@@ -75,8 +75,11 @@ def gather_tables(local: torch.Tensor, n_total: int) -> torch.Tensor:
 class TableGather:
     """All-gather of the per-frame tables issued PASS BY PASS, so that the exchange of one internal pass overlaps the
     kernels of the next one (RCCL runs on its own stream; `async_op=True` only orders it after the pass that produced
-    the chunk).  Every rank's chunk lands directly in its frames' rows of the final [n_total, M, C] tensor - no
-    re-concatenation, also for ragged shards (a rank that has run out of frames contributes an empty-padded chunk).
+    the chunk).  Every pass is ONE `all_gather_into_tensor` into its own staging tensor [world x width, M, C] (each rank
+    pads its rows of the pass to the widest rank's, so ragged shards take the same collective); `finish` waits and copies
+    every rank's rows into its frames' rows of the final [n_total, M, C] tensor.  No tensor-list outputs: nothing relies on
+    how a backend flattens and copies them.  NOTE: this branch has run under gloo (CPU tensors, 2 ranks) and, through host
+    copies, with two ranks sharing one GPU; it has not yet run under RCCL on several GPUs (no multi-GPU box in this build).
 
         g = TableGather(n_total, M, C, device, chunk)
         for off in range(0, g.n_max, chunk):
@@ -90,8 +93,7 @@ class TableGather:
         self.spans = [shard_bounds(n_total, self.ws, r) for r in range(self.ws)]
         self.n_max = max(b - a for a, b in self.spans)
         self.out = torch.empty((n_total, m, cols), dtype=dtype, device=device)
-        self.works = []
-        self._keep = []
+        self.pending = []                               # (work, staging tensor, source kept alive, off, rows per rank)
         self.host = self.ws > 1 and td.get_backend() == "gloo" and torch.device(device).type == "cuda"
 
     def push(self, off: int, local: torch.Tensor):
@@ -104,36 +106,29 @@ class TableGather:
         width = max(cnt)
         if width == 0:
             return
-        even = all(c == width for c in cnt)
         src = local
         if local.shape[0] != width:                     # ragged end: pad to the pass width
             src = torch.zeros((width,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
             src[:local.shape[0]] = local
+        src = src.contiguous()
         if self.host:                                   # gloo rehearsal with device tensors: through the host, synchronous
-            parts = [torch.empty(src.shape, dtype=src.dtype) for _ in range(self.ws)]
-            td.all_gather(parts, src.cpu().contiguous())
-            for r, (ra, _) in enumerate(self.spans):
-                if cnt[r]:
-                    self.out[ra + off:ra + off + cnt[r]] = parts[r][:cnt[r]].to(self.out.device)
+            stage = torch.empty((self.ws * width,) + tuple(src.shape[1:]), dtype=src.dtype)
+            td.all_gather_into_tensor(stage, src.cpu())
+            self._scatter(stage.to(self.out.device), off, cnt)
             return
-        if even:
-            outs = [self.out[ra + off:ra + off + width] for ra, _ in self.spans]        # contiguous row blocks of the result
-            self.works.append(td.all_gather(outs, src.contiguous(), async_op=True))
-            self._keep.append(src)
-        else:
-            tmp = [torch.empty_like(src) for _ in range(self.ws)]
-            w = td.all_gather(tmp, src.contiguous(), async_op=True)
-            self.works.append(w)
-            self._keep.append((src, tmp, off, cnt))
+        stage = torch.empty((self.ws * width,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)       # rank-major
+        work = td.all_gather_into_tensor(stage, src, async_op=True)
+        self.pending.append((work, stage, src, off, cnt))
+
+    def _scatter(self, stage, off, cnt):
+        width = stage.shape[0] // self.ws
+        for r, (ra, _) in enumerate(self.spans):
+            if cnt[r]:
+                self.out[ra + off:ra + off + cnt[r]] = stage[r * width:r * width + cnt[r]]
 
     def finish(self) -> torch.Tensor:
-        for w in self.works:
-            w.wait()
-        for k in self._keep:
-            if isinstance(k, tuple):
-                _, tmp, off, cnt = k
-                for r, (ra, _) in enumerate(self.spans):
-                    if cnt[r]:
-                        self.out[ra + off:ra + off + cnt[r]] = tmp[r][:cnt[r]]
-        self.works, self._keep = [], []
+        for work, stage, _src, off, cnt in self.pending:
+            work.wait()
+            self._scatter(stage, off, cnt)
+        self.pending = []
         return self.out

@@ -276,6 +276,27 @@ class Engine:
         return plane
 
 
+    def deviation_plane(self, vert_start, vert_end, tilt_start, tilt_end, ref_xyz, mode="plane", scale=1.0):
+        """Deviation field between a tilted and a vertical loading and the plane through its end points
+        (`ForceDistribution.py:168-208,218-243`): four table rows [M,10] (one frame each), reference positions [M,3];
+        returns (deviation [M,4] = (common, dX, dY, dZ), out [9] = (n, a, b, c, tilt_deg, mean k dX, k dY, k dZ, mean |d|))."""
+        if mode not in ("plane", "shell"):
+            raise ValueError("mode must be 'plane' or 'shell'")
+        rows = [t.to(device=self.device, dtype=torch.float32).contiguous() for t in (vert_start, vert_end, tilt_start, tilt_end)]
+        m = rows[0].shape[0]
+        if any(tuple(t.shape) != (m, L.TABLE_COLS) for t in rows):
+            raise ValueError(f"table rows must be [M, {L.TABLE_COLS}]")
+        ref = torch.as_tensor(np.asarray(ref_xyz, dtype=np.float32).reshape(-1, 3), device=self.device).contiguous()
+        if ref.shape[0] != m:
+            raise ValueError("ref_xyz must hold one position per table slot")
+        dev = torch.empty((m, 4), dtype=torch.float32, device=self.device)
+        out = torch.empty((L.DEVPLANE_COLS,), dtype=torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.lib.vbs_deviation_plane(self._h, *(_ptr(t) for t in rows), _ptr(ref), m,
+                                                     1 if mode == "shell" else 0, float(scale), _ptr(dev), _ptr(out),
+                                                     self._stream()), "vbs_deviation_plane")
+        return dev, out
+
     # ---- a14 / f4 ------------------------------------------------------------------------------
     def assign_ids(self, det, counts, num_layers=5, id_mode="as_written"):
         """Frame-0 identities on the device: (ids int32 [M,2], ref_xy float64 [M,2]) as device tensors, in the

@@ -13,6 +13,9 @@ Differences a maintainer should know (all deliberate):
  * extra optional config keys: `id_mode` ("as_written" | "full"), `kmeans` ("optimal" | "sklearn"),
    `device` (GPU index), `batch` (frames per device batch), `gray_coeffs` (15 = OpenCV 4's BGR2GRAY fixed-point
    set, the default; 14 = the older set; identical on grey frames).
+ * a frame the device workspace cannot hold (more than 30720 runs in a mask, more than 1024 band components or more
+   than about 512 contours) RAISES with its frame number instead of being dropped; the rows of the batches before it are
+   written to the CSV first (`process`) / ride on the exception as `.rows` (`process_frames`).
 There is no CPU fallback: without a GPU or without the built library every compute call raises.
 """
 from __future__ import annotations
@@ -301,7 +304,15 @@ class MarkerTracker:
                 if ret:
                     buf.append(frame)
                 if buf and (len(buf) == batch or not ret):
-                    data.append(self._process_batch(np.stack(buf)))
+                    try:
+                        data.append(self._process_batch(np.stack(buf)))
+                    except Exception:
+                        # a frame the workspace cannot hold: the rows of the batches before it are not lost (the reference
+                        # would have written a CSV covering them too)
+                        if data:
+                            self._save_results(data)
+                        self._cleanup()
+                        raise
                     buf = []
                 if not ret:
                     break
@@ -317,7 +328,13 @@ class MarkerTracker:
         batch = int(self.config.get("batch", 256))
         data = []
         for s in range(0, frames.shape[0], batch):
-            data.append(self._process_batch(frames[s:s + batch]))
+            try:
+                data.append(self._process_batch(frames[s:s + batch]))
+            except Exception as e:
+                e.rows = _Rows(data)                    # what the batches before the failing frame produced
+                if getattr(self, "_frames", None) is not None and data:
+                    self._save_results(data)            # (called from `process`: keep the partial CSV)
+                raise
         return _Rows(data)
 
     def _process_batch(self, frames):
@@ -343,8 +360,10 @@ class MarkerTracker:
         if (counts < 0).any():                  # the reference would have emitted rows: never drop a frame silently
             from ._lib import VbsError
             bad = int(np.nonzero(counts < 0)[0][0])
-            raise VbsError(f"device status {int(counts[bad])} in frame {self.frame_count + bad} "
-                           f"(capacity exceeded: more runs / components than the workspace holds)")
+            raise VbsError(f"device status {int(counts[bad])} in frame {self.frame_count + bad}: the frame exceeds the "
+                           f"device workspace (more than 30720 runs in a mask, more than {eng.max_markers} band "
+                           f"components, or more than about 512 contours); rows of the batches before it are kept "
+                           f"(`.rows` of this exception / the partial CSV)")
         table = table.cpu().numpy()
         det = det.cpu().numpy()                 # float64 rows: the CSV keeps the reference's precision
         # all rows of the batch at once: (frame, slot) pairs in frame-major, reference-dict order

@@ -45,16 +45,17 @@ def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mo
 
 
 def track_and_gather(eng: Engine, frames_local: torch.Tensor, n_total: int, xy, min_dist=20.0, cam=None,
-                     min_marker_size_px=5.0):
+                     min_marker_size_px=5.0, pipelined=True):
     """This rank's frames through the fused path, one internal pass (`eng.max_batch` frames) at a time, the all-gather of
     each pass's rows issued as soon as the pass is enqueued (`dist.TableGather`): the exchange overlaps the next pass.
+    `pipelined=False`: all passes first, then the single `dist.gather_tables` collective (SURVEY 8e as written).
     Returns (local table [n_local, M, 10], counts [n_local], gathered table [n_total, M, 10])."""
     rank, ws = D.world()
     m = int(np.asarray(xy).reshape(-1, 2).shape[0])
     n_local = int(frames_local.shape[0])
-    if ws == 1:
+    if ws == 1 or not pipelined:
         local, _, counts = eng.track_to_3d(frames_local, xy, min_dist, cam, min_marker_size_px)
-        return local, counts, local
+        return local, counts, (local if ws == 1 else D.gather_tables(local, n_total))
     g = D.TableGather(n_total, m, L.TABLE_COLS, eng.device, eng.max_batch)
     a, _ = D.shard_bounds(n_total, ws, rank)
     counts = torch.zeros((n_local,), dtype=torch.int32, device=eng.device)
@@ -72,7 +73,7 @@ def track_and_gather(eng: Engine, frames_local: torch.Tensor, n_total: int, xy, 
 
 def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None, cam: L.Camera = None,
                 min_dist=20.0, min_marker_size_px=5.0, warmup_frames=0, max_displacement=50.0,
-                num_layers=5, id_mode="full", kmeans="optimal", with_plane=True) -> TrackResult:
+                num_layers=5, id_mode="full", kmeans="optimal", with_plane=True, pipelined=True) -> TrackResult:
     """One rank's part of a sequence of `n_total` frames (`frames_local` = this rank's contiguous block).
     `ref` = (ids, ref_xy) if already known; otherwise the rank holding frame 0 computes and broadcasts it."""
     rank, ws = D.world()
@@ -83,7 +84,7 @@ def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None,
         ids, xy = D.broadcast_reference(ids, xy, eng.device)
     else:
         ids, xy = ref
-    local, counts, table = track_and_gather(eng, frames_local, n_total, xy, min_dist, cam, min_marker_size_px)
+    local, counts, table = track_and_gather(eng, frames_local, n_total, xy, min_dist, cam, min_marker_size_px, pipelined)
     bad = torch.nonzero(counts < 0)            # (after the collective, so a failing rank cannot leave the others waiting in it)
     if bad.numel():
         f = int(bad[0].item())
@@ -98,3 +99,16 @@ def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None,
         if with_plane:
             plane = eng.plane_fit(local)
     return TrackResult(ids, xy, table, disp, plane, a, b, counts)
+
+
+def deviation_pose(eng: Engine, table_vert: torch.Tensor, table_tilt: torch.Tensor, ref_xyz, mode="plane", scale=1.0,
+                   start=0, end=-1):
+    """Pose misalignment from two tracked loadings (`ForceDistribution.py:168-208,218-243`): the displacement of every
+    marker between frames `start` and `end` of the vertical session's table and of the tilted session's, their difference
+    (the deviation field), the plane through reference position + scale * deviation and its tilt.  Both tables must use
+    the same slot order (the same frame-0 identities).  Returns a dict with `deviation` [M,4] (device tensor: common,
+    dX, dY, dZ), `n`, `a`, `b`, `c`, `tilt_deg`, `mean_vector` (scaled, as the reference plots it) and `mean_magnitude`."""
+    dev, out = eng.deviation_plane(table_vert[start], table_vert[end], table_tilt[start], table_tilt[end], ref_xyz, mode, scale)
+    o = out.cpu().numpy().astype(np.float64)
+    return {"deviation": dev, "n": int(o[0]), "a": o[1], "b": o[2], "c": o[3], "tilt_deg": o[4],
+            "mean_vector": o[5:8].copy(), "mean_magnitude": o[8]}
