@@ -12,7 +12,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-extras > $OUT/prof_$TAG.log 2>&1
 echo "collected stats $TAG"
-STAGE='k_morph|k_ccl|k_label|k_finalize'
+STAGE='k_stage|k_morph|k_ccl|k_label|k_finalize'
 for WL in c3 c5; do
   rocprofv3 --pmc FETCH_SIZE --kernel-include-regex "$STAGE" --output-format csv -d $OUT/pmc_fetch_${TAG}_$WL -- python3 $GRAFT_REPO_ROOT/tools/gpu_detect_run.py $FR 2 $WL > $OUT/pmc_fetch_${TAG}_$WL.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$STAGE" --output-format csv -d $OUT/pmc_write_${TAG}_$WL -- python3 $GRAFT_REPO_ROOT/tools/gpu_detect_run.py $FR 2 $WL > $OUT/pmc_write_${TAG}_$WL.log 2>&1

@@ -888,25 +888,39 @@ void launch_labelling(vbs_handle* h, int nb, hipStream_t s) {
 
 // ------------------------------------------------------------------------------------------------
 // fitEllipse from vertex moments (see oracle/stages.py:fit_ellipse for the algorithm being followed)
-__device__ bool solve_sym(double* A, double* b, int N) {   // Gaussian elimination, partial pivoting
+// Gaussian elimination with partial pivoting, fully unrolled: the row swap is a chain of predicated exchanges instead of
+// a run-time row index, so the system stays in registers (indexed by a run-time pivot row it lived in scratch memory:
+// 288 bytes per lane).  Same operations in the same order as the rolled form.
+template <int N>
+__device__ __forceinline__ bool solve_sym(double (&A)[N * N], double (&b)[N]) {
+#pragma unroll
     for (int c = 0; c < N; ++c) {
         int p = c;
         double best = fabs(A[c * N + c]);
+#pragma unroll
         for (int r = c + 1; r < N; ++r)
             if (fabs(A[r * N + c]) > best) { best = fabs(A[r * N + c]); p = r; }
         if (!(best > 1e-300)) return false;
-        if (p != c) {
-            for (int k = 0; k < N; ++k) { double t = A[c * N + k]; A[c * N + k] = A[p * N + k]; A[p * N + k] = t; }
-            double t = b[c]; b[c] = b[p]; b[p] = t;
-        }
+#pragma unroll
         for (int r = c + 1; r < N; ++r) {
-            double f = A[r * N + c] / A[c * N + c];
+            if (p == r) {
+#pragma unroll
+                for (int k = 0; k < N; ++k) { const double t = A[c * N + k]; A[c * N + k] = A[r * N + k]; A[r * N + k] = t; }
+                const double t = b[c]; b[c] = b[r]; b[r] = t;
+            }
+        }
+#pragma unroll
+        for (int r = c + 1; r < N; ++r) {
+            const double f = A[r * N + c] / A[c * N + c];
+#pragma unroll
             for (int k = c; k < N; ++k) A[r * N + k] -= f * A[c * N + k];
             b[r] -= f * b[c];
         }
     }
+#pragma unroll
     for (int c = N - 1; c >= 0; --c) {
         double v = b[c];
+#pragma unroll
         for (int k = c + 1; k < N; ++k) v -= A[c * N + k] * b[k];
         b[c] = v / A[c * N + c];
     }
@@ -914,15 +928,22 @@ __device__ bool solve_sym(double* A, double* b, int N) {   // Gaussian eliminati
 }
 
 // m[a][b] (a+b<=4) about a point shifted by (sx, sy): sum (x-sx)^a (y-sy)^b
-__device__ void shift_moments(const double in[5][5], double sx, double sy, double out[5][5]) {
+__device__ __forceinline__ void shift_moments(const double (&in)[5][5], double sx, double sy, double (&out)[5][5]) {
     const double C[5][5] = {{1, 0, 0, 0, 0}, {1, 1, 0, 0, 0}, {1, 2, 1, 0, 0}, {1, 3, 3, 1, 0}, {1, 4, 6, 4, 1}};
-    double px[5] = {1, -sx, sx * sx, -sx * sx * sx, sx * sx * sx * sx};
-    double py[5] = {1, -sy, sy * sy, -sy * sy * sy, sy * sy * sy * sy};
+    const double px[5] = {1, -sx, sx * sx, -sx * sx * sx, sx * sx * sx * sx};
+    const double py[5] = {1, -sy, sy * sy, -sy * sy * sy, sy * sy * sy * sy};
+    // (every loop has constant bounds and is unrolled: the tables stay in registers)
+#pragma unroll
     for (int a = 0; a <= 4; ++a)
-        for (int b = 0; a + b <= 4; ++b) {
+#pragma unroll
+        for (int b = 0; b <= 4; ++b) {
+            if (a + b > 4) continue;
             double v = 0;
-            for (int i = 0; i <= a; ++i)
-                for (int j = 0; j <= b; ++j) v += C[a][i] * C[b][j] * px[a - i] * py[b - j] * in[i][j];
+#pragma unroll
+            for (int i = 0; i <= 4; ++i)
+#pragma unroll
+                for (int j = 0; j <= 4; ++j)
+                    if (i <= a && j <= b) v += C[a][i] * C[b][j] * px[a - i] * py[b - j] * in[i][j];
             out[a][b] = v;
         }
 }
@@ -950,8 +971,11 @@ __device__ void fit_ellipse_moments(const i64* S, int ax, int ay, double* out) {
     double scale = 100.0 / (n * sqrt(r2) * 1.2732395447351628);
     double sp[5] = {1, scale, scale * scale, scale * scale * scale, scale * scale * scale * scale};
     double m[5][5];
+#pragma unroll
     for (int a = 0; a <= 4; ++a)
-        for (int b = 0; a + b <= 4; ++b) m[a][b] = M[a][b] * sp[a + b];
+#pragma unroll
+        for (int b = 0; b <= 4; ++b)
+            if (a + b <= 4) m[a][b] = M[a][b] * sp[a + b];
     double A[25] = {
         m[4][0],  m[2][2],  m[3][1],  -m[3][0], -m[2][1],
         m[2][2],  m[0][4],  m[1][3],  -m[1][2], -m[0][3],
@@ -961,7 +985,8 @@ __device__ void fit_ellipse_moments(const i64* S, int ax, int ay, double* out) {
     double g[5] = {-1e4 * m[2][0], -1e4 * m[0][2], -1e4 * m[1][1], 1e4 * m[1][0], 1e4 * m[0][1]};
     // conditioning guard, in the spirit of cv2's singular-value test (w[0]*FLT_EPSILON > w[4])
     double tr = A[0] + A[6] + A[12] + A[18] + A[24];
-    if (!solve_sym(A, g, 5)) return;
+    if (!solve_sym<5>(A, g)) return;
+#pragma unroll
     for (int i = 0; i < 5; ++i) if (!isfinite(g[i])) return;
     (void)tr;
     double det = 4.0 * g[0] * g[1] - g[2] * g[2];
@@ -972,7 +997,7 @@ __device__ void fit_ellipse_moments(const i64* S, int ax, int ay, double* out) {
     shift_moments(m, rp0, rp1, mu);
     double A3[9] = {mu[4][0], mu[2][2], mu[3][1], mu[2][2], mu[0][4], mu[1][3], mu[3][1], mu[1][3], mu[2][2]};
     double g3[3] = {mu[2][0], mu[0][2], mu[1][1]};
-    if (!solve_sym(A3, g3, 3)) return;
+    if (!solve_sym<3>(A3, g3)) return;
     const double min_eps = 1e-8;
     double ang = -0.5 * atan2(g3[2], g3[1] - g3[0]);
     double t;
