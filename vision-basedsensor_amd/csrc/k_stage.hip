@@ -144,7 +144,7 @@ __device__ __forceinline__ u64 seg_update(u64 B, u64 rB, const u64 (&pm)[K], con
 #pragma unroll
     for (int k = 0; k < K; ++k) {
         Rn[k] = 0;
-        if (!__any(pm[k] != 0ull)) continue;             // (wave-uniform)
+        if (k >= 2 && !__any(pm[k] != 0ull)) continue;   // (wave-uniform; slots 0 and 1 always run: their chains interleave)
         u64 adj = pm[k];
         if (C8) adj |= (adj << 1) | (adj >> 1);
         u64 Rk = fill_runs(B, rB, B & adj);
@@ -408,7 +408,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
 #pragma unroll
             for (int k = 0; k < SG_KB; ++k) {
                 const u64 Rk = Rn[k];
-                if (__any(Rk != 0ull)) {
+                if (k < 2 || __any(Rk != 0ull)) {
                     const u32 c = (u32)__popcll(Rk);
                     cnt[k] += c; sy[k] += c * y; sk[k] += sum_bitpos(Rk);
                 }
