@@ -85,6 +85,13 @@ int vbs_set_option(vbs_handle* h, int option, int value);
  * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain
  * direction d is foreground; 0=E,1=NE,2=N,...,7=SE). */
 int vbs_contour_lut(uint8_t out[256]);
+/* host-only helper: the body (no header line) of the tracker's CSV - `pandas.DataFrame(rows).to_csv(index=False)`,
+ * marker_detection.py:464-468 - for n rows of three int64 columns (frameno, row, col) and nf float64 columns (Ox, Oy, Cx,
+ * Cy, major_axis, minor_axis, angle), byte for byte: floats as Python's repr writes them (shortest digits that round-trip,
+ * exponent form below 1e-4 and from 1e16), NaN as an empty cell.  Formatted by `threads` host threads into buf.
+ * Returns the bytes written; a negative value -c when cap < c = the capacity that is always enough (n * (65 + 26 nf)). */
+int64_t vbs_format_csv(const int64_t* frameno, const int64_t* row, const int64_t* col, const double* const* fcols, int nf,
+                       int64_t n, char* buf, int64_t cap, int threads);
 /* host-only helpers exposing the constant tables the kernels use, so they can be checked without a
  * GPU: the fixed-point GaussianBlur taps (sum 256; marker_detection.py:118-124 via cv2) and the 1-D
  * factor g of the NCC template with stats = {mean(t), sum((t-mean)^2), l*l, 0.1^2}
@@ -105,7 +112,7 @@ int vbs_undistort_frames(vbs_handle* h, const uint8_t* frames, int n, int channe
 
 /* cv2.cvtColor(frame, COLOR_BGR2GRAY) (marker_detection.py:114) on its own: frames [dev] uint8 BGR (3 channels,
  * addressing as above) -> gray [dev] uint8 [n,h,w] dense, with the handle's coefficient set (VBS_OPT_GRAY_COEFFS).
- * (Stage entry for parity tests; the hot path converts inside the blur kernel's loader.) */
+ * (Stage entry for parity tests; on the hot path the same conversion kernel runs in front of the blur.) */
 int vbs_bgr2gray(vbs_handle* h, const uint8_t* frames, int n, int64_t stride_n, int64_t stride_row, uint8_t* gray,
                  void* stream);
 

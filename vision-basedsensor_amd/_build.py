@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvbs.so")
-SOURCES = ("api.hip", "k_blur.hip", "k_ncc.hip", "k_label.hip", "k_ccl.hip", "k_stage.hip", "k_solve.hip", "k_undistort.hip", "k_ids.hip")
+SOURCES = ("api.hip", "k_blur.hip", "k_ncc.hip", "k_label.hip", "k_ccl.hip", "k_stage.hip", "k_solve.hip", "k_undistort.hip", "k_ids.hip", "host_csv.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # k_ncc_mfma writes its packed float operations out by hand; the SLP vectoriser's own pairings on top of them cost
@@ -47,7 +47,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), suffix: st
             if verbose and warn:
                 print(warn, file=sys.stderr)
     if force or jobs or _stale(lib, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs)
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", lib] + objs)
     return lib
 
 

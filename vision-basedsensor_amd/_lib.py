@@ -16,7 +16,7 @@ SYMBOLS = ("vbs_create", "vbs_destroy", "vbs_last_error", "vbs_version", "vbs_co
            "vbs_profile", "vbs_profile_read", "vbs_frame_stats", "vbs_undistort_points", "vbs_calculate_3d", "vbs_marker_center",
            "vbs_track", "vbs_solve3d", "vbs_track_to_3d", "vbs_displacement", "vbs_displacement_range", "vbs_displacement_f64",
            "vbs_plane_fit", "vbs_assign_ids", "vbs_set_option", "vbs_bgr2gray", "vbs_ncc_counters", "vbs_normxcorr2_general",
-           "vbs_stage_tables", "vbs_deviation_plane")
+           "vbs_stage_tables", "vbs_deviation_plane", "vbs_format_csv")
 
 
 class Camera(C.Structure):
@@ -76,6 +76,7 @@ def lib():
         "vbs_normxcorr2_general": (i32, [i32, vp, i32, i32, vp, i32, i32, i32, vp, vp]),
         "vbs_stage_tables": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
         "vbs_deviation_plane": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, vp, vp]),
+        "vbs_format_csv": (i64, [vp, vp, vp, vp, i32, i64, vp, i64, i32]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)            # AttributeError here = stale library

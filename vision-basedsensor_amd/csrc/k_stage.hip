@@ -39,8 +39,8 @@
 #define SG_KB 4                    // slots of the band walk (a ring crosses a tile as two arcs)
 #define SG_KO 3                    // slots of the opened-mask walk
 #define SG_SEGMAX 8                // segments a thread can start; segment id = 8 tid + i
-#define SG_REC 2048                // segment records per frame
-#define SG_PQ 4096                 // segment pairs waiting to be united
+#define SG_REC 2048                // segment records per frame, at most (StageGeom::rec_cap)
+#define SG_PQ 4096                 // segment pairs waiting to be united, at most (StageGeom::pq_cap)
 #define NONE32 0xFFFFFFFFu
 // why a frame was handed on (slow_flag value)
 #define SLOW_SLOTS 1               // a tile needed more slots / segments / records than there are
@@ -53,6 +53,7 @@ struct StageGeom {
     int H, W, WW, G, NB, R, maxm;   // G row blocks per wave, NB = 8 G row blocks of R rows
     u32 off_rec, off_bot, off_pq, off_mb, off_tmp;       // byte offsets into the dynamic LDS (segment parents at 0)
     u32 mrec_cap, mrec_stride;      // moment records per frame (global scratch), dwords between two frames' records
+    u32 rec_cap, pq_cap, mom_comps; // LDS table sizes: band records, queued pairs, components per moment pass
     int stop;                       // debug builds: leave after phase `stop`
 };
 
@@ -129,10 +130,10 @@ __device__ __forceinline__ u32 sum_bitpos(u64 x) {
 
 // Segments found to belong together are only NOTED during a walk (a pair in an LDS queue, a handful of instructions where
 // it happens); the unions run densely, one pair per thread, once the walk is over.
-struct PairQ { u32* q; int* n; };
+struct PairQ { u32* q; int* n; int cap; };
 __device__ __forceinline__ void pq_push(const PairQ& Q, u32 a, u32 b) {
     const int i = atomicAdd(Q.n, 1);
-    if (i < SG_PQ) Q.q[i] = (a << 16) | b;               // (an overflowing queue hands the frame on: checked after the walk)
+    if (i < Q.cap) Q.q[i] = (a << 16) | b;               // (an overflowing queue hands the frame on: checked after the walk)
 }
 
 // One row of a labelling walk: Rn[k] = the runs of B that continue the segment in slot k (pm[k] = its pixels in the row
@@ -223,7 +224,7 @@ __device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nse
                                            unsigned short* cidmap, u32* tmp, u32 limit, const PairQ& Q) {
     const int tid = threadIdx.x;
     {
-        const int np = min(*Q.n, SG_PQ);
+        const int np = min(*Q.n, Q.cap);
         for (int i = tid; i < np; i += ST_NT) { const u32 pr = Q.q[i]; ccl_union(P, pr >> 16, pr & 0xFFFFu); }
     }
     __syncthreads();
@@ -299,7 +300,8 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
     unsigned char* recb = smem + geo.off_rec;                                            // segment records
     unsigned char* botb = smem + geo.off_bot;                                            // last-row slots | component tables
     PairQ Q;
-    Q.q = reinterpret_cast<u32*>(smem + geo.off_pq);                                      // [SG_PQ]
+    Q.q = reinterpret_cast<u32*>(smem + geo.off_pq);                                      // [pq_cap]
+    Q.cap = (int)geo.pq_cap;
     u32* mb_cnt = reinterpret_cast<u32*>(smem + geo.off_mb);                              // [ST_NT] probe requests
     u32* mb_req = mb_cnt + ST_NT;                                                         // [ST_NT][ST_MB_CAP]
     u32* tmp = reinterpret_cast<u32*>(smem + geo.off_tmp);                                // [32]
@@ -318,11 +320,12 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
     if (tid < 16) misc[tid] = 0;     // [0] Euler sum, [4] records, [5] queued pairs, [6] hand the frame on (why), [7] moment records
     mb_cnt[tid] = 0;
     const int64_t fo = (int64_t)n * H * WW;
-    unsigned short* rec_sid = reinterpret_cast<unsigned short*>(recb);                   // [SG_REC] records, by column
-    u32* rec_pos = reinterpret_cast<u32*>(recb + 2 * SG_REC);
-    u32* rec_cnt = rec_pos + SG_REC;
-    u32* rec_sx = rec_cnt + SG_REC;
-    u32* rec_sy = rec_sx + SG_REC;
+    const u32 rec_cap = geo.rec_cap;
+    unsigned short* rec_sid = reinterpret_cast<unsigned short*>(recb);                   // [rec_cap] records, by column
+    u32* rec_pos = reinterpret_cast<u32*>(recb + 2 * rec_cap);
+    u32* rec_cnt = rec_pos + rec_cap;
+    u32* rec_sx = rec_cnt + rec_cap;
+    u32* rec_sy = rec_sx + rec_cap;
     u32* seg_pos = reinterpret_cast<u32*>(recb);                                          // [8 ST_NT] opened mask: first pixel by segment id
     // last-row slots of every tile; the component tables take their place once the tiles are linked
     u64* bot_mask = reinterpret_cast<u64*>(botb);                                         // [K][NBW]
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         u64 firstB = 0;
         auto emit = [&](u32 sid_, u32 pos_, u32 cnt_, u32 sk_, u32 sy_) {
             const int r = atomicAdd(&misc[4], 1);
-            if (r < SG_REC) {
+            if ((u32)r < rec_cap) {
                 rec_sid[r] = (unsigned short)sid_; rec_pos[r] = pos_; rec_cnt[r] = cnt_;
                 rec_sx[r] = 64u * (u32)j * cnt_ + sk_; rec_sy[r] = sy_;
             } else fail = true;
@@ -463,7 +466,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         const u32 nrec = (u32)misc[4];
         const u32 ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, nullptr, comp_pos, cidmap, tmp,
                                       min((u32)maxm, 1024u), Q);
-        if (misc[5] > SG_PQ) { hand_on(SLOW_SLOTS); return; }
+        if (misc[5] > Q.cap) { hand_on(SLOW_SLOTS); return; }
         if (ncomp == NONE32) { hand_on(SLOW_NCOMP); return; }
         if (geo.stop == 4) return;
         // ---- component sums (center_of_mass :181) ----------------------------------------------------------------------
@@ -748,7 +751,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         if (geo.stop == 13) return;
         ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), nullptr, nullptr, 0, seg_pos, comp_pos, cidmap, tmp,
                             min((u32)maxm, (u32)CCL_OPEN_COMPS), Q);
-        if (misc[5] > SG_PQ) { hand_on(16u + SLOW_SLOTS); return; }
+        if (misc[5] > Q.cap) { hand_on(16u + SLOW_SLOTS); return; }
         if (ncomp == NONE32) { hand_on(16u + SLOW_NCOMP); return; }
         if ((int)ncomp - misc[0] / 4 != 0) {             // holes: RETR_EXTERNAL needs the fill passes of the general path
             hand_on(16u + SLOW_HOLES);
@@ -758,7 +761,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
     if (geo.stop == 14) return;
     // ---- the component's first pixel (the moments' origin) -------------------------------------------------------------
     u32* anchor = reinterpret_cast<u32*>(accb);                                          // [CCL_OPEN_COMPS]  (y << 16) | x
-    u64* acc = reinterpret_cast<u64*>(accb + 4 * CCL_OPEN_COMPS);                         // [CCL_MOM_COMPS][NMOM]
+    u64* acc = reinterpret_cast<u64*>(accb + 4 * CCL_OPEN_COMPS);                         // [mom_comps][NMOM]
     {
         u32* first = area_first + (int64_t)n * maxm;
         for (u32 c = tid; c < ncomp; c += ST_NT) {
@@ -767,11 +770,11 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
             first[cid] = pos;
         }
     }
-    // ---- segment moments -> component moments about its first pixel, 256 components per pass -----------------------------
+    // ---- segment moments -> component moments about its first pixel, `mom_comps` components per pass -----------------------------
     i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
     const u32 nmrec = (u32)misc[7];
-    for (u32 c0 = 0; c0 < ncomp; c0 += CCL_MOM_COMPS) {
-        const u32 nc = min((u32)CCL_MOM_COMPS, ncomp - c0);
+    for (u32 c0 = 0; c0 < ncomp; c0 += geo.mom_comps) {
+        const u32 nc = min(geo.mom_comps, ncomp - c0);
         for (u32 c = tid; c < nc * NMOM; c += ST_NT) acc[c] = 0;
         __syncthreads();
         for (u32 r = tid; r < nmrec; r += ST_NT) {
@@ -814,14 +817,19 @@ static bool stage_geom(const vbs_handle* h, StageGeom* g, size_t* lds_bytes) {
     g->stop = VBS_KNOB("VBS_STAGE_STOP");
     const size_t NBW = (size_t)NB * h->WW;
     auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
+    // table sizes (one workgroup per CU: the whole LDS is there to be used)
+    g->rec_cap = (u32)SG_REC;
+    g->pq_cap = (u32)SG_PQ;
+    g->mom_comps = (u32)CCL_MOM_COMPS;
     const size_t par = up16((size_t)ST_NT * SG_SEGMAX * 2);
-    const size_t rec = up16((size_t)SG_REC * 18);
+    size_t rec = up16((size_t)g->rec_cap * 18);
+    if (rec < (size_t)ST_NT * SG_SEGMAX * 4) rec = (size_t)ST_NT * SG_SEGMAX * 4;     // (the opened mask's first-pixel table)
     const size_t bot = up16((size_t)SG_KB * NBW * 10);
     const size_t acc_band = up16((size_t)(8 * ((h->maxm + 1) / 2)) + 16 * (size_t)h->maxm);
-    const size_t acc_open = up16((size_t)4 * CCL_OPEN_COMPS + (size_t)CCL_MOM_COMPS * NMOM * 8);
+    const size_t acc_open = up16((size_t)4 * CCL_OPEN_COMPS + (size_t)g->mom_comps * NMOM * 8);
     const size_t comp = 4096 + 2048 + (acc_band > acc_open ? acc_band : acc_open);
     const size_t botc = bot > comp ? bot : comp;
-    const size_t pq = (size_t)SG_PQ * 4, mb = (size_t)ST_NT * 4 * (1 + ST_MB_CAP), misc = 32 * 4 + 16 * 4;
+    const size_t pq = (size_t)g->pq_cap * 4, mb = (size_t)ST_NT * 4 * (1 + ST_MB_CAP), misc = 32 * 4 + 16 * 4;
     g->off_rec = (u32)par;
     g->off_bot = (u32)(par + rec);
     g->off_pq = (u32)(par + rec + botc);
