@@ -389,7 +389,12 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     // first / last strips of a row go through clamped 64-bit loads.
     const int wstart = xw + LO;                          // wave-uniform
     const int d0 = wstart >> 5, dsh = wstart & 31;
-    const bool wide = (d0 >= 0) && (d0 + 4 <= 2 * WW);
+    // (uniform conditions as INTEGERS behind an opaque move: as booleans the compiler keeps each of them - and every
+    //  bounds test of the clamped loads below, hoisted out of the step loop - as a 64-bit lane mask in two scalar
+    //  registers, which this kernel then spills and reloads with v_readlane in every step)
+    int wide_i = __builtin_amdgcn_readfirstlane(((d0 >= 0) && (d0 + 4 <= 2 * WW)) ? 1 : 0);
+    asm volatile("" : "+s"(wide_i));
+#define wide (wide_i != 0)
     uint4 nraw = make_uint4(0, 0, 0, 0);
     const u32* fb32 = reinterpret_cast<const u32*>(fbits) + d0;   // (uniform)
     auto load_rows = [&](int t) {
@@ -399,7 +404,9 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
             nraw = make_uint4(r32[0], r32[1], r32[2], r32[3]);
         } else {
             const u64* row = fbits + (int64_t)min(max(y, 0), H - 1) * WW;
-            u64 w0 = load_bits(row, WW, wstart), w1 = load_bits(row, WW, wstart + 64);
+            int ws = __builtin_amdgcn_readfirstlane(wstart);
+            asm volatile("" : "+s"(ws));                 // (its bounds tests are redone per step on the scalar unit, not kept)
+            u64 w0 = load_bits(row, WW, ws), w1 = load_bits(row, WW, ws + 64);
             nraw = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, 0u);
         }
     };
@@ -656,13 +663,14 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
             }
 #endif
             if (uw[0] | uw[1] | uw[2] | uw[3]) {         // rare: queue the tile (see drain)
-                u32 v = (u32)yo;
+                // (one lane writes the ten words: eight `lane == k` selects would each keep a 64-bit lane mask in two scalar
+                //  registers for the whole loop, and this kernel spills scalars as it is)
+                if (lane == 0) {
+                    u32* e = &sm.elist[wave][ecnt][0];
+                    e[0] = (u32)yo;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    v = lane == 2 + 2 * r ? (u32)uw[r] : v;
-                    v = lane == 3 + 2 * r ? (u32)(uw[r] >> 32) : v;
+                    for (int r = 0; r < 4; ++r) { e[2 + 2 * r] = (u32)uw[r]; e[3 + 2 * r] = (u32)(uw[r] >> 32); }
                 }
-                if (lane < 10) sm.elist[wave][ecnt][lane] = v;
                 ecnt++;
             }
             if (U8OUT) {
@@ -698,6 +706,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
         if (nexact) atomicAdd(&fstat[n * 8 + 3], nexact);
     }
 }
+#undef wide
 
 // Toeplitz fragments of k_ncc_mfma in the lane layout of v_mfma_f32_16x16x32_f16 (lane = 16 g + column, element j
 // pairs with the other operand's element j of the same g): weight index (32 s + 8 g + j) - column.  The same
