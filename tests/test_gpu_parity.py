@@ -872,6 +872,43 @@ def test_fused_stage_equals_separate_kernels():
         eng.close()
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (1024, 1280)])
+def test_stage_on_adverse_patterns(shape):
+    """Inputs far from marker frames - all ones, stripes one tile wide, blocks touching at their corners, dense noise, a comb
+    with hundreds of segments per column - through the fused labelling kernel and through the separate kernels: whatever
+    the fused kernel cannot take it must hand to the general kernel (never hang, never differ): same counts (or the same
+    capacity status) and the same detection rows."""
+    from vbs_amd.engine import Engine
+    h, w = shape
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:h, 0:w]
+    pats = [np.ones((h, w), bool), np.zeros((h, w), bool),
+            (xx // 64) % 2 == 0, (yy // 29) % 2 == 0,                      # stripes as wide / tall as a tile
+            ((xx // 8) + (yy // 8)) % 2 == 0,                               # 8x8 blocks touching at their corners
+            rng.random((h, w)) < 0.5, rng.random((h, w)) < 0.9,             # noise
+            ((xx % 12) < 6) & ((yy % 97) > 5),                               # a comb: many runs per word, tall teeth
+            (((xx - w // 2) ** 2 + (yy - h // 2) ** 2) < (min(h, w) // 2 - 3) ** 2)]    # one huge disc
+    n = len(pats)
+    area = np.stack([(p * 255).astype(np.uint8) for p in pats])
+    mask = np.stack([p.astype(np.uint8) for p in pats])
+    eng = Engine(h, w, max_markers=1024, max_batch=n)
+    mt, at = torch.from_numpy(mask).cuda(), torch.from_numpy(area).cuda()
+    out = []
+    for impl in (0, 1):
+        eng.set_option(L.OPT_STAGE_IMPL, impl)
+        det, counts = eng.marker_center(mt, at)
+        torch.cuda.synchronize()
+        out.append((det.clone(), counts.clone()))
+    eng.set_option(L.OPT_STAGE_IMPL, 0)
+    (d0, c0), (d1, c1) = out
+    assert torch.equal(c0, c1), (c0.tolist(), c1.tolist())
+    for i in range(n):
+        k = max(int(c0[i]), 0)
+        assert torch.equal(d0[i, :k], d1[i, :k]), i
+    assert int(c0[1]) == 0 and int(c0[0]) >= 0                              # empty frame: nothing; all ones: one component at most
+    eng.close()
+
+
 def test_smallest_opened_components_fit_without_the_degenerate_branch():
     """`cv2.fitEllipse` re-fits a degenerate point set (collinear, .. : singular design matrix) after nudging the points by
     +-eps in an order-dependent pattern; the HIP path fits from contour-vertex moments, which cannot express that, and
