@@ -50,7 +50,7 @@
 #define SLOW_VERTEX 5              // a contour vertex of multiplicity > 2
 
 struct StageGeom {
-    int H, W, WW, G, NB, R, maxm;   // G row blocks per wave, NB = 8 G row blocks of R rows
+    int H, W, WW, G, NB, R, maxm;   // G row blocks per wave, NB = 12 G row blocks of R rows
     u32 off_rec, off_bot, off_pq, off_mb, off_tmp;       // byte offsets into the dynamic LDS (segment parents at 0)
     u32 mrec_cap, mrec_stride;      // moment records per frame (global scratch), dwords between two frames' records
     u32 rec_cap, pq_cap, mom_comps; // LDS table sizes: band records, queued pairs, components per moment pass
@@ -694,15 +694,21 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                         u64 vg = V1 & pm[k];
                         if (!__any(vg != 0ull)) continue;
                         if (vg) {
-                            // row sums s_a = sum mult dx^a about the word's centre (24-bit multiplies)
+                            // row sums s_a = sum mult dx^a about the word's centre (24-bit multiplies), the two halves of the
+                            // word in turn (32-bit bit scans); a vertex of multiplicity 2 is simply visited twice
                             int s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
-                            while (vg) {
-                                const int kb = __ffsll((long long)vg) - 1;
-                                vg &= vg - 1;
-                                const int dx = kb - 32, two = (int)((V2 >> kb) & 1ull);
-                                const int mx = two ? 2 * dx : dx, x2 = __mul24(dx, dx), mxx = __mul24(mx, dx);
-                                s0 += 1 + two; s1 += mx; s2 += mxx; s3 += __mul24(mx, x2); s4 += __mul24(mxx, x2);
-                            }
+                            auto half = [&](u32 bits, int base) {
+                                while (bits) {
+                                    const int dx = __ffs((int)bits) - 1 + base;
+                                    bits &= bits - 1u;
+                                    const int x2 = __mul24(dx, dx);
+                                    s0 += 1; s1 += dx; s2 += x2; s3 += __mul24(x2, dx); s4 += __mul24(x2, x2);
+                                }
+                            };
+                            half((u32)vg, -32);
+                            half((u32)(vg >> 32), 0);
+                            const u64 v2 = vg & V2;
+                            if (v2) { half((u32)v2, -32); half((u32)(v2 >> 32), 0); }
                             int (&m)[NMOM] = mo[k];
                             if (m[0] > mthr) emit_mom(sid[k], m);
                             m[0] += s0;                    m[1] += s1;                    m[2] += __mul24(s0, tc);
