@@ -74,12 +74,16 @@ int vbs_version(void);
  * (never below the 20 the error bound needs); a wide margin sends thousands of pixels per frame through the queued
  * float64 re-evaluation.  VBS_OPT_STAGE_IMPL (test hook / fallback, results identical): 0 (default) runs band / open /
  * labelling / sums of `_marker_center` (:170-196) in the fused kernel (k_stage.hip) where the frame geometry allows it,
- * 1 always runs the separate kernels (k_morph + k_ccl) that other geometries take. */
+ * 1 always runs the separate kernels (k_morph + k_ccl) that other geometries take.  VBS_OPT_BLUR_IMPL (test hook /
+ * fallback, results identical): 0 (default) runs the two GaussianBlurs (:118-129) on 16-column strips (k_blur16) where the
+ * frame allows it (large branch, width a multiple of 4, rows that load as aligned dwords), 1 always runs the 32-column
+ * kernel (k_blur_mfma) that every other frame takes. */
 #define VBS_OPT_GRAY_COEFFS      1
 #define VBS_OPT_FORCE_SEQ_MATCH  2
 #define VBS_OPT_GRAY_SIDE_STREAM 3
 #define VBS_OPT_NCC_MARGIN       4
 #define VBS_OPT_STAGE_IMPL       5
+#define VBS_OPT_BLUR_IMPL        6
 int vbs_set_option(vbs_handle* h, int option, int value);
 /* host-only helper: the 256-entry table that classifies a border pixel's 8-neighbourhood into the
  * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain

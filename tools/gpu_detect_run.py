@@ -13,6 +13,8 @@ wl = sys.argv[3] if len(sys.argv) > 3 else "c3"
 spec = S.config2() if wl == "c3" else S.config5()
 eng = Engine(spec.height, spec.width, max_markers=512 if wl == "c3" else 1024, max_batch=n)
 ft = S.make_frames_torch(spec, range(n), seed=0, device="cuda")
+if os.environ.get("BLUR_IMPL"):
+    eng.set_option(L.OPT_BLUR_IMPL, int(os.environ["BLUR_IMPL"]))
 torch.cuda.synchronize()
 for _ in range(reps):
     table, det, counts = eng.track_to_3d(ft)

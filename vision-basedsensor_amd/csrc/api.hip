@@ -139,7 +139,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     bp.ncc_hi = (bp.ncc_l - 1) / 2;
     if (height <= bp.taps_b / 2 + 4 || width <= bp.taps_b / 2 + 4) { h->err = "frame smaller than the blur radius"; return VBS_EINVAL; }
     ncc_consts(bp.ncc_l, ts, &h->ncc);
-    std::vector<u32> frags;
+    std::vector<u32> frags, frags16h, frags16v;
     {   // the int8 matrix-core blur needs taps < 128 that sum to 256 (true for every sigma >= 1)
         std::vector<int> ka = gaussian_taps_q8(bp.taps_a, sa), kb = gaussian_taps_q8(bp.taps_b, sb);
         int suma = 0, sumb = 0, mx = 0;
@@ -147,6 +147,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
         for (int v : kb) { sumb += v; mx = std::max(mx, v); }
         if (suma != 256 || sumb != 256 || mx > 127) { h->err = "internal: blur taps do not fit int8"; return VBS_EINVAL; }
         frags = bp.small ? blur_mfma_fragments(ka, kb, 3, 0, 3) : blur_mfma_fragments(ka, kb, 5, 1, 3);
+        if (!bp.small && width >= 128 && (width & 3) == 0) blur16_fragments(ka, kb, width, &frags16h, &frags16v);
     }
 
     const size_t B = (size_t)max_batch, HW = (size_t)height * h->WW, HP = (size_t)height * h->P;
@@ -168,6 +169,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     h->slow_flag = h->slow_total + 4;                    // (one memset clears both)
     ALLOC(lut, 256);
     ALLOC(blur_frags, frags.size() / 4);
+    if (!frags16h.empty()) { ALLOC(blur16_h, frags16h.size() / 4); ALLOC(blur16_v, frags16v.size() / 4); }
     std::vector<u32> nfrags = ncc_mfma_fragments(h->ncc, bp.ncc_l);
     ALLOC(ncc_frags, nfrags.size() / 4);
     ALLOC(ncc_tab, (size_t)2 * VBS_NCC_MAXL + 1);
@@ -191,6 +193,10 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     HIPCHK(h, hipMemcpy(h->ncc_ry, ry.data(), height * sizeof(double), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->lut, lut, 256, hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->blur_frags, frags.data(), frags.size() * sizeof(u32), hipMemcpyHostToDevice));
+    if (h->blur16_h) {
+        HIPCHK(h, hipMemcpy(h->blur16_h, frags16h.data(), frags16h.size() * sizeof(u32), hipMemcpyHostToDevice));
+        HIPCHK(h, hipMemcpy(h->blur16_v, frags16v.data(), frags16v.size() * sizeof(u32), hipMemcpyHostToDevice));
+    }
     HIPCHK(h, hipMemcpy(h->ncc_frags, nfrags.data(), nfrags.size() * sizeof(u32), hipMemcpyHostToDevice));
     {
         std::vector<float2> rowf(height);
@@ -388,6 +394,10 @@ extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
         case VBS_OPT_STAGE_IMPL:
             if (value != 0 && value != 1) break;
             h->stage_impl = value;
+            return VBS_OK;
+        case VBS_OPT_BLUR_IMPL:
+            if (value != 0 && value != 1) break;
+            h->blur_impl = value;
             return VBS_OK;
         case VBS_OPT_GRAY_COEFFS:
             if (value != 14 && value != 15) break;

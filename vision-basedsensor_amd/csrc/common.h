@@ -60,6 +60,9 @@ struct vbs_handle {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_gray[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
     uint4* blur_frags; // Toeplitz operand fragments of k_blur_mfma (blur_mfma_fragments)
+    uint4* blur16_h = nullptr;   // k_blur16: horizontal fragments per 16-column strip (blur16_fragments); null = not built
+    uint4* blur16_v = nullptr;   // k_blur16: the 12 vertical fragment variants
+    int blur_impl = 0;           // vbs_set_option(VBS_OPT_BLUR_IMPL): 0 k_blur16 where it applies, 1 always k_blur_mfma
     u64* area_bits;    // [maxb][H][WW]
     u64* mask_bits;    // [maxb][H][WW]
     u64* band_bits;    // [maxb][H][WW]
@@ -149,6 +152,8 @@ void make_contour_lut(u8 out[256]);
 std::vector<u32> ncc_mfma_fragments(const NccConst& nc, int l);
 std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::vector<int>& taps_b, int nk,
                                      int sa0, int nka);
+void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& taps_l, int W, std::vector<u32>* hfrag,
+                      std::vector<u32>* vfrag);
 void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s);
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s);

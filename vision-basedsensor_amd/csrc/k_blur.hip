@@ -400,6 +400,276 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 }
 
 
+// ---- strips of 16 columns ---------------------------------------------------------------------------
+// The same two products on v_mfma_i32_16x16x64_i8, one wave per 16-column strip sliding down 16 rows per step, for
+// the large branch (101 / 39 taps) on frames whose rows can be loaded as aligned dwords.  Against k_blur_mfma:
+//   * the image rows go straight from memory into the A operand (lane = row, 16 consecutive bytes): no staging in LDS and
+//     no workgroup barrier; the waves of a workgroup only share the table of vertical fragments
+//   * a 16 + 100 pixel window fits K = 128 (32-column strips: 160) and a 16 + 100 row window eight 16-row tiles
+//     (32-row tiles: five of 32), so a quarter of the matrix work on the Toeplitz zero band is gone
+//   * the ring of horizontal tiles is 8 + 4 dwords per byte plane instead of 80 registers: 128 registers per lane,
+//     4 waves per SIMD instead of 2
+//   * reflect-101 at the left / right border is folded into the strip's own horizontal fragments (a pixel that the
+//     border mirrors onto carries the sum of the taps that reach it; the window is shifted to stay inside the row), so
+//     there is no byte-wise gather at the image border
+//   * the vertical result has the column on the lane and four rows in registers: the range test is one subtraction
+//     of byte 2 and one compare per register, whose lane mask IS 4 rows x 16 mask bits
+// Window of strip xw: pixels [L0, L0 + 128), L0 = xw - 56 clamped to [0, W - 128]; operand P = window bytes 0..31 and
+// 96..127, operand Q = bytes 32..95 (all the 39-tap kernel needs away from the border).  Horizontal tile t = rows
+// Y0 - 56 + 16 t ..: the output tile of step t (rows Y0 + 16 (t - 7) ..) reads tiles t-7 .. t of the large kernel and tiles
+// t-5 .. t-2 of the small one.  Ring slot = t mod 8 (mod 4), the step loop is unrolled by 8, and what changes with the
+// phase is the vertical fragment: 8 + 4 variants in LDS.
+#define B16_RL 50
+#define B16_RS 19
+#define B16_LEFT 56
+typedef u32 u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+
+__device__ __forceinline__ void pack16(const v4i& acc, int& hi, int& lo) {
+    const u32 t01 = __builtin_amdgcn_perm((u32)acc[1], (u32)acc[0], 0x05010400u);
+    const u32 t23 = __builtin_amdgcn_perm((u32)acc[3], (u32)acc[2], 0x05010400u);
+    lo = (int)(__builtin_amdgcn_perm(t23, t01, 0x05040100u) ^ 0x80808080u);
+    hi = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
+}
+
+template <bool U8OUT>
+__global__ __launch_bounds__(256, 4) void k_blur16(const u8* __restrict__ gray, int64_t gstride_n, int gstride_row,
+                                                   const uint4* __restrict__ hfrag, const uint4* __restrict__ vfrag,
+                                                   u64* __restrict__ bits, u8* __restrict__ area_u8,
+                                                   u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
+                                                   int k3, int k8, int span_i, int nframes, int gx, int gy) {
+    __shared__ uint4 vf[12 * 64];
+    __shared__ uint4 stg[4][128];                        // per wave: 16 rows x 128 window bytes
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, q = lane & 15;
+    // Workgroups are dealt round-robin over the 8 XCDs (observed, not promised: it only matters for speed).  With many
+    // frames in the launch, workgroup b works on frame 8 (b / 8 / per_frame) + b % 8: the workgroups of one frame - whose
+    // windows overlap, 176 bytes of a row per 64 columns - then share one XCD's L2 and the frame crosses the fabric
+    // once, not 2.75 times (1.41 -> 1.25 us per frame; with every row already in L2 the kernel takes 0.9).  (k_blur_mfma,
+    // whose 128-column workgroups re-read less, measured the same either way.)
+    int n, bx, by;
+    if (nframes) {
+        const int b = blockIdx.x, per = gx * gy, j = b >> 3;
+        n = 8 * (j / per) + (b & 7);
+        const int w = j % per;
+        bx = w % gx; by = w / gx;
+        if (n >= nframes) return;
+    } else { n = blockIdx.z; bx = blockIdx.x; by = blockIdx.y; }
+    const int tilesY = (H + 15) / 16;
+    const int tile0 = by * tiles_per_seg;
+    const int ntiles = min(tiles_per_seg, tilesY - tile0);
+    if (ntiles <= 0) return;
+    for (int i = tid; i < 12 * 64; i += 256) vf[i] = vfrag[i];
+    __syncthreads();                                     // (the only barrier)
+    const int strip = bx * 4 + wave, xw = 16 * strip;
+    const int Y0 = tile0 * 16, nsteps = ntiles + 7;
+    if (xw >= W) {                                       // (uniform) a strip in the padding of the last mask word: zeros
+        if (xw < 64 * WW)
+            for (int y = Y0 + lane; y < min(Y0 + 16 * ntiles, H); y += 64)
+                reinterpret_cast<unsigned short*>(bits)[((int64_t)n * H + y) * WW * 4 + strip] = 0;
+        return;
+    }
+    const int L0 = min(max(xw - B16_LEFT, 0), W - 128);
+    const bool edge = L0 != xw - B16_LEFT;               // (uniform) the 39-tap window is not all inside Q
+    v4i lp, lq, sq, sp = {0, 0, 0, 0};
+    {
+        const uint4* hf = hfrag + (size_t)strip * 4 * 64 + lane;
+        const uint4 a = hf[0], b = hf[64], c = hf[128];
+        lp = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+        lq = v4i{(int)b.x, (int)b.y, (int)b.z, (int)b.w};
+        sq = v4i{(int)c.x, (int)c.y, (int)c.z, (int)c.w};
+        if (edge) { const uint4 d = hf[192]; sp = v4i{(int)d.x, (int)d.y, (int)d.z, (int)d.w}; }
+    }
+    // Rows travel memory -> registers -> this wave's 2 KB of LDS -> operand: loaded with four consecutive lanes on 64
+    // consecutive bytes of one row (lane = 4 row + piece; a lane per row and piece of the OPERAND layout, lane = 16 piece +
+    // row, puts every lane of a quad on another cache line: 1.9 us per frame against 1.3), read back one row per lane.
+    // 16-byte piece p of row r sits at slot p ^ f(r): eight consecutive lanes cover all 32 banks on the way in (two
+    // rows x four pieces) and on the way out (eight rows, one piece).
+    const u8* g0 = gray + (int64_t)n * gstride_n + L0;   // (uniform)
+    const int lr = lane >> 2, lc = lane & 3;
+    auto fsw = [](int r) { return ((r & 1) << 2) | ((r >> 1) & 3); };
+    u8* const stw = reinterpret_cast<u8*>(&stg[wave][0]);
+    // a lane loads pieces lc and lc + 4 of its row (window bytes 16 lc .. and 64 + 16 lc ..: one address, two loads);
+    // operand P = pieces 0, 1, 6, 7 and operand Q = pieces 2 .. 5
+    uint4* const wA = reinterpret_cast<uint4*>(stw + 128 * lr + 16 * (lc ^ fsw(lr)));
+    uint4* const wB = reinterpret_cast<uint4*>(stw + 128 * lr + 16 * ((4 + lc) ^ fsw(lr)));
+    const uint4* const rP = reinterpret_cast<const uint4*>(stw + 128 * q + 16 * ((g < 2 ? g : g + 4) ^ fsw(q)));
+    const uint4* const rQ = reinterpret_cast<const uint4*>(stw + 128 * q + 16 * ((2 + g) ^ fsw(q)));
+    const u32 lane_off = (u32)__mul24(lr, gstride_row) + 16u * (u32)lc;
+    // two sets of row registers: a tile is asked for three steps before it is multiplied (memory latency under this
+    // kernel's traffic is about one step of one wave), spends two steps on its way and one in LDS
+    u32x4a nA[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, nB[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    auto load_rows = [&](int t, int set) {
+        const int yt = Y0 - B16_LEFT + 16 * t;           // (uniform)
+        u32 off;
+        if (yt >= 0 && yt + 15 < H) off = (u32)(yt * gstride_row) + lane_off;    // one scalar multiply, one vector add
+        else off = (u32)__mul24(reflect101(yt + lr, H), gstride_row) + 16u * (u32)lc;
+        const u8* r = g0 + off;
+        nA[set] = *reinterpret_cast<const u32x4a*>(r);
+        nB[set] = *reinterpret_cast<const u32x4a*>(r + 64);
+    };
+    auto stage_rows = [&](int set) {                     // p - 128 as int8
+        *wA = make_uint4(nA[set].x ^ 0x80808080u, nA[set].y ^ 0x80808080u, nA[set].z ^ 0x80808080u, nA[set].w ^ 0x80808080u);
+        *wB = make_uint4(nB[set].x ^ 0x80808080u, nB[set].y ^ 0x80808080u, nB[set].z ^ 0x80808080u, nB[set].w ^ 0x80808080u);
+    };
+    v4i LhA = {0, 0, 0, 0}, LhB = {0, 0, 0, 0}, LlA = {0, 0, 0, 0}, LlB = {0, 0, 0, 0};   // large kernel: ring slots 0-3 / 4-7
+    v4i S4h = {0, 0, 0, 0}, S4l = {0, 0, 0, 0};          // small kernel: tiles t-5 .. t-2
+    int Sdh[4] = {0, 0, 0, 0}, Sdl[4] = {0, 0, 0, 0};    // small kernel: the last four tiles (slot t mod 4)
+    const u32 span = (u32)span_i;
+    const u32 m16 = xw + 16 <= W ? 0xFFFFu : ((1u << (W - xw)) - 1u);
+    const u64 colmask = (u64)m16 * 0x0001000100010001ull;
+    unsigned short* mb16 = reinterpret_cast<unsigned short*>(bits) + (int64_t)n * H * WW * 4 + strip;   // (uniform)
+    const u32 sel1 = 0u - ((u32)lane & 1u), sel2 = 0u - (((u32)lane >> 1) & 1u);
+    // Mask rows leave once per eight steps (lane j < 16 keeps the 16-bit pieces of rows yo + j of the eight tiles in four
+    // registers): while a store is in flight next to loads the memory counter cannot be waited on for "all but the
+    // newest loads" (loads and stores return out of order with respect to each other), and every wait for a tile would be
+    // a wait for the tile asked for one step ago as well.
+    u32 total = 0, pp[4] = {0, 0, 0, 0};
+    auto flush_rows = [&](int tg) {                      // tiles of steps tg .. tg + 7
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int y = Y0 + 16 * (tg + k - 7) + lane;
+            if (lane < 16 && tg + k >= 7 && tg + k < nsteps && y < H)
+                mb16[(u32)__mul24(y, 4 * WW)] = (unsigned short)(pp[k >> 1] >> (16 * (k & 1)));
+        }
+    };
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // operand fragments landed (see k_blur_mfma)
+    load_rows(0, 1);
+    stage_rows(1);
+    load_rows(1, 1);                                     // tile t + 1 sits in set (t + 1) & 1
+    load_rows(2, 0);
+    uint4 aP_ = *rP, aQ_ = *rQ;                          // tile 0
+    for (int t0 = 0; t0 < nsteps; t0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                    // u = ring slot of step t: a constant of this copy of the body
+            const int t = t0 + u;
+            if (t >= nsteps) break;                      // uniform
+            const v4i aP = v4i{(int)aP_.x, (int)aP_.y, (int)aP_.z, (int)aP_.w}, aQ = v4i{(int)aQ_.x, (int)aQ_.y, (int)aQ_.z, (int)aQ_.w};
+            // this step's vertical fragments, asked for here and used after the horizontal products
+            const uint4 fa_ = vf[u * 64 + lane], fb_ = vf[((u + 4) & 7) * 64 + lane], fs_ = vf[(8 + (u & 3)) * 64 + lane];
+            // ---- horizontal tile t ----
+            v4i accL = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
+            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aP, lp, accL, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, sq, accS, 0, 0, 0);
+            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, lq, accL, 0, 0, 0);
+            if (edge) accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aP, sp, accS, 0, 0, 0);
+            // behind the products: tile t + 1 (loaded a step ago) through LDS into next step's operands, tile t + 2 on its
+            // way
+            // (unconditionally: past the last tile these are rows the mirror rule still maps into the frame, and nobody
+            //  multiplies them; a branch here makes every wait for a load a wait for all of them)
+            stage_rows((u + 1) & 1); aP_ = *rP; aQ_ = *rQ;
+            load_rows(t + 3, (u + 1) & 1);
+            {
+                int hi, lo;
+                pack16(accL, hi, lo);
+                if (u < 4) { LhA[u & 3] = hi; LlA[u & 3] = lo; } else { LhB[u & 3] = hi; LlB[u & 3] = lo; }
+                pack16(accS, hi, lo);
+                Sdh[u & 3] = hi; Sdl[u & 3] = lo;
+                S4h[(u + 2) & 3] = Sdh[(u + 2) & 3];     // tile t - 2 (zeros for t < 2) takes the place of tile t - 6
+                S4l[(u + 2) & 3] = Sdl[(u + 2) & 3];
+            }
+            if (t < 7) { if (u == 7) flush_rows(t0); continue; }
+            // ---- vertical: output rows yo .. yo + 15, lane (g, q) gets rows yo + 4 g + i of column xw + q ----
+            const int yo = Y0 + 16 * (t - 7);
+            const v4i fa = v4i{(int)fa_.x, (int)fa_.y, (int)fa_.z, (int)fa_.w}, fb = v4i{(int)fb_.x, (int)fb_.y, (int)fb_.z, (int)fb_.w};
+            const v4i fs = v4i{(int)fs_.x, (int)fs_.y, (int)fs_.z, (int)fs_.w};
+            v4i d8 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LhA, d8, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4h, d3, 0, 0, 0);
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, LhB, d8, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d3[i] = (d3[i] << 8) + k3;
+            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4l, d3, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d8[i] = (d8[i] << 8) + k8;
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LlA, d8, 0, 0, 0);
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, LlB, d8, 0, 0, 0);
+            u64 pw[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const u32 dg = (((u32)d8[i] >> 16) - ((u32)d3[i] >> 16)) & 255u;     // (blur_8 - blur_3 + 15 - thresh) mod 256 (:128)
+                pw[i] = __ballot(dg <= span) & colmask;
+            }
+            if (yo + 15 >= H) {                          // uniform: the last tile sticks out of the image
+#pragma unroll
+                for (int i = 0; i < 4; ++i) pw[i] &= __ballot(yo + 4 * g + i < H);
+            }
+            total += (u32)(__popcll(pw[0]) + __popcll(pw[1]) + __popcll(pw[2]) + __popcll(pw[3]));
+            if (U8OUT) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int y = yo + 4 * g + i, x = xw + q;
+                    if (y < H && x < W) area_u8[((int64_t)n * H + y) * W + x] = (u8)(((pw[i] >> lane) & 1ull) ? 255 : 0);
+                }
+            }
+            {
+                // lane j < 16 stores row yo + j: quarter j >> 2 of pw[j & 3] (as k_ncc_mfma does), behind the next step's loads
+                const u32 x01l = (u32)pw[0] ^ (u32)pw[1], x01h = (u32)(pw[0] >> 32) ^ (u32)(pw[1] >> 32);
+                const u32 x23l = (u32)pw[2] ^ (u32)pw[3], x23h = (u32)(pw[2] >> 32) ^ (u32)(pw[3] >> 32);
+                const u32 t0l = (x01l & sel1) ^ (u32)pw[0], t0h = (x01h & sel1) ^ (u32)(pw[0] >> 32);
+                const u32 t1l = (x23l & sel1) ^ (u32)pw[2], t1h = (x23h & sel1) ^ (u32)(pw[2] >> 32);
+                const u32 vl = ((t0l ^ t1l) & sel2) ^ t0l, vh = ((t0h ^ t1h) & sel2) ^ t0h;
+                const u32 piece = ((lane & 8 ? vh : vl) >> (16 * ((lane >> 2) & 1))) & 0xFFFFu;
+                pp[u >> 1] = (u & 1) ? (pp[u >> 1] | (piece << 16)) : piece;
+            }
+            if (u == 7) flush_rows(t0);
+        }
+    }
+    if (nsteps & 7) flush_rows(nsteps & ~7);
+    if (lane == 0 && total) atomicAdd(&fstat[n * 8 + 0], total);
+}
+
+// Operand fragments of k_blur16 (lane = 16 g + index, byte e of a lane <-> k = 16 g + e):
+//   horizontal, per strip: LP, LQ, SQ, SP - B operands over the window pixels of P / Q, output column on the lane; the
+//     entry for window pixel x_in and output column x is the sum of the taps j with reflect101(x + j - R) = x_in
+//   vertical: A operands, output row on the lane; byte 4 pos + i of lane group g is row 4 g + i of the tile in ring slot
+//     pos; variant psi for the phase of the ring (8 for the large kernel's two groups, 4 for the small kernel's)
+void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& taps_l, int W, std::vector<u32>* hfrag,
+                      std::vector<u32>* vfrag) {
+    const int nstrips = (W + 15) / 16;
+    auto refl = [&](int i) { if (i < 0) i = -i; if (i >= W) i = 2 * (W - 1) - i; return std::min(std::max(i, 0), W - 1); };
+    hfrag->assign((size_t)nstrips * 4 * 64 * 4, 0);
+    for (int s = 0; s < nstrips; ++s) {
+        const int xw = 16 * s, L0 = std::min(std::max(xw - B16_LEFT, 0), W - 128);
+        for (int f = 0; f < 4; ++f) {
+            const std::vector<int>& taps = f < 2 ? taps_l : taps_s;
+            const int R = (int)taps.size() / 2;
+            const bool useP = (f == 0 || f == 3);
+            for (int lane = 0; lane < 64; ++lane) {
+                const int g = lane >> 4, x = std::min(xw + (lane & 15), W - 1);
+                for (int e = 0; e < 16; ++e) {
+                    const int k = 16 * g + e, w = useP ? (k < 32 ? k : k + 64) : 32 + k, xin = L0 + w;
+                    int c = 0;
+                    for (int j = 0; j <= 2 * R; ++j) if (refl(x + j - R) == xin) c += taps[j];
+                    (*hfrag)[(((size_t)s * 4 + f) * 64 + lane) * 4 + (e >> 2)] |= (u32)(c & 255) << (8 * (e & 3));
+                }
+            }
+        }
+    }
+    vfrag->assign((size_t)12 * 64 * 4, 0);
+    for (int v = 0; v < 12; ++v) {
+        const std::vector<int>& taps = v < 8 ? taps_l : taps_s;
+        const int R = (int)taps.size() / 2;
+        for (int lane = 0; lane < 64; ++lane) {
+            const int g = lane >> 4, m = lane & 15;
+            for (int e = 0; e < 16; ++e) {
+                const int pos = e >> 2, i = e & 3;
+                const int a = v < 8 ? ((v - pos) % 8 + 8) % 8 : 2 + (((v - 8) - pos - 2) % 4 + 4) % 4;
+                const int k = R + B16_LEFT - 16 * a + 4 * g + i - m;
+                const u32 c = (k >= 0 && k <= 2 * R) ? (u32)taps[k] : 0u;
+                (*vfrag)[((size_t)v * 64 + lane) * 4 + (e >> 2)] |= c << (8 * (e & 3));
+            }
+        }
+    }
+}
+
+// the strips kernel takes the large branch on frames whose rows load as aligned dwords (else k_blur_mfma)
+static bool blur16_takes(const vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row) {
+    return h->blur_impl == 0 && h->blur16_h && !h->bp.small && h->W >= 128 && (h->W & 3) == 0 && h->H >= 64 &&
+           (reinterpret_cast<uintptr_t>(gray) & 3) == 0 && (gstride_n & 3) == 0 && (gstride_row & 3) == 0 &&
+           gstride_row >= h->W && gstride_row < (1 << 23) && (int64_t)h->H * gstride_row < (1ll << 31);
+}
+
 void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
                  int64_t stride_row, u8* gray, hipStream_t s) {
     const int vec_ok = (reinterpret_cast<uintptr_t>(frames) % 16 == 0) && (stride_n % 16 == 0) && (stride_row % 16 == 0);
@@ -417,12 +687,29 @@ void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t 
 
 void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row, int nb,
                  u8* area_u8, hipStream_t s) {
+    const int k3 = 256 * (128 + 32768) + 32768, k8 = k3 + (15 - h->bp.thresh) * 65536;
+    if (blur16_takes(h, gray, gstride_n, gstride_row)) {
+        const int gx16 = h->WW, tiles16 = (h->H + 15) / 16;
+        int nseg = std::min(tiles16 / 8, std::max(1, (2048 + gx16 * nb - 1) / (gx16 * nb)));     // few frames: split the columns
+        nseg = std::max(nseg, 1);
+        const int tps = (tiles16 + nseg - 1) / nseg;
+        nseg = (tiles16 + tps - 1) / tps;
+        // many frames: a 1-D grid that the kernel maps to (frame, strip group, segment) with a frame's workgroups on one XCD
+        const int xcd = nb >= 32 ? nb : 0;
+        dim3 grid16 = xcd ? dim3((unsigned)((nb + 7) / 8 * 8 * gx16 * nseg)) : dim3(gx16, nseg, nb);
+        if (area_u8)
+            VBS_LAUNCH(h, s, "k_blur16", k_blur16<true>, grid16, dim3(256), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
+                       h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg);
+        else
+            VBS_LAUNCH(h, s, "k_blur16", k_blur16<false>, grid16, dim3(256), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
+                       h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg);
+        return;
+    }
     const int gx = (h->P + 127) / 128, tilesY = (h->H + 31) / 32;
     int nseg = std::min(tilesY, std::max(1, (1024 + gx * nb - 1) / (gx * nb)));     // few frames: split columns
     const int tps = (tilesY + nseg - 1) / nseg;
     nseg = (tilesY + tps - 1) / tps;
     dim3 grid(gx, nseg, nb);
-    const int k3 = 256 * (128 + 32768) + 32768, k8 = k3 + (15 - h->bp.thresh) * 65536;
 #define BLUR_GO(NK, SA0, NKA, U8)                                                                            \
     VBS_LAUNCH(h, s, "k_blur_mfma", (k_blur_mfma<NK, SA0, NKA, U8>), grid, dim3(256), 0, s, gray, gstride_n, \
                gstride_row, h->blur_frags, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8,  \
