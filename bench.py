@@ -23,7 +23,7 @@ Extra objects on the JSON line:
                 for the staged entry `vbs_marker_center` on two uint8 images (k_threshold + the same kernels), with the
                 one-image (8d) and the two-image numerators.  `traffic` = HBM bytes per launch from the newest
                 profiles/*_pmc_traffic_<workload>.json (separate rocprofv3 --pmc passes), null when there is none.
-  roofline_mfma k_blur_mfma (int8) and k_ncc_mfma (float16) against the dense matrix-core peaks: algorithmic
+  roofline_mfma k_blur16 / k_blur_mfma (int8) and k_ncc_mfma (float16) against the dense matrix-core peaks: algorithmic
                 operations of the separable filters / live kernel time (same HIP events)
   kernels       live average ms per launch of every kernel of the fused path (one launch = `batch` frames)
   cpu_baseline  BASELINE.md 3: the NumPy/SciPy oracle (oracle/stages.py, a port: the reference needs OpenCV) on the
@@ -385,7 +385,8 @@ def main():
         small = H <= 480
         ta, tb_, ln = (21, 35, 33) if small else (39, 101, 80)
         mf = []
-        for name, ops_px, peak, dt in (("k_blur_mfma", 2 * 2 * (ta + tb_), 5000.0, "i8"),
+        for name, ops_px, peak, dt in (("k_blur16", 2 * 2 * (ta + tb_), 5000.0, "i8"),     # (whichever blur kernel ran)
+                                       ("k_blur_mfma", 2 * 2 * (ta + tb_), 5000.0, "i8"),
                                        ("k_ncc_mfma", 2 * 2 * ln, 2500.0, "f16")):
             if name in prof:
                 c, ms = prof[name]

@@ -18,6 +18,6 @@ for WL in c3 c5; do
   rocprofv3 --pmc WRITE_SIZE --kernel-include-regex "$STAGE" --output-format csv -d $OUT/pmc_write_${TAG}_$WL -- python3 $GRAFT_REPO_ROOT/tools/gpu_detect_run.py $FR 2 $WL > $OUT/pmc_write_${TAG}_$WL.log 2>&1
   echo "collected traffic $TAG $WL"
 done
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-include-regex "k_blur_mfma|k_ncc_mfma" --output-format csv -d $OUT/pmc_sqa_$TAG -- python3 $GRAFT_REPO_ROOT/tools/gpu_detect_run.py $FR 2 > $OUT/pmc_sqa_$TAG.log 2>&1
-rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --kernel-include-regex "k_blur_mfma|k_ncc_mfma" --output-format csv -d $OUT/pmc_sqb_$TAG -- python3 $GRAFT_REPO_ROOT/tools/gpu_detect_run.py $FR 2 > $OUT/pmc_sqb_$TAG.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_VALU_MFMA_BUSY_CYCLES --kernel-include-regex "k_blur16|k_blur_mfma|k_ncc_mfma" --output-format csv -d $OUT/pmc_sqa_$TAG -- python3 $GRAFT_REPO_ROOT/tools/gpu_detect_run.py $FR 2 > $OUT/pmc_sqa_$TAG.log 2>&1
+rocprofv3 --pmc SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_WAVES GRBM_GUI_ACTIVE --kernel-include-regex "k_blur16|k_blur_mfma|k_ncc_mfma" --output-format csv -d $OUT/pmc_sqb_$TAG -- python3 $GRAFT_REPO_ROOT/tools/gpu_detect_run.py $FR 2 > $OUT/pmc_sqb_$TAG.log 2>&1
 echo "collected sq $TAG"

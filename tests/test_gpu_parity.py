@@ -81,6 +81,50 @@ def test_find_markers_bit_exact(tag, channels, crop):
     eng.close()
 
 
+def _textured(h, w, n, seed):
+    """frames whose difference of Gaussians crosses the inRange bounds all over: smooth random fields + noise"""
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    out = np.zeros((n, h, w), np.float32)
+    for f in range(n):
+        for _ in range(30):
+            cx, cy, s = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(6, 60)
+            out[f] += rng.uniform(-120, 160) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+        out[f] += 90 + rng.normal(0, 12, (h, w))
+    return np.clip(out, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("h,w,view", [(600, 800, False), (1000, 1284, False), (520, 132, False), (1024, 1280, True)])
+def test_blur_strips_equal_the_32_column_kernel_and_the_oracle(h, w, view):
+    """a4-a5 through both blur kernels (VBS_OPT_BLUR_IMPL): the 16-column strips (k_blur16: rows straight into the
+    operands, border mirror folded into each strip's fragments, windows shifted to stay inside the row) and the 32-column
+    kernel give the oracle's area mask bit for bit on frames whose DoG crosses the range bounds everywhere - widths that
+    are no multiple of 16 / 64, a frame barely wider than one window, and a strided view of a larger buffer."""
+    n = 2
+    if view:
+        big = torch.from_numpy(_textured(h + 8, w + 64, n, 5)).cuda()
+        ft = big[:, 4:4 + h, 32:32 + w]
+    else:
+        ft = torch.from_numpy(_textured(h, w, n, h + w)).cuda()
+    host = ft.cpu().numpy()
+    eng = engine(h, w, max_batch=n)
+    got = {}
+    for impl in (0, 1):
+        eng.set_option(L.OPT_BLUR_IMPL, impl)
+        mask, area = eng.find_markers(ft)
+        got[impl] = (mask.cpu().numpy(), area.cpu().numpy(), eng.frame_stats(n)[:, 0].copy())
+    eng.set_option(L.OPT_BLUR_IMPL, 0)
+    for a, b in zip(got[0], got[1]):
+        assert np.array_equal(a, b)
+    p = O.branch_params(h)
+    for i in range(n):
+        g = host[i]
+        want = O.in_range(O.dog_image(g), p["thresh"], p["hi"]) > 0
+        assert np.array_equal(got[0][1][i] > 0, want)
+        assert got[0][2][i] == want.sum() and want.sum() > 0.02 * h * w
+    eng.close()
+
+
 @pytest.mark.parametrize("h,w,pitch,dia", [(470, 650, 60, 20), (700, 1003, 72, 40)])
 def test_find_markers_borders_and_odd_sizes(h, w, pitch, dia):
     """a4-a8 where the matrix-core kernels leave their fast paths: sizes that are no multiple of the 32 / 64 / 128
