@@ -403,8 +403,11 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 // ---- strips of 16 columns ---------------------------------------------------------------------------
 // The same two products on v_mfma_i32_16x16x64_i8, one wave per 16-column strip sliding down 16 rows per step, for
 // the large branch (101 / 39 taps) on frames whose rows can be loaded as aligned dwords.  Against k_blur_mfma:
-//   * the image rows go straight from memory into the A operand (lane = row, 16 consecutive bytes): no staging in LDS and
-//     no workgroup barrier; the waves of a workgroup only share the table of vertical fragments
+//   * every wave loads and stages its own rows (2 KB of LDS per wave): no workgroup barrier in the loop; the waves of a
+//     workgroup share the table of vertical fragments and, through the L1, the overlap of their windows.  (One 192-byte
+//     window per workgroup, loaded once and shared through LDS, was built with a barrier per step and with LDS tick
+//     counters instead of barriers: 1.55 and 1.7 us per frame against 1.25 - fewer L1 lookups, but every wave then
+//     waits for the slowest of its workgroup at every tile.)
 //   * a 16 + 100 pixel window fits K = 128 (32-column strips: 160) and a 16 + 100 row window eight 16-row tiles
 //     (32-row tiles: five of 32), so a quarter of the matrix work on the Toeplitz zero band is gone
 //   * the ring of horizontal tiles is 8 + 4 dwords per byte plane instead of 80 registers: 128 registers per lane,
@@ -432,13 +435,14 @@ __device__ __forceinline__ void pack16(const v4i& acc, int& hi, int& lo) {
 }
 
 template <bool U8OUT>
-__global__ __launch_bounds__(256, 4) void k_blur16(const u8* __restrict__ gray, int64_t gstride_n, int gstride_row,
+#define B16_WAVES 8                                      // strips per workgroup (4: 1.25, 8: 1.21, 16: 1.24 us per frame)
+__global__ __launch_bounds__(64 * B16_WAVES, 4) void k_blur16(const u8* __restrict__ gray, int64_t gstride_n, int gstride_row,
                                                    const uint4* __restrict__ hfrag, const uint4* __restrict__ vfrag,
                                                    u64* __restrict__ bits, u8* __restrict__ area_u8,
                                                    u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
                                                    int k3, int k8, int span_i, int nframes, int gx, int gy) {
     __shared__ uint4 vf[12 * 64];
-    __shared__ uint4 stg[4][128];                        // per wave: 16 rows x 128 window bytes
+    __shared__ uint4 stg[B16_WAVES][128];                        // per wave: 16 rows x 128 window bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, q = lane & 15;
@@ -459,9 +463,9 @@ __global__ __launch_bounds__(256, 4) void k_blur16(const u8* __restrict__ gray, 
     const int tile0 = by * tiles_per_seg;
     const int ntiles = min(tiles_per_seg, tilesY - tile0);
     if (ntiles <= 0) return;
-    for (int i = tid; i < 12 * 64; i += 256) vf[i] = vfrag[i];
+    for (int i = tid; i < 12 * 64; i += 64 * B16_WAVES) vf[i] = vfrag[i];
     __syncthreads();                                     // (the only barrier)
-    const int strip = bx * 4 + wave, xw = 16 * strip;
+    const int strip = bx * B16_WAVES + wave, xw = 16 * strip;
     const int Y0 = tile0 * 16, nsteps = ntiles + 7;
     if (xw >= W) {                                       // (uniform) a strip in the padding of the last mask word: zeros
         if (xw < 64 * WW)
@@ -689,7 +693,7 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
                  u8* area_u8, hipStream_t s) {
     const int k3 = 256 * (128 + 32768) + 32768, k8 = k3 + (15 - h->bp.thresh) * 65536;
     if (blur16_takes(h, gray, gstride_n, gstride_row)) {
-        const int gx16 = h->WW, tiles16 = (h->H + 15) / 16;
+        const int gx16 = (64 * h->WW + 16 * B16_WAVES - 1) / (16 * B16_WAVES), tiles16 = (h->H + 15) / 16;
         int nseg = std::min(tiles16 / 8, std::max(1, (2048 + gx16 * nb - 1) / (gx16 * nb)));     // few frames: split the columns
         nseg = std::max(nseg, 1);
         const int tps = (tiles16 + nseg - 1) / nseg;
@@ -698,10 +702,10 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
         const int xcd = nb >= 32 ? nb : 0;
         dim3 grid16 = xcd ? dim3((unsigned)((nb + 7) / 8 * 8 * gx16 * nseg)) : dim3(gx16, nseg, nb);
         if (area_u8)
-            VBS_LAUNCH(h, s, "k_blur16", k_blur16<true>, grid16, dim3(256), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
+            VBS_LAUNCH(h, s, "k_blur16", k_blur16<true>, grid16, dim3(64 * B16_WAVES), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
                        h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg);
         else
-            VBS_LAUNCH(h, s, "k_blur16", k_blur16<false>, grid16, dim3(256), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
+            VBS_LAUNCH(h, s, "k_blur16", k_blur16<false>, grid16, dim3(64 * B16_WAVES), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
                        h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg);
         return;
     }
