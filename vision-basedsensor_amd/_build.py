@@ -9,9 +9,10 @@ LIB = os.path.join(CSRC, "libvbs.so")
 SOURCES = ("api.hip", "k_blur.hip", "k_ncc.hip", "k_label.hip", "k_ccl.hip", "k_stage.hip", "k_solve.hip", "k_undistort.hip", "k_ids.hip", "host_csv.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
-# k_ncc_mfma writes its packed float operations out by hand; the SLP vectoriser's own pairings on top of them cost
-# registers (127 -> 108) and instructions
-FILE_FLAGS = {"k_ncc.hip": ["-fno-slp-vectorize"]}
+# k_ncc.hip: no SLP pairings (they cost registers, 127 -> 108, and instructions) and no packed float32 instructions at all:
+# next to matrix-core instructions a v_pk_fma_f32 costs more than the two v_fma_f32 it replaces (k_ncc_mfma 1.94 ->
+# 1.90 us per frame with its float2 arithmetic split by the compiler)
+FILE_FLAGS = {"k_ncc.hip": ["-fno-slp-vectorize", "-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]}
 
 
 def _stale(target, deps):
