@@ -1061,6 +1061,8 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
     __shared__ double bx[1024], by[1024];
     __shared__ u8 unmatched[1024];
     __shared__ int best_of[1024], claim[1024], wsum[4];
+    __shared__ double thr_s[1024];
+    __shared__ u64 best_d[1024];
     __shared__ int dup_s;
     const int n = blockIdx.x, tid = threadIdx.x;
     int status = (int)fstat[n * 8 + 2];
@@ -1089,50 +1091,57 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
     double* d32 = det32 ? det32 + (int64_t)n * maxm * 6 : nullptr;
 
     // ---- matching (:203-243).  The reference walks the contours in order and gives each the nearest
-    // still-unmatched centre inside it.  Every contour first finds its nearest admissible centre among
+    // still-unmatched centre inside it.  Every contour first gets its nearest admissible centre among
     // ALL centres, in parallel; if no centre is claimed twice, the sequential walk would have made exactly
     // these choices (a contour loses its first choice only to an earlier contour with the same choice).
     // Otherwise (never seen on marker frames) one wave replays the reference's sequential loop.
+    // A centre can only lie inside the polygon of a component that owns a pixel of the 2x2 cell around it (every
+    // accepting branch of inside_polygon needs one), so the search runs from the centres: a thread per centre tries the
+    // at most four components of its probe cell, and a contour keeps the smallest (distance, index) offered to it - the
+    // order the reference's strict "<" over ascending indices produces - through two LDS atomic minima: the distance's
+    // bit pattern (monotone for non-negative doubles), then the index among the centres at that distance.
     for (int i = tid; i < nb_; i += blockDim.x) claim[i] = 0;
+    for (int c = tid; c < na; c += blockDim.x) {
+        const double* e = ell + c * 8;
+        double thr = -1.0;
+        if (e[6] != 0.0 && e[5] >= 5.0) {               // len(contour) >= 5 (:204) and a valid fit
+            const double w = e[2], hh = e[3], minor = (w > hh) ? hh : w;
+            if (!(minor < 5.0)) thr = (minor / 10.0) * (minor / 10.0);     // (:219)
+        }
+        thr_s[c] = thr;
+        best_d[c] = ~0ull;
+        best_of[c] = 0x7FFFFFFF;
+    }
     if (tid == 0) dup_s = force_seq;
     __syncthreads();
-    // The polygon test walks global tables (a chain of dependent loads): it is run for the NEAREST candidate only and
-    // by all lanes of a wave together; a rejected candidate (rare) sends its lane round again for the next-nearest,
-    // candidates ordered by (distance, index) as the reference's strict "<" over ascending indices does.
-    for (int c0 = 0; c0 < na; c0 += blockDim.x) {
-        const int ci = c0 + tid;
-        const double* e = ell + min(ci, na - 1) * 8;
-        bool active = false;
-        double ecx = 0, ecy = 0, thr = 0;
-        if (ci < na && e[6] != 0.0 && e[5] >= 5.0) {    // len(contour) >= 5 (:204) and a valid fit
-            ecx = e[0]; ecy = e[1];
-            const double w = e[2], hh = e[3], minor = (w > hh) ? hh : w;
-            if (!(minor < 5.0)) {                       // (:219)
-                thr = (minor / 10.0) * (minor / 10.0);
-                active = true;
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = tid; i < nb_; i += blockDim.x) {
+            const unsigned short* pr = probe + i * 4;
+            const double cx = bx[i], cy = by[i];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const u32 cid = pr[q4];
+                if (cid >= (u32)na) continue;
+                bool seen = false;
+#pragma unroll
+                for (int q5 = 0; q5 < 4; ++q5) seen |= (q5 < q4) && (pr[q5] == cid);
+                if (seen) continue;
+                const double thr = thr_s[cid];
+                if (!(thr >= 0.0)) continue;
+                const double* e = ell + cid * 8;
+                const double dx = cx - e[0], dy = cy - e[1], d = dx * dx + dy * dy;
+                if (!(d < thr) || !inside_polygon(pr, cx, cy, cid)) continue;
+                const u64 key = (u64)__double_as_longlong(d);
+                if (pass == 0) atomicMin(&best_d[cid], key);
+                else if (key == best_d[cid]) atomicMin(&best_of[cid], i);
             }
         }
-        int bi = -1, lasti = -1;
-        double lastd = -1.0;
-        for (;;) {
-            double best = 1e300;
-            int cand = -1;
-            if (active)
-                for (int i = 0; i < nb_; ++i) {
-                    const double dx = bx[i] - ecx, dy = by[i] - ecy, d = dx * dx + dy * dy;
-                    if (d < thr && d < best && (d > lastd || (d == lastd && i > lasti))) { best = d; cand = i; }
-                }
-            const bool need = active && cand >= 0;
-            if (!__any(need)) break;
-            const bool ok = need && inside_polygon(probe + max(cand, 0) * 4, bx[max(cand, 0)], by[max(cand, 0)], (u32)ci);
-            if (ok) { bi = cand; active = false; }
-            else if (need) { lastd = best; lasti = cand; }
-            else active = false;
-        }
-        if (ci < na) {
-            best_of[ci] = bi;
-            if (bi >= 0 && atomicAdd(&claim[bi], 1) > 0) dup_s = 1;
-        }
+        __syncthreads();
+    }
+    for (int c = tid; c < na; c += blockDim.x) {
+        const int bi = best_of[c] == 0x7FFFFFFF ? -1 : best_of[c];
+        best_of[c] = bi;
+        if (bi >= 0 && atomicAdd(&claim[bi], 1) > 0) dup_s = 1;
     }
     __syncthreads();
     if (!dup_s) {
