@@ -79,12 +79,28 @@ __global__ __launch_bounds__(256) void k_track(const double* __restrict__ det64,
     __syncthreads();
     for (int r = tid; r < m_ref; r += blockDim.x) {
         double ox = ref_xy[2 * r], oy = ref_xy[2 * r + 1];
-        double best = 1e300;
+        // cdist 'euclidean' + argmin (the first minimum of the rounded distances).  The square root is monotone, so the
+        // minimum distance is the root of the minimum squared distance, taken once; only a detection whose squared distance
+        // lies within a few units in the last place of that minimum could round to the same root and win on its index, so
+        // the runner-up is tracked too and the reference's loop over rounded roots runs only for such a near tie (never on
+        // marker frames) - instead of 169 float64 square roots per reference ID
+        double m2 = 1e300, m2b = 1e300;
         int bi = -1;
         for (int i = 0; i < cnt; ++i) {
-            double dx = ox - mx[i], dy = oy - my[i];
-            double ds = sqrt(dx * dx + dy * dy);            // cdist 'euclidean'; argmin takes the first minimum
-            if (ds < best) { best = ds; bi = i; }
+            const double dx = ox - mx[i], dy = oy - my[i], d2 = dx * dx + dy * dy;
+            const bool lt = d2 < m2;
+            m2b = lt ? m2 : (d2 < m2b ? d2 : m2b);
+            bi = lt ? i : bi;
+            m2 = lt ? d2 : m2;
+        }
+        double best = bi >= 0 ? sqrt(m2) : 1e300;
+        if (bi >= 0 && m2b <= m2 * (1.0 + 0x1p-48)) {
+            best = 1e300; bi = -1;
+            for (int i = 0; i < cnt; ++i) {
+                const double dx = ox - mx[i], dy = oy - my[i];
+                const double ds = sqrt(dx * dx + dy * dy);
+                if (ds < best) { best = ds; bi = i; }
+            }
         }
         float* row = table + ((int64_t)n * m_ref + r) * VBS_TABLE_COLS;
         float o[VBS_TABLE_COLS] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
