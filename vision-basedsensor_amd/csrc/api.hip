@@ -247,7 +247,6 @@ static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, in
         launch_blur(h, h->gray, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
     }
     launch_ncc(h, nb, mask_u8, ncc_out, s);
-    launch_stat_accum(h, nb, s);
     return check_launch(h);
 }
 

@@ -159,7 +159,6 @@ void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, 
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s);
 int launch_ncc_general(const double* T, int th, int tw, const double* I, int h, int w, int mode, double* out,
                        double* stats, hipStream_t s);
-void launch_stat_accum(vbs_handle* h, int nb, hipStream_t s);
 void launch_displacement64(const double* table, int n, int m_ref, int warmup, double min_size, double max_disp,
                            double* disp, int* fmin_scratch, hipStream_t s);
 int setup_undistort(vbs_handle* h, const double* K9, const double* dist, int ndist, hipStream_t s);

@@ -276,7 +276,8 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
                                                      const double* __restrict__ tab, const float2* __restrict__ rowf,
                                                      u64* __restrict__ mbits, u8* __restrict__ mask_u8,
-                                                     u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
+                                                     u32* __restrict__ fstat, u64* __restrict__ tot, int H, int W, int WW,
+                                                     int tiles_per_seg,
                                                      int dbg_arg, float rel_arg, NccConst nc) {
 #ifdef VBS_DEBUG_KNOBS
     const int dbg = dbg_arg;                            // tools/ phase timing and dumps
@@ -701,10 +702,11 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
             if (ecnt) drain();
         }
     }
-    if (lane == 0) {                                     // (wave-uniform counters)
-        if (amb) atomicAdd(&fstat[n * 8 + 1], amb);
-        if (nexact) atomicAdd(&fstat[n * 8 + 3], nexact);
+    if (lane == 0) {                                     // (wave-uniform counters; per frame and the handle's running totals)
+        if (amb) { atomicAdd(&fstat[n * 8 + 1], amb); atomicAdd(&tot[0], (u64)amb); }
+        if (nexact) { atomicAdd(&fstat[n * 8 + 3], nexact); atomicAdd(&tot[1], (u64)nexact); }
     }
+    if (tid == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) atomicAdd(&tot[2], (u64)gridDim.z);      // frames
 }
 #undef wide
 
@@ -842,7 +844,7 @@ __global__ __launch_bounds__(256) void k_stat_accum(const u32* __restrict__ fsta
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&tot[2], (u64)nb);
 }
 
-void launch_stat_accum(vbs_handle* h, int nb, hipStream_t s) {
+static void launch_stat_accum(vbs_handle* h, int nb, hipStream_t s) {
     VBS_LAUNCH(h, s, "k_stat_accum", k_stat_accum, dim3(1), dim3(256), 0, s, h->fstat, h->ncc_tot, nb);
 }
 
@@ -859,8 +861,8 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         dim3 grid(h->WW, nseg, nb);
 #define NCC_GO(L_, LO_, U8)                                                                                      \
     VBS_LAUNCH(h, s, "k_ncc_mfma", (k_ncc_mfma<L_, LO_, U8>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx,    \
-               h->ncc_ry, h->ncc_frags, h->ncc_tab, h->ncc_rowf, h->mask_bits, mask_u8, h->fstat, h->H, h->W,   \
-               h->WW, tps,                                                                                       \
+               h->ncc_ry, h->ncc_frags, h->ncc_tab, h->ncc_rowf, h->mask_bits, mask_u8, h->fstat, h->ncc_tot,   \
+               h->H, h->W, h->WW, tps,                                                                           \
                VBS_KNOB("VBS_NCC_DBG"), std::max(NCC_REL, 1e-6f * (float)h->ncc_margin_ppm), h->ncc)
         if (!h->bp.small) { if (mask_u8) NCC_GO(80, -40, true); else NCC_GO(80, -40, false); }
         else { if (mask_u8) NCC_GO(33, -16, true); else NCC_GO(33, -16, false); }
@@ -876,4 +878,5 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         VBS_LAUNCH(h, s, "k_ncc", (k_ncc<33, -16>), grid, dim3(256), 0, s, h->area_bits, h->ncc_rx, h->ncc_ry,
                    h->mask_bits, mask_u8, ncc_out, h->fstat, h->H, h->W, h->WW, stop, h->ncc);
     }
+    launch_stat_accum(h, nb, s);                         // (k_ncc_mfma adds to the running totals itself)
 }
