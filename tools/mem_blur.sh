@@ -8,9 +8,9 @@ cd /tmp && export TMPDIR=/tmp
 i=0
 for set in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_PENDING_STALL_CYCLES_sum" \
            "TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_TA_TCP_STATE_READ_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
-           "TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_FLAT_READ_WAVEFRONTS_sum" \
+           "TCP_TAGRAM0_REQ_sum TCP_LFIFO_STALL_CYCLES_sum" \
            "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
-           "GRBM_GUI_ACTIVE TA_TA_BUSY_sum TCP_TAGRAM0_REQ_sum TCP_LFIFO_STALL_CYCLES_sum"; do
+           "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   rm -rf $OUT/pmc_mem_${i}_$TAG
   rocprofv3 --pmc $set --kernel-include-regex "k_blur" --output-format csv -d $OUT/pmc_mem_${i}_$TAG -- python3 $GRAFT_REPO_ROOT/tools/gpu_detect_run.py $FR 2 > $OUT/pmc_mem_${i}_$TAG.log 2>&1 || echo "pass $i failed"
