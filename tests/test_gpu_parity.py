@@ -125,6 +125,22 @@ def test_blur_strips_equal_the_32_column_kernel_and_the_oracle(h, w, view):
     eng.close()
 
 
+def test_blur_strips_many_frames_per_launch_equal_few():
+    """k_blur16 maps a launch of 32 or more frames onto a 1-D grid (frame = 8 (b / 8 / per_frame) + b % 8, so that a
+    frame's workgroups share an XCD) and pads the frame count to a multiple of 8: 37 frames in one pass give, frame by
+    frame, what passes of 16 (the plain 3-D grid) give."""
+    h, w, n = 600, 800, 37
+    base = _textured(h, w, 5, 77)
+    host = np.stack([np.roll(base[i % 5], 13 * i, axis=1) for i in range(n)])
+    ft = torch.from_numpy(host).cuda()
+    big, small = engine(h, w, max_batch=40), engine(h, w, max_batch=16)
+    m1, a1 = big.find_markers(ft)
+    m2, a2 = small.find_markers(ft)
+    assert torch.equal(a1, a2) and torch.equal(m1, m2)
+    assert len({int(a1[i].count_nonzero()) for i in range(n)}) > 4          # (the frames differ)
+    big.close(); small.close()
+
+
 @pytest.mark.parametrize("h,w,pitch,dia", [(470, 650, 60, 20), (700, 1003, 72, 40)])
 def test_find_markers_borders_and_odd_sizes(h, w, pitch, dia):
     """a4-a8 where the matrix-core kernels leave their fast paths: sizes that are no multiple of the 32 / 64 / 128
