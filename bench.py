@@ -172,6 +172,8 @@ def main():
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--batch", type=int, default=512, help="frames per internal pass (workspace size)")
     ap.add_argument("--roofline-frames", type=int, default=1024)
+    ap.add_argument("--pass-streams", type=int, default=2, choices=[1, 2],
+                    help="VBS_OPT_PASS_STREAMS: 2 = odd internal passes on a second workspace and stream (the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the BGR and host-path side measurements")
     ap.add_argument("--cpu-single-frames", type=int, default=32)
@@ -219,6 +221,7 @@ def main():
     K, dist, R, T = S.default_camera(spec)
     cam = L.make_camera(K, dist, R, T, 2.0)
     eng = Engine(H, W, max_markers=512 if args.workload == "c3" else 1024, max_batch=args.batch, device=local_rank)
+    eng.set_option(L.OPT_PASS_STREAMS, args.pass_streams)
 
     # synthetic frames of this rank's contiguous block, rendered on the device (same bytes as NumPy)
     a, b = D.shard_bounds(n_total, world, rank)
@@ -289,7 +292,7 @@ def main():
                                     f"(21x21 dots), plus plane-fit pose") +
                                    f", resident in HBM; fused track->3D table + "
                                    f"{'RCCL all-gather + ' if world > 1 else ''}last-seen displacement",
-                       "frames_per_gpu": args.frames, "internal_batch": args.batch, "markers": M, "channels": args.channels,
+                       "frames_per_gpu": args.frames, "internal_batch": args.batch, "pass_streams": args.pass_streams, "markers": M, "channels": args.channels,
                        "world_size": td.get_world_size() if world > 1 else 1,
                        "backend": td.get_backend() if world > 1 else "none (single process)",
                        "tracked_observations": tracked, "xyz_solved": solved,

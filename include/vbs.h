@@ -77,13 +77,18 @@ int vbs_version(void);
  * 1 always runs the separate kernels (k_morph + k_ccl) that other geometries take.  VBS_OPT_BLUR_IMPL (test hook /
  * fallback, results identical): 0 (default) runs the two GaussianBlurs (:118-129) on 16-column strips (k_blur16) where the
  * frame allows it (large branch, width a multiple of 4, rows that load as aligned dwords), 1 always runs the 32-column
- * kernel (k_blur_mfma) that every other frame takes. */
+ * kernel (k_blur_mfma) that every other frame takes.  VBS_OPT_PASS_STREAMS (tuning, results identical): 2 (default) lets
+ * vbs_track_to_3d run the odd internal passes of a call on gray frames with a second workspace on the handle's own
+ * stream (forked from and joined to the caller's stream by events), so that the tail of one pass's kernels overlaps the
+ * next pass; 1 runs every pass on the caller's stream.  (With vbs_profile on, passes run on one stream: the per-kernel
+ * event timings would otherwise overlap.) */
 #define VBS_OPT_GRAY_COEFFS      1
 #define VBS_OPT_FORCE_SEQ_MATCH  2
 #define VBS_OPT_GRAY_SIDE_STREAM 3
 #define VBS_OPT_NCC_MARGIN       4
 #define VBS_OPT_STAGE_IMPL       5
 #define VBS_OPT_BLUR_IMPL        6
+#define VBS_OPT_PASS_STREAMS     7
 int vbs_set_option(vbs_handle* h, int option, int value);
 /* host-only helper: the 256-entry table that classifies a border pixel's 8-neighbourhood into the
  * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain

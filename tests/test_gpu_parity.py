@@ -1036,6 +1036,38 @@ def test_two_handles_of_different_sizes_alternate():
         e.close()
 
 
+def test_passes_on_two_streams_equal_one():
+    """VBS_OPT_PASS_STREAMS: the odd internal passes of vbs_track_to_3d on the handle's second workspace and stream
+    (default) give, row for row, what all passes on the caller's stream give - tables, detections, counts and the running
+    NCC counters (summed over both workspaces); options set on the handle reach the second workspace; a following call on
+    the caller's stream sees the joined results."""
+    from vbs_amd.engine import Engine
+    from vbs_amd.pipeline import reference_from_frame0
+    spec = S.config1()
+    n = 23                                                # 6 passes of 4: three on either stream
+    ft = S.make_frames_torch(spec, range(n), seed=3, device="cuda")
+    eng = Engine(spec.height, spec.width, max_markers=256, max_batch=4)
+    ids, xy = reference_from_frame0(eng, ft[:1], 5, "full", "optimal")
+    cam = L.make_camera(*S.default_camera(spec), 2.0)
+    got = {}
+    for ps, impl in ((1, 0), (2, 0), (2, 1), (1, 1)):
+        eng.set_option(L.OPT_PASS_STREAMS, ps)
+        eng.set_option(L.OPT_STAGE_IMPL, impl)            # (reaches the second workspace as well)
+        eng.ncc_counters(reset=True)
+        table, det, counts = eng.track_to_3d(ft, xy, 20.0, cam, 5.0, want_det=True)
+        disp = eng.displacement(table, 0, 5.0, 50.0)      # on the caller's stream, behind the join
+        ctr = eng.ncc_counters()
+        got[(ps, impl)] = (table.cpu(), det.cpu(), counts.cpu(), disp.cpu(), ctr)
+    ref = got[(1, 0)]
+    assert ref[2].tolist() == [spec.n_markers] * n and ref[4]["frames"] == n
+    for key, g in got.items():
+        for a, b in zip(g[:4], ref[:4]):
+            assert torch.equal(a, b), key
+        assert g[4] == ref[4], (key, g[4], ref[4])
+    eng.set_option(L.OPT_STAGE_IMPL, 0)
+    eng.close()
+
+
 def test_engine_argument_errors():
     from vbs_amd.engine import Engine
     with pytest.raises(ValueError):

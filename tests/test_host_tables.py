@@ -28,10 +28,10 @@ def test_option_and_status_constants_match_the_header():
     """`_lib.py` restates the header's #defines (options, status codes, table layout): they must agree."""
     hdr = open(os.path.join(ROOT, "include", "vbs.h")).read()
     defs = {k: int(v) for k, v in re.findall(r"#define\s+(VBS_[A-Z0-9_]+)\s+(-?\d+)", hdr)}
-    for name in ("GRAY_COEFFS", "FORCE_SEQ_MATCH", "GRAY_SIDE_STREAM", "NCC_MARGIN", "STAGE_IMPL", "BLUR_IMPL"):
+    for name in ("GRAY_COEFFS", "FORCE_SEQ_MATCH", "GRAY_SIDE_STREAM", "NCC_MARGIN", "STAGE_IMPL", "BLUR_IMPL", "PASS_STREAMS"):
         assert getattr(L, "OPT_" + name) == defs["VBS_OPT_" + name], name
     opts = [v for k, v in defs.items() if k.startswith("VBS_OPT_")]
-    assert len(opts) == len(set(opts)) == 6
+    assert len(opts) == len(set(opts)) == 7
     for k, v in defs.items():
         if hasattr(L, k[4:]) and isinstance(getattr(L, k[4:]), int) and not k.startswith("VBS_OPT_"):
             assert getattr(L, k[4:]) == v, k

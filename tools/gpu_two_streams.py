@@ -37,3 +37,16 @@ for k in (1, 2, 1, 2, 4):
     print(f"{k} stream(s): {n / dt:10.0f} frames/s  {dt * 1e6 / n:.3f} us/frame  counts {int(cnt.min())}..{int(cnt.max())}", flush=True)
     for e in engs:
         e.close()
+
+# the library's own form: VBS_OPT_PASS_STREAMS = 1 | 2 on one handle (odd internal passes on a second workspace and stream)
+from vbs_amd import _lib as L
+eng = Engine(spec.height, spec.width, max_markers=512, max_batch=batch)
+for ps in (1, 2, 1, 2):
+    eng.set_option(L.OPT_PASS_STREAMS, ps)
+    eng.track_to_3d(ft, ref_xy=ref); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(4):
+        out = eng.track_to_3d(ft, ref_xy=ref)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 4
+    print(f"pass_streams {ps}: {n / dt:10.0f} frames/s  {dt * 1e6 / n:.3f} us/frame", flush=True)

@@ -106,6 +106,10 @@ extern "C" int vbs_ncc_template(int l, double sigma, double* g, double* stats) {
 extern "C" int vbs_destroy(vbs_handle* h) {
     if (!h) return VBS_EINVAL;
     (void)hipSetDevice(h->device);
+    if (h->twin) { (void)vbs_destroy(h->twin); h->twin = nullptr; }
+    if (h->twin_stream) (void)hipStreamDestroy(h->twin_stream);
+    if (h->ev_tfork) (void)hipEventDestroy(h->ev_tfork);
+    if (h->ev_tjoin) (void)hipEventDestroy(h->ev_tjoin);
     for (void* p : h->allocs) (void)hipFree(p);
     if (h->side) (void)hipStreamDestroy(h->side);
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
@@ -383,7 +387,12 @@ extern "C" int vbs_normxcorr2(vbs_handle* h, const uint8_t* area_mask, int n, do
 
 extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
     if (!h) return VBS_EINVAL;
+    if (h->twin && option != VBS_OPT_PASS_STREAMS) (void)vbs_set_option(h->twin, option, value);   // (same checks, same answer)
     switch (option) {
+        case VBS_OPT_PASS_STREAMS:
+            if (value != 1 && value != 2) break;
+            h->pass_streams = value;
+            return VBS_OK;
         case VBS_OPT_FORCE_SEQ_MATCH: h->force_seq_match = value != 0; return VBS_OK;
         case VBS_OPT_GRAY_SIDE_STREAM: h->gray_side = value != 0; return VBS_OK;
         case VBS_OPT_NCC_MARGIN:
@@ -508,6 +517,12 @@ extern "C" int vbs_ncc_counters(vbs_handle* h, uint64_t out[3], int reset) {
     HIPCHK(h, hipDeviceSynchronize());
     HIPCHK(h, hipMemcpy(out, h->ncc_tot, 3 * sizeof(u64), hipMemcpyDeviceToHost));
     if (reset) HIPCHK(h, hipMemset(h->ncc_tot, 0, 4 * sizeof(u64)));
+    if (h->twin) {                                      // the passes the second workspace ran
+        uint64_t t[3] = {0, 0, 0};
+        HIPCHK(h, hipMemcpy(t, h->twin->ncc_tot, 3 * sizeof(u64), hipMemcpyDeviceToHost));
+        if (reset) HIPCHK(h, hipMemset(h->twin->ncc_tot, 0, 4 * sizeof(u64)));
+        for (int i = 0; i < 3; ++i) out[i] += t[i];
+    }
     return VBS_OK;
 }
 
@@ -573,6 +588,31 @@ extern "C" int vbs_solve3d(vbs_handle* h, float* table, int n, int m_ref, const 
     return check_launch(h);
 }
 
+// The second workspace of VBS_OPT_PASS_STREAMS = 2: a whole second handle (same geometry, same options) plus the stream
+// its passes run on and the two events that fork it from / join it to the caller's stream.
+static int twin_of(vbs_handle* h) {
+    if (h->twin) return VBS_OK;
+    vbs_handle* t = nullptr;
+    int rc = vbs_create(h->device, h->H, h->W, h->maxm, h->maxb, &t);
+    if (rc != VBS_OK) {
+        h->err = std::string("second pass workspace: ") + (t ? t->err : std::string("allocation failed"));
+        if (t) (void)vbs_destroy(t);
+        return rc;
+    }
+    t->pass_streams = 1;
+    t->gray_bits = h->gray_bits; t->force_seq_match = h->force_seq_match; t->ncc_margin_ppm = h->ncc_margin_ppm;
+    t->stage_impl = h->stage_impl; t->blur_impl = h->blur_impl;
+    if (hipStreamCreateWithFlags(&h->twin_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tfork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&h->ev_tjoin, hipEventDisableTiming) != hipSuccess) {
+        (void)vbs_destroy(t);
+        h->err = "second pass workspace: stream / event creation failed";
+        return VBS_EHIP;
+    }
+    h->twin = t;
+    return VBS_OK;
+}
+
 extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int channels, int64_t stride_n,
                                int64_t stride_row, const double* ref_xy, int m_ref, double min_dist,
                                const vbs_camera* cam, double min_marker_size_px, float* table, double* det,
@@ -589,24 +629,42 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
     GrayPipe gp{h, frames, n, channels, stride_n, stride_row, s, false};
     int rc = gp.start();
     if (rc != VBS_OK) return rc;
+    // Gray frames over several passes: odd passes on the second workspace and stream (VBS_OPT_PASS_STREAMS), so that the
+    // partly filled last round of one pass's kernels runs next to the other pass.  Every pass writes its own slice of the
+    // caller's tables; the second stream starts behind what the caller's stream holds and is joined before the return.
+    const bool two = h->pass_streams == 2 && !h->prof && channels == 1 && !h->undist && n > h->maxb;
+    if (two) {
+        if ((rc = twin_of(h)) != VBS_OK) return gp.fail(rc);
+        HIPCHK(h, hipEventRecord(h->ev_tfork, s));
+        HIPCHK(h, hipStreamWaitEvent(h->twin_stream, h->ev_tfork, 0));
+    }
+    auto join = [&](int code) {                          // (also on the error returns: an un-joined fork breaks a capture)
+        if (two) {
+            (void)hipEventRecord(h->ev_tjoin, h->twin_stream);
+            (void)hipStreamWaitEvent(s, h->ev_tjoin, 0);
+        }
+        return code;
+    };
     for (int k = 0; gp.pass_off(k) < n; ++k) {
         const int off = gp.pass_off(k), nb = gp.pass_len(k);
+        vbs_handle* hh = (two && (k & 1)) ? h->twin : h;
+        hipStream_t ss = (two && (k & 1)) ? h->twin_stream : s;
         const u8* plane;
-        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return gp.fail(rc);
-        rc = detect_pass(h, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr, nullptr, nullptr,
-                         s, plane);
-        if (rc != VBS_OK) return gp.fail(rc);
-        if ((rc = gp.release(k)) != VBS_OK) return gp.fail(rc);
-        launch_labelling(h, nb, s);
-        launch_finalize(h, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr,
-                        counts ? counts + off : nullptr, s);
+        if ((rc = gp.acquire(k, &plane)) != VBS_OK) return join(gp.fail(rc));
+        rc = detect_pass(hh, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr, nullptr, nullptr,
+                         ss, plane);
+        if (rc != VBS_OK) { if (hh != h) h->err = hh->err; return join(gp.fail(rc)); }
+        if ((rc = gp.release(k)) != VBS_OK) return join(gp.fail(rc));
+        launch_labelling(hh, nb, ss);
+        launch_finalize(hh, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr,
+                        counts ? counts + off : nullptr, ss);
         if (table)
-            launch_track_fused(h, nb, ref_xy, m_ref, min_dist, table + (size_t)off * m_ref * VBS_TABLE_COLS, cam,
-                               min_marker_size_px, s);
-        rc = check_launch(h);
-        if (rc != VBS_OK) return gp.fail(rc);
+            launch_track_fused(hh, nb, ref_xy, m_ref, min_dist, table + (size_t)off * m_ref * VBS_TABLE_COLS, cam,
+                               min_marker_size_px, ss);
+        rc = check_launch(hh);
+        if (rc != VBS_OK) { if (hh != h) h->err = hh->err; return join(gp.fail(rc)); }
     }
-    return VBS_OK;
+    return join(VBS_OK);
 }
 
 extern "C" int vbs_displacement_range(vbs_handle* h, const float* table, int n, int m_ref, int warmup_frames,

@@ -63,6 +63,12 @@ struct vbs_handle {
     uint4* blur16_h = nullptr;   // k_blur16: horizontal fragments per 16-column strip (blur16_fragments); null = not built
     uint4* blur16_v = nullptr;   // k_blur16: the 12 vertical fragment variants
     int blur_impl = 0;           // vbs_set_option(VBS_OPT_BLUR_IMPL): 0 k_blur16 where it applies, 1 always k_blur_mfma
+    // vbs_set_option(VBS_OPT_PASS_STREAMS) = 2: the internal passes of vbs_track_to_3d alternate between this handle on the
+    // caller's stream and a second workspace (`twin`, created at first use) on `twin_stream`
+    int pass_streams = 2;
+    vbs_handle* twin = nullptr;
+    hipStream_t twin_stream = nullptr;
+    hipEvent_t ev_tfork = nullptr, ev_tjoin = nullptr;
     u64* area_bits;    // [maxb][H][WW]
     u64* mask_bits;    // [maxb][H][WW]
     u64* band_bits;    // [maxb][H][WW]
