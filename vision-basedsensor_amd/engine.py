@@ -30,6 +30,7 @@ class Engine:
         self.device = torch.device("cuda", device if isinstance(device, int) else device.index or 0)
         self.H, self.W = int(height), int(width)
         self.max_markers, self.max_batch = int(max_markers), int(max_batch)
+        self.pass_streams = 2                           # the library's default for VBS_OPT_PASS_STREAMS (see set_option)
         h = C.c_void_p()
         rc = self.lib.vbs_create(self.device.index, self.H, self.W, self.max_markers, self.max_batch,
                                  C.byref(h))
@@ -149,8 +150,10 @@ class Engine:
 
     def set_option(self, option: int, value: int):
         """`vbs_set_option`: L.OPT_GRAY_COEFFS (15 | 14), L.OPT_GRAY_SIDE_STREAM (0 | 1), test hooks L.OPT_FORCE_SEQ_MATCH,
-        L.OPT_NCC_MARGIN (units of 1e-6)."""
+        L.OPT_NCC_MARGIN (units of 1e-6), L.OPT_STAGE_IMPL / L.OPT_BLUR_IMPL (0 | 1), L.OPT_PASS_STREAMS (1 | 2)."""
         self._check(self.lib.vbs_set_option(self._h, int(option), int(value)), "vbs_set_option")
+        if int(option) == L.OPT_PASS_STREAMS:
+            self.pass_streams = int(value)
 
     def profile(self, enable: bool):
         self._check(self.lib.vbs_profile(self._h, 1 if enable else 0), "vbs_profile")

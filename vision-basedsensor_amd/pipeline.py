@@ -46,8 +46,8 @@ def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mo
 
 def track_and_gather(eng: Engine, frames_local: torch.Tensor, n_total: int, xy, min_dist=20.0, cam=None,
                      min_marker_size_px=5.0, pipelined=True):
-    """This rank's frames through the fused path, one internal pass (`eng.max_batch` frames) at a time, the all-gather of
-    each pass's rows issued as soon as the pass is enqueued (`dist.TableGather`): the exchange overlaps the next pass.
+    """This rank's frames through the fused path, `eng.pass_streams` internal passes (`eng.max_batch` frames each) at a time,
+    the all-gather of their rows issued as soon as they are enqueued (`dist.TableGather`): the exchange overlaps the next ones.
     `pipelined=False`: all passes first, then the single `dist.gather_tables` collective (SURVEY 8e as written).
     Returns (local table [n_local, M, 10], counts [n_local], gathered table [n_total, M, 10])."""
     rank, ws = D.world()
@@ -56,11 +56,14 @@ def track_and_gather(eng: Engine, frames_local: torch.Tensor, n_total: int, xy, 
     if ws == 1 or not pipelined:
         local, _, counts = eng.track_to_3d(frames_local, xy, min_dist, cam, min_marker_size_px)
         return local, counts, (local if ws == 1 else D.gather_tables(local, n_total))
-    g = D.TableGather(n_total, m, L.TABLE_COLS, eng.device, eng.max_batch)
+    # one call and one collective per `pass_streams` internal passes: with two, the library runs the second pass of a call
+    # on its second workspace and stream (VBS_OPT_PASS_STREAMS), as it does for a single process
+    chunk = eng.max_batch * max(1, int(getattr(eng, "pass_streams", 1)))
+    g = D.TableGather(n_total, m, L.TABLE_COLS, eng.device, chunk)
     a, _ = D.shard_bounds(n_total, ws, rank)
     counts = torch.zeros((n_local,), dtype=torch.int32, device=eng.device)
-    for off in range(0, g.n_max, eng.max_batch):
-        part = frames_local[off:off + eng.max_batch]
+    for off in range(0, g.n_max, chunk):
+        part = frames_local[off:off + chunk]
         if part.shape[0]:
             t, _, c = eng.track_to_3d(part, xy, min_dist, cam, min_marker_size_px)
             counts[off:off + part.shape[0]] = c
