@@ -629,10 +629,11 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
     GrayPipe gp{h, frames, n, channels, stride_n, stride_row, s, false};
     int rc = gp.start();
     if (rc != VBS_OK) return rc;
-    // Gray frames over several passes: odd passes on the second workspace and stream (VBS_OPT_PASS_STREAMS), so that the
-    // partly filled last round of one pass's kernels runs next to the other pass.  Every pass writes its own slice of the
+    // Several passes: odd passes on the second workspace and stream (VBS_OPT_PASS_STREAMS), so that the partly filled last
+    // round of one pass's kernels runs next to the other pass - and, for BGR frames, the bandwidth-bound conversion of one pass
+    // next to the matrix-core kernels of the other (each workspace converts into its own gray plane).  Every pass writes its own slice of the
     // caller's tables; the second stream starts behind what the caller's stream holds and is joined before the return.
-    const bool two = h->pass_streams == 2 && !h->prof && channels == 1 && !h->undist && n > h->maxb;
+    const bool two = h->pass_streams == 2 && !h->prof && !h->undist && !gp.on && n > h->maxb;     // (gp.on: BGR converted a pass ahead on h->side)
     if (two) {
         if ((rc = twin_of(h)) != VBS_OK) return gp.fail(rc);
         HIPCHK(h, hipEventRecord(h->ev_tfork, s));
