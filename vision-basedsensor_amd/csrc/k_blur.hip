@@ -401,31 +401,43 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 
 
 // ---- strips of 16 columns ---------------------------------------------------------------------------
-// The same two products on v_mfma_i32_16x16x64_i8, one wave per 16-column strip sliding down 16 rows per step, for
-// the large branch (101 / 39 taps) on frames whose rows can be loaded as aligned dwords.  Against k_blur_mfma:
-//   * every wave loads and stages its own rows (2 KB of LDS per wave): no workgroup barrier in the loop; the waves of a
-//     workgroup share the table of vertical fragments and, through the L1, the overlap of their windows.  (One 192-byte
-//     window per workgroup, loaded once and shared through LDS, was built with a barrier per step and with LDS tick
-//     counters instead of barriers: 1.55 and 1.7 us per frame against 1.25 - fewer L1 lookups, but every wave then
-//     waits for the slowest of its workgroup at every tile.)
+// The same two products on v_mfma_i32_16x16x64_i8, one wave per 16-column strip sliding down 16 rows per step, for the
+// large branch (101 / 39 taps) on frames whose rows can be loaded as aligned dwords.  Against k_blur_mfma:
 //   * a 16 + 100 pixel window fits K = 128 (32-column strips: 160) and a 16 + 100 row window eight 16-row tiles
 //     (32-row tiles: five of 32), so a quarter of the matrix work on the Toeplitz zero band is gone
-//   * the ring of horizontal tiles is 8 + 4 dwords per byte plane instead of 80 registers: 128 registers per lane,
-//     4 waves per SIMD instead of 2
+//   * the ring of horizontal tiles is 8 + 4 dwords per byte plane instead of 80 registers: 100 registers per lane, 4
+//     waves per SIMD instead of 2
 //   * reflect-101 at the left / right border is folded into the strip's own horizontal fragments (a pixel that the
 //     border mirrors onto carries the sum of the taps that reach it; the window is shifted to stay inside the row), so
-//     there is no byte-wise gather at the image border
+//     nothing is ever gathered byte by byte at the image border
 //   * the vertical result has the column on the lane and four rows in registers: the range test is one subtraction
 //     of byte 2 and one compare per register, whose lane mask IS 4 rows x 16 mask bits
-// Window of strip xw: pixels [L0, L0 + 128), L0 = xw - 56 clamped to [0, W - 128]; operand P = window bytes 0..31 and
-// 96..127, operand Q = bytes 32..95 (all the 39-tap kernel needs away from the border).  Horizontal tile t = rows
-// Y0 - 56 + 16 t ..: the output tile of step t (rows Y0 + 16 (t - 7) ..) reads tiles t-7 .. t of the large kernel and tiles
-// t-5 .. t-2 of the small one.  Ring slot = t mod 8 (mod 4), the step loop is unrolled by 8, and what changes with the
-// phase is the vertical fragment: 8 + 4 variants in LDS.
+//   * no workgroup barrier in the loop, and the strips never load a row: see below
+// A workgroup = seven strips (waves 0..6) and ONE LOADER WAVE (wave 7).  The workgroup's window is 240 bytes of each row,
+// [X0, X0 + 240) with X0 = 112 bx - 64 shifted to stay inside the row; the loader keeps three tiles (16 rows x 15 pieces
+// of 16 bytes, four per lane) on their way from memory, stages a tile into one of six ring slots in LDS once every strip
+// has ticked off the tile that was there, and announces it with a tick; a strip waits for the tick of the tile it needs
+// (it nearly always finds it there: the loader runs tiles ahead), reads its own 128-byte window [L0, L0 + 128) out of
+// the slot as operand P = window bytes 0..31 and 96..127 and operand Q = bytes 32..95 (all the 39-tap kernel needs away
+// from the border), and ticks the slot off one step later.  The first touch of a row from HBM - which every strip of the
+// frame used to wait for at about the same time - is the loader's business three tiles ahead of anybody's need, and the
+// L1 sees 64 tag lookups per tile instead of 8 x 62.
+// (On the way here, us per frame at 1280x1024: every wave loading its own window straight into the operand layout 1.87 -
+// every lane of a load quad on another cache line; four lanes per 64 bytes of a row and a per-wave LDS hop 1.41; + a
+// frame's workgroups on one XCD 1.25, + eight strips per workgroup 1.21 = round 3's first product form; the shared
+// window with a barrier per tile 1.55, with tick counters in every wave 1.7, with this loader wave 3.4 - all three because
+// the pieces past the image border were gathered byte by byte behind a full wait for memory, in two workgroups of every
+// frame; with the border in the fragments instead, as above: 1.06-1.13.  With no row loads at all: 0.78-1.06.)
+// Horizontal tile t = rows Y0 - 56 + 16 t ..: the output tile of step t (rows Y0 + 16 (t - 7) ..) reads tiles t-7 .. t of
+// the large kernel and tiles t-5 .. t-2 of the small one.  Ring slot = t mod 8 (mod 4), the step loop is unrolled by 8,
+// and what changes with the phase is the vertical fragment: 8 + 4 variants in LDS.
 #define B16_RL 50
 #define B16_RS 19
 #define B16_LEFT 56
-typedef u32 u32x4a __attribute__((ext_vector_type(4), aligned(4)));
+#define B16_NSW 7                                        // strips (compute waves) per workgroup; wave B16_NSW is the loader
+#define B16_NP 15                                        // 16-byte pieces of the workgroup's window per row: 112 + 128 columns
+#define B16_ROWB 272                                     // LDS bytes per staged row: 240 + pad; eight rows tile the banks
+#define B16_NS 6                                         // tiles of rows in LDS (ring slots)
 
 __device__ __forceinline__ void pack16(const v4i& acc, int& hi, int& lo) {
     const u32 t01 = __builtin_amdgcn_perm((u32)acc[1], (u32)acc[0], 0x05010400u);
@@ -435,22 +447,21 @@ __device__ __forceinline__ void pack16(const v4i& acc, int& hi, int& lo) {
 }
 
 template <bool U8OUT>
-#define B16_WAVES 8                                      // strips per workgroup (4: 1.25, 8: 1.21, 16: 1.24 us per frame)
-__global__ __launch_bounds__(64 * B16_WAVES, 4) void k_blur16(const u8* __restrict__ gray, int64_t gstride_n, int gstride_row,
+__global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __restrict__ gray, int64_t gstride_n, int gstride_row,
                                                    const uint4* __restrict__ hfrag, const uint4* __restrict__ vfrag,
                                                    u64* __restrict__ bits, u8* __restrict__ area_u8,
                                                    u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
                                                    int k3, int k8, int span_i, int nframes, int gx, int gy) {
     __shared__ uint4 vf[12 * 64];
-    __shared__ uint4 stg[B16_WAVES][128];                        // per wave: 16 rows x 128 window bytes
+    __shared__ __align__(16) u8 stg[B16_NS][16 * B16_ROWB];
+    __shared__ u32 ready[B16_NS];                        // ready[s]: tiles the loader has staged into slot s, ever
+    __shared__ u32 done[B16_NS];                         // done[s]: reads of slot s the strips have finished, ever
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, q = lane & 15;
     // Workgroups are dealt round-robin over the 8 XCDs (observed, not promised: it only matters for speed).  With many
     // frames in the launch, workgroup b works on frame 8 (b / 8 / per_frame) + b % 8: the workgroups of one frame - whose
-    // windows overlap, 176 bytes of a row per 64 columns - then share one XCD's L2 and the frame crosses the fabric
-    // once, not 2.75 times (1.41 -> 1.25 us per frame; with every row already in L2 the kernel takes 0.9).  (k_blur_mfma,
-    // whose 128-column workgroups re-read less, measured the same either way.)
+    // windows overlap - then share one XCD's L2 and the frame crosses the fabric once.
     int n, bx, by;
     if (nframes) {
         const int b = blockIdx.x, per = gx * gy, j = b >> 3;
@@ -463,86 +474,163 @@ __global__ __launch_bounds__(64 * B16_WAVES, 4) void k_blur16(const u8* __restri
     const int tile0 = by * tiles_per_seg;
     const int ntiles = min(tiles_per_seg, tilesY - tile0);
     if (ntiles <= 0) return;
-    for (int i = tid; i < 12 * 64; i += 64 * B16_WAVES) vf[i] = vfrag[i];
-    __syncthreads();                                     // (the only barrier)
-    const int strip = bx * B16_WAVES + wave, xw = 16 * strip;
+    for (int i = tid; i < 12 * 64; i += 64 * (B16_NSW + 1)) vf[i] = vfrag[i];
+    const bool is_loader = wave == B16_NSW;              // (uniform)
+    const int strip = bx * B16_NSW + wave, xw = 16 * strip;
     const int Y0 = tile0 * 16, nsteps = ntiles + 7;
-    if (xw >= W) {                                       // (uniform) a strip in the padding of the last mask word: zeros
-        if (xw < 64 * WW)
-            for (int y = Y0 + lane; y < min(Y0 + 16 * ntiles, H); y += 64)
-                reinterpret_cast<unsigned short*>(bits)[((int64_t)n * H + y) * WW * 4 + strip] = 0;
-        return;
-    }
-    const int L0 = min(max(xw - B16_LEFT, 0), W - 128);
+    const bool live = !is_loader && xw < W;              // (uniform) else a strip in the padding of the last mask word
+    if (!is_loader && !live && xw < 64 * WW)
+        for (int y = Y0 + lane; y < min(Y0 + 16 * ntiles, H); y += 64)
+            reinterpret_cast<unsigned short*>(bits)[((int64_t)n * H + y) * WW * 4 + strip] = 0;
+    const int L0 = min(max(xw - B16_LEFT, 0), W - 128);  // this strip's window [L0, L0 + 128): shifted to stay inside the row
     const bool edge = L0 != xw - B16_LEFT;               // (uniform) the 39-tap window is not all inside Q
     v4i lp, lq, sq, sp = {0, 0, 0, 0};
     {
-        const uint4* hf = hfrag + (size_t)strip * 4 * 64 + lane;
+        const uint4* hf = hfrag + (size_t)min(strip, (W + 15) / 16 - 1) * 4 * 64 + lane;
         const uint4 a = hf[0], b = hf[64], c = hf[128];
         lp = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
         lq = v4i{(int)b.x, (int)b.y, (int)b.z, (int)b.w};
         sq = v4i{(int)c.x, (int)c.y, (int)c.z, (int)c.w};
         if (edge) { const uint4 d = hf[192]; sp = v4i{(int)d.x, (int)d.y, (int)d.z, (int)d.w}; }
     }
-    // Rows travel memory -> registers -> this wave's 2 KB of LDS -> operand: loaded with four consecutive lanes on 64
-    // consecutive bytes of one row (lane = 4 row + piece; a lane per row and piece of the OPERAND layout, lane = 16 piece +
-    // row, puts every lane of a quad on another cache line: 1.9 us per frame against 1.3), read back one row per lane.
-    // 16-byte piece p of row r sits at slot p ^ f(r): eight consecutive lanes cover all 32 banks on the way in (two
-    // rows x four pieces) and on the way out (eight rows, one piece).
-    const u8* g0 = gray + (int64_t)n * gstride_n + L0;   // (uniform)
-    const int lr = lane >> 2, lc = lane & 3;
-    auto fsw = [](int r) { return ((r & 1) << 2) | ((r >> 1) & 3); };
-    u8* const stw = reinterpret_cast<u8*>(&stg[wave][0]);
-    // a lane loads pieces lc and lc + 4 of its row (window bytes 16 lc .. and 64 + 16 lc ..: one address, two loads);
-    // operand P = pieces 0, 1, 6, 7 and operand Q = pieces 2 .. 5
-    uint4* const wA = reinterpret_cast<uint4*>(stw + 128 * lr + 16 * (lc ^ fsw(lr)));
-    uint4* const wB = reinterpret_cast<uint4*>(stw + 128 * lr + 16 * ((4 + lc) ^ fsw(lr)));
-    const uint4* const rP = reinterpret_cast<const uint4*>(stw + 128 * q + 16 * ((g < 2 ? g : g + 4) ^ fsw(q)));
-    const uint4* const rQ = reinterpret_cast<const uint4*>(stw + 128 * q + 16 * ((2 + g) ^ fsw(q)));
-    const u32 lane_off = (u32)__mul24(lr, gstride_row) + 16u * (u32)lc;
-    // two sets of row registers: a tile is asked for three steps before it is multiplied (memory latency under this
-    // kernel's traffic is about one step of one wave), spends two steps on its way and one in LDS
-    u32x4a nA[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, nB[2] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    auto load_rows = [&](int t, int set) {
-        const int yt = Y0 - B16_LEFT + 16 * t;           // (uniform)
-        u32 off;
-        if (yt >= 0 && yt + 15 < H) off = (u32)(yt * gstride_row) + lane_off;    // one scalar multiply, one vector add
-        else off = (u32)__mul24(reflect101(yt + lr, H), gstride_row) + 16u * (u32)lc;
-        const u8* r = g0 + off;
-        nA[set] = *reinterpret_cast<const u32x4a*>(r);
-        nB[set] = *reinterpret_cast<const u32x4a*>(r + 64);
+    const u8* gf = gray + (int64_t)n * gstride_n;        // (uniform)
+    const int X0 = min(max(16 * B16_NSW * bx - 64, 0), W - 16 * B16_NP);   // the workgroup's window [X0, X0 + 240): inside the row
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    __builtin_amdgcn_s_waitcnt(0x0F70);                  // operand fragments landed (see k_blur_mfma)
+    if (tid < B16_NS) { ready[tid] = 0; done[tid] = 0; }
+    __syncthreads();                                     // (the only barrier: fragments and counters are in place)
+
+    // ================================ the loader wave ===============================================================
+    // Tile tau = rows Y0 - 56 + 16 tau ..: 16 rows x 15 pieces of 16 bytes, four per lane (id = 64 k + lane: row id / 15,
+    // piece id % 15).  Three tiles are on their way at any time (three register sets, the loop unrolled by three), a tile
+    // is staged into ring slot tau % B16_NS once every strip has ticked off its reads of tile tau - B16_NS, and
+    // announced with a tick of ready[].  The strips never load a row: nothing of theirs queues behind a first touch of
+    // HBM, and this wave sees that latency three tiles deep.  Loads and waits are inline assembly: "at most 8
+    // outstanding" = the two younger tiles' loads (always issued, also past the last tile: clamped rows nobody reads),
+    // loads return in order.  Pieces that touch the image border are gathered byte by byte with the mirror rule
+    // (first / last workgroup of a row only); every lane always issues its four loads (a lane without a plain piece
+    // from a clamped address), so the count of operations in flight does not depend on the data.
+    if (is_loader) {
+        int prow[4];
+        bool pval[4];
+        u32 poff[4];
+        u8* pdst[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int id = 64 * k + lane;
+            pval[k] = id < 16 * B16_NP;
+            prow[k] = pval[k] ? id / B16_NP : 0;
+            const int pc = pval[k] ? id - B16_NP * prow[k] : 0;
+            poff[k] = (u32)(__mul24(prow[k], gstride_row) + X0 + 16 * pc);
+            pdst[k] = &stg[0][0] + B16_ROWB * prow[k] + 16 * pc;
+        }
+        u32x4 R[3][4];
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) R[j][k] = u32x4{0, 0, 0, 0};
+        auto row_of = [&](int t, int r) { return reflect101(Y0 - B16_LEFT + 16 * t + r, H); };
+        auto issue = [&](int t, u32x4 (&Rt)[4]) {
+            const int yt = Y0 - B16_LEFT + 16 * t;       // (uniform)
+            u32 o[4];
+            if (yt >= 0 && yt + 15 < H) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (u32)(yt * gstride_row) + poff[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = (u32)(__mul24(row_of(t, prow[k]) - prow[k], gstride_row)) + poff[k];
+            }
+            asm volatile("global_load_dwordx4 %0, %4, %8\n\tglobal_load_dwordx4 %1, %5, %8\n\t"
+                         "global_load_dwordx4 %2, %6, %8\n\tglobal_load_dwordx4 %3, %7, %8"
+                         : "=&v"(Rt[0]), "=&v"(Rt[1]), "=&v"(Rt[2]), "=&v"(Rt[3])
+                         : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "s"(gf) : "memory");
+        };
+        issue(0, R[0]);
+        issue(1, R[1]);
+        issue(2, R[2]);
+        int slot = 0, gen = 0;                           // slot = tau % B16_NS, gen = tau / B16_NS
+        for (int t0 = 0; t0 < nsteps; t0 += 3) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int t = t0 + j;
+                if (t >= nsteps) break;                  // uniform
+                if (gen > 0) {                           // the slot's last tile read by every strip?  (bounded spin)
+                    const u32 want = (u32)(B16_NSW * gen);
+                    for (int spin = 0; spin < (1 << 20); ++spin) {
+                        const u32 have = __hip_atomic_load(&done[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (__builtin_amdgcn_readfirstlane(have) >= want) break;
+                        __builtin_amdgcn_s_sleep(1);
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(8)" : "+v"(R[j][0]), "+v"(R[j][1]), "+v"(R[j][2]), "+v"(R[j][3]) :: "memory");
+                const int sb = slot * (16 * B16_ROWB);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    u8* dst = pdst[k] + sb;
+                    if (pval[k])
+                        *reinterpret_cast<uint4*>(dst) = make_uint4(R[j][k].x ^ 0x80808080u, R[j][k].y ^ 0x80808080u,
+                                                                    R[j][k].z ^ 0x80808080u, R[j][k].w ^ 0x80808080u);
+                }
+                // (release: the rows above are in LDS before the tick is)
+                if (lane == 0) __hip_atomic_fetch_add(&ready[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                issue(t + 3, R[j]);
+                if (++slot == B16_NS) { slot = 0; ++gen; }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[0][0]), "+v"(R[0][1]), "+v"(R[0][2]), "+v"(R[0][3]), "+v"(R[1][0]), "+v"(R[1][1]),
+                     "+v"(R[1][2]), "+v"(R[1][3]), "+v"(R[2][0]), "+v"(R[2][1]), "+v"(R[2][2]), "+v"(R[2][3]) :: "memory");
+        return;
+    }
+
+    // ================================ the strips ======================================================================
+    // LDS row: pixel x of the workgroup's window at byte 8 + (x - X0), so that every strip's operand window (it starts
+    // 8 + 16 wave pixels in) is 16-byte aligned.  Lane (g, q) takes row q: P = window bytes 16 g (+ 64 for g >= 2), Q = 32 + 16 g.
+    const u8* const rP = &stg[0][0] + B16_ROWB * q + (L0 - X0) + 16 * g + (g >= 2 ? 64 : 0);
+    const u8* const rQ = &stg[0][0] + B16_ROWB * q + (L0 - X0) + 32 + 16 * g;
+    // A tile is read once the loader has announced it (nearly always long before: the loader runs tiles ahead), and ticked
+    // off a step later, when its operands have been multiplied.  Bounded spins: a logic error shows up as wrong pixels in
+    // the parity tests, not as a hung GPU.
+    int rslot = 0, rgen = 0;                             // ring position of the NEXT tile to read
+    auto read_ops = [&](uint4& p, uint4& qq) {
+        const u32 want = (u32)rgen + 1u;
+        for (int spin = 0; spin < (1 << 20); ++spin) {
+            const u32 have = __hip_atomic_load(&ready[rslot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (__builtin_amdgcn_readfirstlane(have) >= want) break;
+            __builtin_amdgcn_s_sleep(1);
+        }
+        const uint2* a = reinterpret_cast<const uint2*>(rP + rslot * (16 * B16_ROWB));   // (8-byte aligned: two halves each)
+        const uint2* b = reinterpret_cast<const uint2*>(rQ + rslot * (16 * B16_ROWB));
+        const uint2 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
+        p = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        qq = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        if (++rslot == B16_NS) { rslot = 0; ++rgen; }
     };
-    auto stage_rows = [&](int set) {                     // p - 128 as int8
-        *wA = make_uint4(nA[set].x ^ 0x80808080u, nA[set].y ^ 0x80808080u, nA[set].z ^ 0x80808080u, nA[set].w ^ 0x80808080u);
-        *wB = make_uint4(nB[set].x ^ 0x80808080u, nB[set].y ^ 0x80808080u, nB[set].z ^ 0x80808080u, nB[set].w ^ 0x80808080u);
+    int dslot = 0;                                       // ring position of the next tile to tick off
+    auto tick_done = [&]() {
+        if (lane == 0) __hip_atomic_fetch_add(&done[dslot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (++dslot == B16_NS) dslot = 0;
     };
     v4i LhA = {0, 0, 0, 0}, LhB = {0, 0, 0, 0}, LlA = {0, 0, 0, 0}, LlB = {0, 0, 0, 0};   // large kernel: ring slots 0-3 / 4-7
     v4i S4h = {0, 0, 0, 0}, S4l = {0, 0, 0, 0};          // small kernel: tiles t-5 .. t-2
     int Sdh[4] = {0, 0, 0, 0}, Sdl[4] = {0, 0, 0, 0};    // small kernel: the last four tiles (slot t mod 4)
     const u32 span = (u32)span_i;
-    const u32 m16 = xw + 16 <= W ? 0xFFFFu : ((1u << (W - xw)) - 1u);
+    const u32 m16 = xw + 16 <= W ? 0xFFFFu : (live ? ((1u << (W - xw)) - 1u) : 0u);
     const u64 colmask = (u64)m16 * 0x0001000100010001ull;
     unsigned short* mb16 = reinterpret_cast<unsigned short*>(bits) + (int64_t)n * H * WW * 4 + strip;   // (uniform)
     const u32 sel1 = 0u - ((u32)lane & 1u), sel2 = 0u - (((u32)lane >> 1) & 1u);
     // Mask rows leave once per eight steps (lane j < 16 keeps the 16-bit pieces of rows yo + j of the eight tiles in four
-    // registers): while a store is in flight next to loads the memory counter cannot be waited on for "all but the
-    // newest loads" (loads and stores return out of order with respect to each other), and every wait for a tile would be
-    // a wait for the tile asked for one step ago as well.
+    // registers).
     u32 total = 0, pp[4] = {0, 0, 0, 0};
     auto flush_rows = [&](int tg) {                      // tiles of steps tg .. tg + 7
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int y = Y0 + 16 * (tg + k - 7) + lane;
-            if (lane < 16 && tg + k >= 7 && tg + k < nsteps && y < H)
+            if (live && lane < 16 && tg + k >= 7 && tg + k < nsteps && y < H)
                 mb16[(u32)__mul24(y, 4 * WW)] = (unsigned short)(pp[k >> 1] >> (16 * (k & 1)));
         }
     };
-    __builtin_amdgcn_s_waitcnt(0x0F70);                  // operand fragments landed (see k_blur_mfma)
-    load_rows(0, 1);
-    stage_rows(1);
-    load_rows(1, 1);                                     // tile t + 1 sits in set (t + 1) & 1
-    load_rows(2, 0);
-    uint4 aP_ = *rP, aQ_ = *rQ;                          // tile 0
+    uint4 aP_, aQ_;
+    read_ops(aP_, aQ_);                                  // tile 0
     for (int t0 = 0; t0 < nsteps; t0 += 8) {
 #pragma unroll
         for (int u = 0; u < 8; ++u) {                    // u = ring slot of step t: a constant of this copy of the body
@@ -557,12 +645,9 @@ __global__ __launch_bounds__(64 * B16_WAVES, 4) void k_blur16(const u8* __restri
             accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, sq, accS, 0, 0, 0);
             accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, lq, accL, 0, 0, 0);
             if (edge) accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aP, sp, accS, 0, 0, 0);
-            // behind the products: tile t + 1 (loaded a step ago) through LDS into next step's operands, tile t + 2 on its
-            // way
-            // (unconditionally: past the last tile these are rows the mirror rule still maps into the frame, and nobody
-            //  multiplies them; a branch here makes every wait for a load a wait for all of them)
-            stage_rows((u + 1) & 1); aP_ = *rP; aQ_ = *rQ;
-            load_rows(t + 3, (u + 1) & 1);
+            // behind the products: tile t's slot is free (its operands have been multiplied), tile t + 1 into next step's operands
+            tick_done();
+            if (t + 1 < nsteps) read_ops(aP_, aQ_);
             {
                 int hi, lo;
                 pack16(accL, hi, lo);
@@ -572,7 +657,7 @@ __global__ __launch_bounds__(64 * B16_WAVES, 4) void k_blur16(const u8* __restri
                 S4h[(u + 2) & 3] = Sdh[(u + 2) & 3];     // tile t - 2 (zeros for t < 2) takes the place of tile t - 6
                 S4l[(u + 2) & 3] = Sdl[(u + 2) & 3];
             }
-            if (t < 7) { if (u == 7) flush_rows(t0); continue; }
+            if (t >= 7) {
             // ---- vertical: output rows yo .. yo + 15, lane (g, q) gets rows yo + 4 g + i of column xw + q ----
             const int yo = Y0 + 16 * (t - 7);
             const v4i fa = v4i{(int)fa_.x, (int)fa_.y, (int)fa_.z, (int)fa_.w}, fb = v4i{(int)fb_.x, (int)fb_.y, (int)fb_.z, (int)fb_.w};
@@ -607,7 +692,7 @@ __global__ __launch_bounds__(64 * B16_WAVES, 4) void k_blur16(const u8* __restri
                 }
             }
             {
-                // lane j < 16 stores row yo + j: quarter j >> 2 of pw[j & 3] (as k_ncc_mfma does), behind the next step's loads
+                // lane j < 16 keeps row yo + j: quarter j >> 2 of pw[j & 3] (as k_ncc_mfma does)
                 const u32 x01l = (u32)pw[0] ^ (u32)pw[1], x01h = (u32)(pw[0] >> 32) ^ (u32)(pw[1] >> 32);
                 const u32 x23l = (u32)pw[2] ^ (u32)pw[3], x23h = (u32)(pw[2] >> 32) ^ (u32)(pw[3] >> 32);
                 const u32 t0l = (x01l & sel1) ^ (u32)pw[0], t0h = (x01h & sel1) ^ (u32)(pw[0] >> 32);
@@ -616,11 +701,12 @@ __global__ __launch_bounds__(64 * B16_WAVES, 4) void k_blur16(const u8* __restri
                 const u32 piece = ((lane & 8 ? vh : vl) >> (16 * ((lane >> 2) & 1))) & 0xFFFFu;
                 pp[u >> 1] = (u & 1) ? (pp[u >> 1] | (piece << 16)) : piece;
             }
+            }
             if (u == 7) flush_rows(t0);
         }
     }
     if (nsteps & 7) flush_rows(nsteps & ~7);
-    if (lane == 0 && total) atomicAdd(&fstat[n * 8 + 0], total);
+    if (live && lane == 0 && total) atomicAdd(&fstat[n * 8 + 0], total);
 }
 
 // Operand fragments of k_blur16 (lane = 16 g + index, byte e of a lane <-> k = 16 g + e):
@@ -669,7 +755,7 @@ void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& ta
 
 // the strips kernel takes the large branch on frames whose rows load as aligned dwords (else k_blur_mfma)
 static bool blur16_takes(const vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row) {
-    return h->blur_impl == 0 && h->blur16_h && !h->bp.small && h->W >= 128 && (h->W & 3) == 0 && h->H >= 64 &&
+    return h->blur_impl == 0 && h->blur16_h && !h->bp.small && h->W >= 16 * B16_NP && (h->W & 7) == 0 && h->H >= 64 &&
            (reinterpret_cast<uintptr_t>(gray) & 3) == 0 && (gstride_n & 3) == 0 && (gstride_row & 3) == 0 &&
            gstride_row >= h->W && gstride_row < (1 << 23) && (int64_t)h->H * gstride_row < (1ll << 31);
 }
@@ -693,7 +779,7 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
                  u8* area_u8, hipStream_t s) {
     const int k3 = 256 * (128 + 32768) + 32768, k8 = k3 + (15 - h->bp.thresh) * 65536;
     if (blur16_takes(h, gray, gstride_n, gstride_row)) {
-        const int gx16 = (64 * h->WW + 16 * B16_WAVES - 1) / (16 * B16_WAVES), tiles16 = (h->H + 15) / 16;
+        const int gx16 = (4 * h->WW + B16_NSW - 1) / B16_NSW, tiles16 = (h->H + 15) / 16;
         int nseg = std::min(tiles16 / 8, std::max(1, (2048 + gx16 * nb - 1) / (gx16 * nb)));     // few frames: split the columns
         nseg = std::max(nseg, 1);
         const int tps = (tiles16 + nseg - 1) / nseg;
@@ -702,10 +788,10 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
         const int xcd = nb >= 32 ? nb : 0;
         dim3 grid16 = xcd ? dim3((unsigned)((nb + 7) / 8 * 8 * gx16 * nseg)) : dim3(gx16, nseg, nb);
         if (area_u8)
-            VBS_LAUNCH(h, s, "k_blur16", k_blur16<true>, grid16, dim3(64 * B16_WAVES), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
+            VBS_LAUNCH(h, s, "k_blur16", k_blur16<true>, grid16, dim3(64 * (B16_NSW + 1)), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
                        h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg);
         else
-            VBS_LAUNCH(h, s, "k_blur16", k_blur16<false>, grid16, dim3(64 * B16_WAVES), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
+            VBS_LAUNCH(h, s, "k_blur16", k_blur16<false>, grid16, dim3(64 * (B16_NSW + 1)), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
                        h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg);
         return;
     }
