@@ -76,7 +76,7 @@ int vbs_version(void);
  * labelling / sums of `_marker_center` (:170-196) in the fused kernel (k_stage.hip) where the frame geometry allows it,
  * 1 always runs the separate kernels (k_morph + k_ccl) that other geometries take.  VBS_OPT_BLUR_IMPL (test hook /
  * fallback, results identical): 0 (default) runs the two GaussianBlurs (:118-129) on 16-column strips (k_blur16) where the
- * frame allows it (large branch, width a multiple of 4, rows that load as aligned dwords), 1 always runs the 32-column
+ * frame allows it (large branch, width >= 240 and a multiple of 8, rows that load as aligned dwords), 1 always runs the 32-column
  * kernel (k_blur_mfma) that every other frame takes.  VBS_OPT_PASS_STREAMS (tuning, results identical): 2 (default) lets
  * vbs_track_to_3d run the odd internal passes of a call on gray frames with a second workspace on the handle's own
  * stream (forked from and joined to the caller's stream by events), so that the tail of one pass's kernels overlaps the
