@@ -416,8 +416,8 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 // A workgroup = seven strips (waves 0..6) and ONE LOADER WAVE (wave 7).  The workgroup's window is 240 bytes of each row,
 // [X0, X0 + 240) with X0 = 112 bx - 64 shifted to stay inside the row; the loader keeps three tiles (16 rows x 15 pieces
 // of 16 bytes, four per lane) on their way from memory, stages a tile into one of six ring slots in LDS once every strip
-// has ticked off the tile that was there, and announces it with a tick; a strip waits for the tick of the tile it needs
-// (it nearly always finds it there: the loader runs tiles ahead), reads its own 128-byte window [L0, L0 + 128) out of
+// has ticked off the tile that was there, and announces it by counting `staged` up; a strip keeps the last count it saw and
+// asks again only when it needs a tile beyond it (the loader runs tiles ahead: every few steps), reads its own 128-byte window [L0, L0 + 128) out of
 // the slot as operand P = window bytes 0..31 and 96..127 and operand Q = bytes 32..95 (all the 39-tap kernel needs away
 // from the border), and ticks the slot off one step later.  The first touch of a row from HBM - which every strip of the
 // frame used to wait for at about the same time - is the loader's business three tiles ahead of anybody's need, and the
@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                                                    int k3, int k8, int span_i, int nframes, int gx, int gy) {
     __shared__ uint4 vf[12 * 64];
     __shared__ __align__(16) u8 stg[B16_NS][16 * B16_ROWB];
-    __shared__ u32 ready[B16_NS];                        // ready[s]: tiles the loader has staged into slot s, ever
+    __shared__ u32 staged;                               // tiles the loader has staged so far
     __shared__ u32 done[B16_NS];                         // done[s]: reads of slot s the strips have finished, ever
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -497,14 +497,15 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
     const int X0 = min(max(16 * B16_NSW * bx - 64, 0), W - 16 * B16_NP);   // the workgroup's window [X0, X0 + 240): inside the row
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // operand fragments landed (see k_blur_mfma)
-    if (tid < B16_NS) { ready[tid] = 0; done[tid] = 0; }
+    if (tid < B16_NS) done[tid] = 0;
+    if (tid == B16_NS) staged = 0;
     __syncthreads();                                     // (the only barrier: fragments and counters are in place)
 
     // ================================ the loader wave ===============================================================
     // Tile tau = rows Y0 - 56 + 16 tau ..: 16 rows x 15 pieces of 16 bytes, four per lane (id = 64 k + lane: row id / 15,
     // piece id % 15).  Three tiles are on their way at any time (three register sets, the loop unrolled by three), a tile
     // is staged into ring slot tau % B16_NS once every strip has ticked off its reads of tile tau - B16_NS, and
-    // announced with a tick of ready[].  The strips never load a row: nothing of theirs queues behind a first touch of
+    // announced by counting `staged` up.  The strips never load a row: nothing of theirs queues behind a first touch of
     // HBM, and this wave sees that latency three tiles deep.  Loads and waits are inline assembly: "at most 8
     // outstanding" = the two younger tiles' loads (always issued, also past the last tile: clamped rows nobody reads),
     // loads return in order.  Pieces that touch the image border are gathered byte by byte with the mirror rule
@@ -572,7 +573,7 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                                                                     R[j][k].z ^ 0x80808080u, R[j][k].w ^ 0x80808080u);
                 }
                 // (release: the rows above are in LDS before the tick is)
-                if (lane == 0) __hip_atomic_fetch_add(&ready[slot], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (lane == 0) __hip_atomic_fetch_add(&staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 issue(t + 3, R[j]);
                 if (++slot == B16_NS) { slot = 0; ++gen; }
             }
@@ -587,23 +588,26 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
     // 8 + 16 wave pixels in) is 16-byte aligned.  Lane (g, q) takes row q: P = window bytes 16 g (+ 64 for g >= 2), Q = 32 + 16 g.
     const u8* const rP = &stg[0][0] + B16_ROWB * q + (L0 - X0) + 16 * g + (g >= 2 ? 64 : 0);
     const u8* const rQ = &stg[0][0] + B16_ROWB * q + (L0 - X0) + 32 + 16 * g;
-    // A tile is read once the loader has announced it (nearly always long before: the loader runs tiles ahead), and ticked
-    // off a step later, when its operands have been multiplied.  Bounded spins: a logic error shows up as wrong pixels in
+    // A tile is read once the loader has counted it into `staged` (the strip remembers the last count it saw and asks again
+    // only beyond it: the loader runs tiles ahead), and ticked off a step later, when its operands have been multiplied.  Bounded spins: a logic error shows up as wrong pixels in
     // the parity tests, not as a hung GPU.
-    int rslot = 0, rgen = 0;                             // ring position of the NEXT tile to read
+    int rslot = 0;                                       // ring slot of the NEXT tile to read
+    u32 rt = 0, known = 0;                               // its index; tiles known to be staged (asked for again only beyond it)
     auto read_ops = [&](uint4& p, uint4& qq) {
-        const u32 want = (u32)rgen + 1u;
-        for (int spin = 0; spin < (1 << 20); ++spin) {
-            const u32 have = __hip_atomic_load(&ready[rslot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (__builtin_amdgcn_readfirstlane(have) >= want) break;
-            __builtin_amdgcn_s_sleep(1);
+        if (rt >= known) {
+            for (int spin = 0; spin < (1 << 20); ++spin) {
+                known = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&staged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+                if (rt < known) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
         }
         const uint2* a = reinterpret_cast<const uint2*>(rP + rslot * (16 * B16_ROWB));   // (8-byte aligned: two halves each)
         const uint2* b = reinterpret_cast<const uint2*>(rQ + rslot * (16 * B16_ROWB));
         const uint2 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
         p = make_uint4(a0.x, a0.y, a1.x, a1.y);
         qq = make_uint4(b0.x, b0.y, b1.x, b1.y);
-        if (++rslot == B16_NS) { rslot = 0; ++rgen; }
+        ++rt;
+        if (++rslot == B16_NS) rslot = 0;
     };
     int dslot = 0;                                       // ring position of the next tile to tick off
     auto tick_done = [&]() {
