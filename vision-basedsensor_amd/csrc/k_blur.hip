@@ -414,13 +414,13 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 //     of byte 2 and one compare per register, whose lane mask IS 4 rows x 16 mask bits
 //   * no workgroup barrier in the loop, and the strips never load a row: see below
 // A workgroup = seven strips (waves 0..6) and ONE LOADER WAVE (wave 7).  The workgroup's window is 240 bytes of each row,
-// [X0, X0 + 240) with X0 = 112 bx - 64 shifted to stay inside the row; the loader keeps three tiles (16 rows x 15 pieces
-// of 16 bytes, four per lane) on their way from memory, stages a tile into one of six ring slots in LDS once every strip
+// [X0, X0 + 240) with X0 = 112 bx - 64 shifted to stay inside the row; the loader keeps four tiles (16 rows x 15 pieces
+// of 16 bytes, four per lane) on their way from memory, stages a tile into one of eight ring slots in LDS once every strip
 // has ticked off the tile that was there, and announces it by counting `staged` up; a strip keeps the last count it saw and
 // asks again only when it needs a tile beyond it (the loader runs tiles ahead: every few steps), reads its own 128-byte window [L0, L0 + 128) out of
 // the slot as operand P = window bytes 0..31 and 96..127 and operand Q = bytes 32..95 (all the 39-tap kernel needs away
 // from the border), and ticks the slot off one step later.  The first touch of a row from HBM - which every strip of the
-// frame used to wait for at about the same time - is the loader's business three tiles ahead of anybody's need, and the
+// frame used to wait for at about the same time - is the loader's business four tiles ahead of anybody's need, and the
 // L1 sees 64 tag lookups per tile instead of 8 x 62.
 // (On the way here, us per frame at 1280x1024: every wave loading its own window straight into the operand layout 1.87 -
 // every lane of a load quad on another cache line; four lanes per 64 bytes of a row and a per-wave LDS hop 1.41; + a
@@ -437,7 +437,8 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 #define B16_NSW 7                                        // strips (compute waves) per workgroup; wave B16_NSW is the loader
 #define B16_NP 15                                        // 16-byte pieces of the workgroup's window per row: 112 + 128 columns
 #define B16_ROWB 272                                     // LDS bytes per staged row: 240 + pad; eight rows tile the banks
-#define B16_NS 6                                         // tiles of rows in LDS (ring slots)
+#define B16_NS 8                                         // tiles of rows in LDS (ring slots; 4: +3 %, 6: +2 % on the kernel's time)
+#define B16_LD 4                                         // tiles the loader keeps on their way from memory
 
 __device__ __forceinline__ void pack16(const v4i& acc, int& hi, int& lo) {
     const u32 t01 = __builtin_amdgcn_perm((u32)acc[1], (u32)acc[0], 0x05010400u);
@@ -503,11 +504,11 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
 
     // ================================ the loader wave ===============================================================
     // Tile tau = rows Y0 - 56 + 16 tau ..: 16 rows x 15 pieces of 16 bytes, four per lane (id = 64 k + lane: row id / 15,
-    // piece id % 15).  Three tiles are on their way at any time (three register sets, the loop unrolled by three), a tile
+    // piece id % 15).  Four tiles are on their way at any time (four register sets, the loop unrolled by four), a tile
     // is staged into ring slot tau % B16_NS once every strip has ticked off its reads of tile tau - B16_NS, and
     // announced by counting `staged` up.  The strips never load a row: nothing of theirs queues behind a first touch of
-    // HBM, and this wave sees that latency three tiles deep.  Loads and waits are inline assembly: "at most 8
-    // outstanding" = the two younger tiles' loads (always issued, also past the last tile: clamped rows nobody reads),
+    // HBM, and this wave sees that latency four tiles deep.  Loads and waits are inline assembly: "at most 12
+    // outstanding" = the three younger tiles' loads (always issued, also past the last tile: clamped rows nobody reads),
     // loads return in order.  Pieces that touch the image border are gathered byte by byte with the mirror rule
     // (first / last workgroup of a row only); every lane always issues its four loads (a lane without a plain piece
     // from a clamped address), so the count of operations in flight does not depend on the data.
@@ -525,9 +526,9 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
             poff[k] = (u32)(__mul24(prow[k], gstride_row) + X0 + 16 * pc);
             pdst[k] = &stg[0][0] + B16_ROWB * prow[k] + 16 * pc;
         }
-        u32x4 R[3][4];
+        u32x4 R[B16_LD][4];
 #pragma unroll
-        for (int j = 0; j < 3; ++j)
+        for (int j = 0; j < B16_LD; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) R[j][k] = u32x4{0, 0, 0, 0};
         auto row_of = [&](int t, int r) { return reflect101(Y0 - B16_LEFT + 16 * t + r, H); };
@@ -546,13 +547,12 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                          : "=&v"(Rt[0]), "=&v"(Rt[1]), "=&v"(Rt[2]), "=&v"(Rt[3])
                          : "v"(o[0]), "v"(o[1]), "v"(o[2]), "v"(o[3]), "s"(gf) : "memory");
         };
-        issue(0, R[0]);
-        issue(1, R[1]);
-        issue(2, R[2]);
-        int slot = 0, gen = 0;                           // slot = tau % B16_NS, gen = tau / B16_NS
-        for (int t0 = 0; t0 < nsteps; t0 += 3) {
 #pragma unroll
-            for (int j = 0; j < 3; ++j) {
+        for (int j = 0; j < B16_LD; ++j) issue(j, R[j]);
+        int slot = 0, gen = 0;                           // slot = tau % B16_NS, gen = tau / B16_NS
+        for (int t0 = 0; t0 < nsteps; t0 += B16_LD) {
+#pragma unroll
+            for (int j = 0; j < B16_LD; ++j) {
                 const int t = t0 + j;
                 if (t >= nsteps) break;                  // uniform
                 if (gen > 0) {                           // the slot's last tile read by every strip?  (bounded spin)
@@ -563,7 +563,8 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                         __builtin_amdgcn_s_sleep(1);
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(8)" : "+v"(R[j][0]), "+v"(R[j][1]), "+v"(R[j][2]), "+v"(R[j][3]) :: "memory");
+                static_assert(B16_LD == 4, "the wait below leaves the B16_LD - 1 younger tiles' loads outstanding");
+                asm volatile("s_waitcnt vmcnt(12)" : "+v"(R[j][0]), "+v"(R[j][1]), "+v"(R[j][2]), "+v"(R[j][3]) :: "memory");
                 const int sb = slot * (16 * B16_ROWB);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -574,12 +575,13 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                 }
                 // (release: the rows above are in LDS before the tick is)
                 if (lane == 0) __hip_atomic_fetch_add(&staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                issue(t + 3, R[j]);
+                issue(t + B16_LD, R[j]);
                 if (++slot == B16_NS) { slot = 0; ++gen; }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[0][0]), "+v"(R[0][1]), "+v"(R[0][2]), "+v"(R[0][3]), "+v"(R[1][0]), "+v"(R[1][1]),
-                     "+v"(R[1][2]), "+v"(R[1][3]), "+v"(R[2][0]), "+v"(R[2][1]), "+v"(R[2][2]), "+v"(R[2][3]) :: "memory");
+#pragma unroll
+        for (int j = 0; j < B16_LD; ++j)                 // (the loads past the last tile, never used, have landed)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(R[j][0]), "+v"(R[j][1]), "+v"(R[j][2]), "+v"(R[j][3]) :: "memory");
         return;
     }
 
