@@ -94,12 +94,14 @@ def _textured(h, w, n, seed):
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
-@pytest.mark.parametrize("h,w,view", [(600, 800, False), (1000, 1284, False), (520, 132, False), (1024, 1280, True)])
+@pytest.mark.parametrize("h,w,view", [(600, 800, False), (1000, 1284, False), (520, 132, False), (1024, 1280, True),
+                                      (488, 240, False), (500, 248, False), (700, 1288, False)])
 def test_blur_strips_equal_the_32_column_kernel_and_the_oracle(h, w, view):
     """a4-a5 through both blur kernels (VBS_OPT_BLUR_IMPL): the 16-column strips (k_blur16: rows straight into the
     operands, border mirror folded into each strip's fragments, windows shifted to stay inside the row) and the 32-column
     kernel give the oracle's area mask bit for bit on frames whose DoG crosses the range bounds everywhere - widths that
-    are no multiple of 16 / 64, a frame barely wider than one window, and a strided view of a larger buffer."""
+    are no multiple of 16 / 64 (1284, 132: the 32-column kernel either way), the narrowest frame the strips take (240: every
+    workgroup's window is the whole row), 248 and 1288 (a last strip of 8 columns), and a strided view of a larger buffer."""
     n = 2
     if view:
         big = torch.from_numpy(_textured(h + 8, w + 64, n, 5)).cuda()
