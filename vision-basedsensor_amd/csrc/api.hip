@@ -260,6 +260,7 @@ static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, in
 struct GrayPipe {
     vbs_handle* h; const u8* frames; int n, channels; int64_t stride_n, stride_row; hipStream_t s;
     bool on;
+    bool stagger = false;                               // two pass streams: a first pass of half a batch puts them out of phase
     int start() {
         on = h->gray_side && !h->undist && channels == 3 && n > h->maxb;
         if (!on) return VBS_OK;
@@ -268,7 +269,7 @@ struct GrayPipe {
         return convert(0);
     }
     // pass schedule: with the conversion pipelined, a short first pass keeps the only exposed conversion small
-    int lead() const { return on ? std::min(h->maxb, std::max(64, h->maxb / 8)) : h->maxb; }
+    int lead() const { return on ? std::min(h->maxb, std::max(64, h->maxb / 8)) : (stagger ? std::max(1, h->maxb / 2) : h->maxb); }
     int pass_off(int k) const { return k == 0 ? 0 : lead() + (k - 1) * h->maxb; }
     int pass_len(int k) const { return std::min(k == 0 ? lead() : h->maxb, n - pass_off(k)); }
     int convert(int k) {                                // pass k -> plane k & 1, on the side stream
@@ -635,6 +636,7 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
     // caller's tables; the second stream starts behind what the caller's stream holds and is joined before the return.
     const bool two = h->pass_streams == 2 && !h->prof && !h->undist && !gp.on && n > h->maxb;     // (gp.on: BGR converted a pass ahead on h->side)
     if (two) {
+        gp.stagger = true;
         if ((rc = twin_of(h)) != VBS_OK) return gp.fail(rc);
         HIPCHK(h, hipEventRecord(h->ev_tfork, s));
         HIPCHK(h, hipStreamWaitEvent(h->twin_stream, h->ev_tfork, 0));
