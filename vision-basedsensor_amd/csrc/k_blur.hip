@@ -417,8 +417,8 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 // [X0, X0 + 240) with X0 = 112 bx - 64 shifted to stay inside the row; the loader keeps four tiles (16 rows x 15 pieces
 // of 16 bytes, four per lane) on their way from memory, stages a tile into one of eight ring slots in LDS once every strip
 // has ticked off the tile that was there, and announces it by counting `staged` up; a strip keeps the last count it saw and
-// asks again only when it needs a tile beyond it (the loader runs tiles ahead: every few steps), reads its own 128-byte window [L0, L0 + 128) out of
-// the slot as operand P = window bytes 0..31 and 96..127 and operand Q = bytes 32..95 (all the 39-tap kernel needs away
+// asks again only when it needs a tile beyond it (the loader runs tiles ahead: every few steps), reads its own 128-byte
+// window [L0, L0 + 128) out of the slot as operand P = window bytes 0..31 and 96..127 and operand Q = bytes 32..95 (all the 39-tap kernel needs away
 // from the border), and ticks the slot off one step later.  The first touch of a row from HBM - which every strip of the
 // frame used to wait for at about the same time - is the loader's business four tiles ahead of anybody's need, and the
 // L1 sees 64 tag lookups per tile instead of 8 x 62.
@@ -427,7 +427,9 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 // frame's workgroups on one XCD 1.25, + eight strips per workgroup 1.21 = round 3's first product form; the shared
 // window with a barrier per tile 1.55, with tick counters in every wave 1.7, with this loader wave 3.4 - all three because
 // the pieces past the image border were gathered byte by byte behind a full wait for memory, in two workgroups of every
-// frame; with the border in the fragments instead, as above: 1.06-1.13.  With no row loads at all: 0.78-1.06.)
+// frame; with the border in the fragments instead, as above: 1.06-1.13; the strips re-reading the loader's count only
+// when they need a tile beyond the last one seen: 0.98-1.07; eight slots and four tiles in flight: 0.97-1.00.  With no row
+// loads at all: 0.78-1.06.)
 // Horizontal tile t = rows Y0 - 56 + 16 t ..: the output tile of step t (rows Y0 + 16 (t - 7) ..) reads tiles t-7 .. t of
 // the large kernel and tiles t-5 .. t-2 of the small one.  Ring slot = t mod 8 (mod 4), the step loop is unrolled by 8,
 // and what changes with the phase is the vertical fragment: 8 + 4 variants in LDS.
@@ -509,9 +511,8 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
     // announced by counting `staged` up.  The strips never load a row: nothing of theirs queues behind a first touch of
     // HBM, and this wave sees that latency four tiles deep.  Loads and waits are inline assembly: "at most 12
     // outstanding" = the three younger tiles' loads (always issued, also past the last tile: clamped rows nobody reads),
-    // loads return in order.  Pieces that touch the image border are gathered byte by byte with the mirror rule
-    // (first / last workgroup of a row only); every lane always issues its four loads (a lane without a plain piece
-    // from a clamped address), so the count of operations in flight does not depend on the data.
+    // loads return in order.  The window lies inside the row, so every piece is a plain 16-byte load; every lane always issues
+    // its four loads (the 16 lanes without a fourth piece repeat piece 0), so the count of operations in flight is fixed.
     if (is_loader) {
         int prow[4];
         bool pval[4];
