@@ -143,6 +143,28 @@ def test_blur_strips_many_frames_per_launch_equal_few():
     big.close(); small.close()
 
 
+def test_blur_strips_hand_shake_under_load():
+    """k_blur16's strips take their rows from a ring in LDS that a loader wave fills (counters, no barrier): 96 frames of
+    random smooth fields (made on the GPU; 40 % of the pixels in range) in one launch, twice, give the 32-column kernel's
+    area and NCC masks bit for bit - a lost or early tile would show as wrong pixels."""
+    h, w, n = 600, 808, 96
+    g = torch.Generator(device="cuda").manual_seed(4242)
+    lo = torch.randn((n, 1, h // 24 + 2, w // 24 + 2), device="cuda", generator=g) * 55 + 100
+    fr = torch.nn.functional.interpolate(lo, size=(h, w), mode="bicubic", align_corners=False)[:, 0]
+    fr = (fr + torch.randn((n, h, w), device="cuda", generator=g) * 10).clamp(0, 255).to(torch.uint8).contiguous()
+    eng = engine(h, w, max_batch=n)
+    got = []
+    for impl in (0, 1, 0):
+        eng.set_option(L.OPT_BLUR_IMPL, impl)
+        m, a = eng.find_markers(fr)
+        got.append((m.clone(), a.clone()))
+    eng.set_option(L.OPT_BLUR_IMPL, 0)
+    assert 0.2 < float((got[1][1] > 0).float().mean()) < 0.7
+    for k in (0, 2):
+        assert torch.equal(got[k][1], got[1][1]) and torch.equal(got[k][0], got[1][0])
+    eng.close()
+
+
 @pytest.mark.parametrize("h,w,pitch,dia", [(470, 650, 60, 20), (700, 1003, 72, 40)])
 def test_find_markers_borders_and_odd_sizes(h, w, pitch, dia):
     """a4-a8 where the matrix-core kernels leave their fast paths: sizes that are no multiple of the 32 / 64 / 128
