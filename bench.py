@@ -23,12 +23,20 @@ Extra objects on the JSON line:
                 for the staged entry `vbs_marker_center` on two uint8 images (k_threshold + the same kernels), with the
                 one-image (8d) and the two-image numerators.  `traffic` = HBM bytes per launch from the newest
                 profiles/*_pmc_traffic_<workload>.json (separate rocprofv3 --pmc passes), null when there is none.
+                `band_stage` = the 8(d) stage proper (band half of the kernel, from the committed phase log), `valu` = the
+                vector-issue share of the SIMDs' cycles in k_stage (committed SQ counters): the yardstick of a kernel that
+                reads 0.3 x its algorithmic bytes.
   roofline_mfma k_blur16 / k_blur_mfma (int8) and k_ncc_mfma (float16) against the dense matrix-core peaks: algorithmic
                 operations of the separable filters / live kernel time (same HIP events)
   kernels       live average ms per launch of every kernel of the fused path (one launch = `batch` frames)
   cpu_baseline  BASELINE.md 3: the NumPy/SciPy oracle (oracle/stages.py, a port: the reference needs OpenCV) on the
                 box's host cores over a bounded sample of the same frames (rank 0, N = 1 only): single process over
-                >= 32 frames after 2 warm-ups, and one worker process per physical core this job may use.
+                >= 32 frames after 2 warm-ups, and one worker process per core this job can really keep busy: the
+                smallest of physical cores, affinity mask, cgroup quota / cpuset and a MEASURED count (1, 2, 4, ... forked
+                busy loops until the aggregate rate stops growing: a shared box schedules fewer CPUs than its mask shows).
+                `cores` = the workers that ran; `oversubscribed` = a worker ran below half the single-process rate.
+  (A utilisation sampler with a period of seconds can show the GPU idle throughout: the timed region is ~0.3 s of a run
+   that spends two minutes rendering frames, in the CPU baseline and in the host-path leg.)
   config        also: bgr_fps (the same workload fed as 3-channel BGR frames, the reference's input format),
                 host_path_fps (NumPy frames in host memory -> CSV on disk through MarkerTracker), the NCC decision
                 counters of the timed batch, world size / backend as torch.distributed reports them.
@@ -98,7 +106,79 @@ def _host_cpus():
     return os.cpu_count() or 1, len(phys) or (os.cpu_count() or 1), usable, model
 
 
-def cpu_baseline(spec, seed, cam, single_frames, max_workers, per_worker, warm=2):
+def _cgroup_quota_cpus():
+    """CPUs the cgroup CPU controller grants this process (cpu.max of cgroup v2, cfs_quota_us / cfs_period_us of v1), and
+    the size of its effective cpuset; None where nothing is set or readable."""
+    quota = cpuset = None
+    paths = {}
+    try:
+        for line in open("/proc/self/cgroup"):
+            _, ctrl, path = line.rstrip("\n").split(":", 2)
+            for c in ctrl.split(","):
+                paths[c] = path
+    except OSError:
+        pass
+
+    def first(cands):
+        for c in cands:
+            try:
+                return open(c).read().strip()
+            except OSError:
+                continue
+        return None
+
+    v2 = paths.get("", "/")
+    t = first([f"/sys/fs/cgroup{v2.rstrip('/')}/cpu.max", "/sys/fs/cgroup/cpu.max"])
+    if t:
+        q, _, per = t.partition(" ")
+        if q != "max" and per:
+            quota = int(q) / int(per)
+    if quota is None:
+        v1 = paths.get("cpu", "/").rstrip("/")
+        q = first([f"/sys/fs/cgroup/cpu{v1}/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"])
+        per = first([f"/sys/fs/cgroup/cpu{v1}/cpu.cfs_period_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us"])
+        if q and per and int(q) > 0:
+            quota = int(q) / int(per)
+    cs = paths.get("cpuset", "/").rstrip("/")
+    t = first([f"/sys/fs/cgroup{v2.rstrip('/')}/cpuset.cpus.effective", "/sys/fs/cgroup/cpuset.cpus.effective",
+               f"/sys/fs/cgroup/cpuset{cs}/cpuset.effective_cpus", "/sys/fs/cgroup/cpuset/cpuset.effective_cpus"])
+    if t:
+        try:
+            cpuset = sum((int(b) - int(a) + 1) for a, _, b in (r.partition("-") for r in (x if "-" in x else f"{x}-{x}"
+                                                                                      for x in t.split(","))))
+        except ValueError:
+            cpuset = None
+    return quota, cpuset
+
+
+def _spin(seconds):
+    t_end = time.perf_counter() + seconds
+    n = 0
+    while time.perf_counter() < t_end:
+        for _ in range(2000):
+            n += 1
+    return n
+
+
+def probe_parallel_cpus(limit, seconds=0.25):
+    """How many CPUs this process can really keep busy at once: fork 1, 2, 4, ... busy loops for `seconds` each and take
+    the best aggregate rate over the one-process rate.  A box that shows 128 CPUs in its affinity mask but schedules 16 of
+    them (a quota the cgroup files do not always show) saturates here at 16.  Called BEFORE anything touches the GPU
+    (fork), takes about 2 s."""
+    import multiprocessing as mp
+    ctx = mp.get_context("fork")
+    rates, n = {}, 1
+    while n <= max(1, limit):
+        with ctx.Pool(n) as pool:
+            rates[n] = sum(pool.map(_spin, [seconds] * n)) / seconds
+        if n > 1 and rates[n] < 1.10 * rates[n // 2] and rates[n // 2] < 1.10 * rates.get(n // 4, 0.0):
+            break                                          # two doublings without gain: saturated
+        n *= 2
+    best = max(rates.values())
+    return {"effective_cpus": round(best / rates[1], 1), "rate_vs_one_process": {str(k): round(v / rates[1], 2) for k, v in rates.items()}}
+
+
+def cpu_baseline(spec, seed, cam, single_frames, max_workers, per_worker, warm=2, probe=None):
     """BASELINE.md 3: (i) single process, default FFT/BLAS threading, fps over >= 32 frames after 2 warm-ups;
     (ii) one worker process per physical core over disjoint frame ranges: min(physical cores, CPUs this process may run
     on) workers; `max_workers` > 0 caps that (a shared box that grants fewer CPUs than its affinity mask shows), and the
@@ -107,7 +187,15 @@ def cpu_baseline(spec, seed, cam, single_frames, max_workers, per_worker, warm=2
     import vbs_amd.synth as S
     from oracle import stages as O
     logical, physical, usable, model = _host_cpus()
-    available = max(1, min(physical, usable))
+    quota, cpuset = _cgroup_quota_cpus()
+    limits = {"physical_cores": physical, "affinity_mask": usable}
+    if quota:
+        limits["cgroup_quota"] = max(1, int(quota))
+    if cpuset:
+        limits["cgroup_cpuset"] = cpuset
+    if probe:
+        limits["measured_parallel_cpus"] = max(1, int(probe["effective_cpus"] + 0.5))
+    available = max(1, min(limits.values()))
     workers = min(available, max_workers) if max_workers > 0 else available
     for var in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):       # one worker = one core
         os.environ.setdefault(var, "1")
@@ -126,15 +214,21 @@ def cpu_baseline(spec, seed, cam, single_frames, max_workers, per_worker, warm=2
     wall = time.perf_counter() - t0
     busy = max(r[0] for r in res)
     total = sum(r[1] for r in res)
-    return {"value": round(total / busy, 3), "unit": "frames/s", "cores": workers, "cores_available": available, "kind": "port",
+    value = total / busy
+    per_worker_fps = value / workers
+    return {"value": round(value, 3), "unit": "frames/s", "cores": workers, "cores_available": available, "kind": "port",
+            "per_worker_fps": round(per_worker_fps, 3),
+            # a worker that runs at less than half the single-process rate did not have a core to itself
+            "oversubscribed": bool(per_worker_fps < 0.5 * single_fps),
+            "quota_cpus": quota, "cpu_limits": limits, "parallel_probe": probe,
             "single_process": {"value": round(single_fps, 3), "frames": n_single, "warmup_frames": warm,
                                "threads": "default FFT/BLAS threading"},
             "host": {"logical_cpus": logical, "physical_cores": physical, "usable_cpus": usable, "model": model},
             "sample": f"oracle/stages.py end to end (find_markers+marker_center+track+3D) on the benchmark's "
                       f"{spec.width}x{spec.height} frames: single process {n_single} frames after {warm} warm-ups = "
-                      f"{single_fps:.3f} frames/s; {workers} single-threaded worker processes on {available} available cores "
-                      f"(min of {physical} physical cores and {usable} CPUs in the affinity mask; {logical} logical"
-                      f"{', capped by --cpu-workers' if workers < available else ''}) x {per_worker} frames after "
+                      f"{single_fps:.3f} frames/s; {workers} single-threaded worker processes = the smallest of "
+                      f"{limits} ({logical} logical CPUs"
+                      f"{'; capped by --cpu-workers' if workers < available else ''}) x {per_worker} frames after "
                       f"{warm} warm-ups each = value; pool wall incl. spawn {wall:.1f}s"}
 
 
@@ -189,6 +283,15 @@ def main():
                     help="1 = gray frames (headline); 3 = the whole benchmark on BGR frames (the line then says so)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) | gloo (rehearsal of N>1 on one GPU)")
     args = ap.parse_args()
+
+    # the parallel-CPU probe of the cpu_baseline leg forks: it runs before anything touches the GPU
+    cpu_probe = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_cpu_baseline:
+        try:
+            cpu_probe = probe_parallel_cpus(_host_cpus()[2])
+        except Exception as e:
+            cpu_probe = None
+            print(f"parallel-CPU probe failed: {type(e).__name__}: {e}", file=sys.stderr)
 
     import numpy as np
     import torch
@@ -363,6 +466,45 @@ def main():
             "stage_ms_per_launch": round(stage_ms_launch, 4),
             "per_kernel_avg_ms": {k: round(prof[k][1] / prof[k][0], 4) for k in STAGE if k in prof},
             "us_per_frame": round(1e3 * stage_ms_launch / fpl, 3)}
+        # (a) SURVEY 8(d) defines the stage as band + label + three sums (24 B per label); the kernel on the timed path also
+        #     does the opened-mask half (a12-a13: opening, external contours, vertex moments).  `band_stage` is the 8(d) part
+        #     alone, from the newest committed phase log of the debug library (tools/gpu_stage_phase.py: the kernel stopped
+        #     after the band half's sums are out, `stop 10`); `opened_half_us_per_frame` is the rest of the live time.
+        # (b) the stage reads 0.3 x its algorithmic bytes and is bound by vector-instruction issue: `valu` = the share of the
+        #     SIMDs' cycles in which k_stage issues a vector instruction, from the newest committed SQ counters.
+        ph = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_stage_phase_timing_{args.workload}.log")))
+        if ph:
+            stops = {}
+            for line in open(ph[-1]):
+                parts = line.split(None, 2)
+                if len(parts) == 3 and parts[0] == "stop":
+                    try:
+                        stops[int(parts[1])] = json.loads(parts[2])
+                    except ValueError:
+                        pass
+            pick = next((k for k in (10, 4, 3, 2) if k in stops and "k_stage" in stops[k]), None)
+            if pick is not None:
+                band_us = float(stops[pick]["k_stage"])
+                live_us = 1e3 * stage_ms_launch / fpl
+                result["roofline"]["band_stage"] = {
+                    "what": "band + 4-connected labels + count / sum x / sum y per label: the SURVEY 8(d) stage proper",
+                    "us_per_frame": band_us, "frac": round(alg_bytes_frame / (band_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
+                    "opened_half_us_per_frame": round(max(live_us - band_us, 0.0), 3),
+                    "source": f"{os.path.basename(ph[-1])} (stop {pick}; debug library, batch 512, not measured in this run)"}
+        sqf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters_stage.json")))
+        if sqf and args.workload == "c3":
+            sj = json.load(open(sqf[-1]))
+            ks = sj.get("kernels", {}).get("k_stage", {})
+            if ks.get("SQ_INSTS_VALU") and ks.get("GRBM_GUI_ACTIVE"):
+                cyc = 4.0 * ks["SQ_ACTIVE_INST_VALU"]                       # the counter is in quad-cycles
+                avail = 1024.0 * ks["GRBM_GUI_ACTIVE"] / 8.0                 # 1024 SIMDs x the launch's cycles (counter summed over 8 XCDs)
+                result["roofline"]["valu"] = {
+                    "bound": "valu issue", "kernel": "k_stage",
+                    "instructions_per_frame": round(ks["SQ_INSTS_VALU"] / sj["frames_per_launch"]),
+                    "cycles_per_instruction": round(cyc / ks["SQ_INSTS_VALU"], 2),
+                    "simd_cycles_per_frame": round(avail / sj["frames_per_launch"]),
+                    "frac": round(cyc / avail, 4), "waves_per_simd": 3,
+                    "source": f"{os.path.basename(sqf[-1])} (rocprofv3 --pmc passes over a {sj['frames_per_launch']}-frame launch, not this run)"}
         # the staged entry on uint8 images (the reference's `_marker_center(mask, area_mask)` interface)
         if args.channels == 1:
             mask, area = eng.find_markers(frames[:nk])
@@ -412,7 +554,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             result["cpu_baseline"] = cpu_baseline(spec, args.seed, (K, dist, R, T), args.cpu_single_frames,
-                                                  args.cpu_workers, args.cpu_frames_per_worker)
+                                                  args.cpu_workers, args.cpu_frames_per_worker, probe=cpu_probe)
         except Exception as e:                                  # the baseline must not sink the GPU number
             result["cpu_baseline"] = {"value": None, "unit": "frames/s", "cores": 0, "kind": "port",
                                       "sample": f"failed: {type(e).__name__}: {e}"}

@@ -10,7 +10,11 @@
  *
  * Conventions
  *  - every pointer marked [dev] is device memory of the handle's GPU, owned by the caller;
- *    the library owns only the workspace inside `vbs_handle` (no allocation on a hot call);
+ *    the library owns only the workspace inside `vbs_handle`.  No allocation on a hot call, with two stated
+ *    exceptions that happen ONCE per handle and never under stream capture: the gray plane of 3-channel / undistorted
+ *    input (first such call, or vbs_set_undistort), and the second pass workspace of a handle left at the default
+ *    VBS_OPT_PASS_STREAMS (first call spanning several internal passes; vbs_set_option(h, VBS_OPT_PASS_STREAMS, 2)
+ *    builds it ahead of time - do that before capturing calls into a graph);
  *  - calls are asynchronous on `stream` (a hipStream_t passed as void*, NULL = default stream);
  *    the caller synchronises before reading results;
  *  - return value: VBS_OK or a negative status; `vbs_last_error` gives the text.  Per-frame
@@ -35,6 +39,9 @@ extern "C" {
 #define VBS_ECAPACITY  -2   /* more runs / components in a frame than the handle was sized for */
 #define VBS_EHIP       -3   /* a HIP runtime call failed                                      */
 #define VBS_ENOMEM     -4   /* workspace allocation failed                                    */
+#define VBS_EINTERNAL  -5   /* per-frame (in counts[i]): a kernel's internal hand-shake timed out - the frame's result is
+                               not to be trusted (never seen in practice: the wait is bounded so that a logic error or a
+                               lost workgroup cannot hang the GPU, and it reports here instead of continuing silently) */
 
 #define VBS_DET_COLS    6   /* x, y, major_axis, minor_axis, angle, label(band component, 1-based) */
 #define VBS_TABLE_COLS 10   /* flags, Cx, Cy, major, minor, angle, X, Y, Z, det_index            */
@@ -78,10 +85,14 @@ int vbs_version(void);
  * fallback, results identical): 0 (default) runs the two GaussianBlurs (:118-129) on 16-column strips (k_blur16) where the
  * frame allows it (large branch, width >= 240 and a multiple of 8, rows that load as aligned dwords), 1 always runs the 32-column
  * kernel (k_blur_mfma) that every other frame takes.  VBS_OPT_PASS_STREAMS (tuning, results identical): 2 (default) lets
- * vbs_track_to_3d run the odd internal passes of a call on gray frames with a second workspace on the handle's own
- * stream (forked from and joined to the caller's stream by events), so that the tail of one pass's kernels overlaps the
- * next pass; 1 runs every pass on the caller's stream.  (With vbs_profile on, passes run on one stream: the per-kernel
- * event timings would otherwise overlap.) */
+ * vbs_track_to_3d run the odd internal passes of a call (gray or BGR frames converted in line) with a SECOND WORKSPACE on
+ * the handle's own stream (forked from and joined to the caller's stream by events), so that the tail of one pass's kernels
+ * overlaps the next pass; 1 runs every pass on the caller's stream.  The second workspace is a second copy of every
+ * per-pass buffer (twice the device memory of the handle).  Setting the option to 2 EXPLICITLY builds it at once (a set-up
+ * call: allocations, copies, one device synchronisation; VBS_ENOMEM / VBS_EHIP if it cannot be built).  A handle left at
+ * the default builds it at its first call that spans several passes; if that call's stream is being captured, or the
+ * workspace cannot be built, the call runs every pass on the caller's stream instead.  (With vbs_profile on, passes run on
+ * one stream: the per-kernel event timings would otherwise overlap.) */
 #define VBS_OPT_GRAY_COEFFS      1
 #define VBS_OPT_FORCE_SEQ_MATCH  2
 #define VBS_OPT_GRAY_SIDE_STREAM 3
@@ -154,7 +165,7 @@ int vbs_normxcorr2_general(int device, const double* tmpl, int th, int tw, const
  * and writes one text line per kernel: "<name> <launches> <total_ms>". */
 int vbs_profile(vbs_handle* h, int enable);
 int vbs_profile_read(vbs_handle* h, char* buf, int cap);
-/* host copy of the per-frame counters of the LAST internal pass: out[i*8 + {0: area_mask popcount,
+/* host copy of the per-frame counters of the LAST internal pass (of whichever workspace ran it): out[i*8 + {0: area_mask popcount,
  * 1: NCC pixels within 1e-9 (relative) of the 0.1 threshold, 2: status, 3: NCC pixels re-evaluated in float64,
  * 4: holes LEFT in the opened area mask (components - Euler number; holes are filled before contouring, like
  * cv2.findContours(RETR_EXTERNAL) ignores them, so this is 0 unless the fill pass ran out of capacity), 5 / 6: connected

@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """Turn the raw rocprofv3 output merged back under gpurun_out/ into the small files kept in profiles/:
-   <tag>_rocprofv3_kernel_stats.csv     rows of this repo's kernels from `--kernel-trace --stats`
+   <tag>_rocprofv3_kernel_stats.csv     rows of this repo's kernels from `--kernel-trace --stats` (rocprofv3's own table: it
+                                        averages EVERY call of a name, one-frame launches included)
+   <tag>_kernel_trace_by_shape.json     the same kernels from the per-dispatch trace, averaged over launches of the benchmark
+                                        shape only (the numbers DESIGN.md quotes)
    <tag>_pmc_traffic_<workload>.json    HBM traffic per launch of the threshold+CCL stage of the FUSED path from the
                                         FETCH_SIZE / WRITE_SIZE passes (profiles/collect.sh), workload c3 / c5
    <tag>_sq_counters.json               SQ counters of the matrix-core kernels
@@ -36,6 +39,37 @@ with open(os.path.join(ROOT, "profiles", f"{tag}_rocprofv3_kernel_stats.csv"), "
     for r in rows[1:]:
         if r[0].startswith(("void k_", "k_")):
             w.writerow(r)
+
+# Per-kernel averages over launches of ONE shape only.  rocprofv3's kernel_stats.csv averages every call of a name: the bench
+# also launches each kernel once on a single frame (frame 0's reference table), and that 15 us call in an average of eleven
+# 500 us calls made round 3's quoted per-frame times 9 % too low.  From the kernel TRACE: calls are
+# grouped by grid size, the group with the largest total duration is the benchmark shape, and `us_per_frame` divides ITS
+# average by the frames one such launch covers.
+trace = one(f"prof_{tag}/**/*kernel_trace.csv", required=False)
+if trace:
+    by = collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(trace)):
+        k = kname(r["Kernel_Name"])
+        if not k.startswith("k_"):
+            continue
+        grid = (int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
+        by[k][grid].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    shapes = {}
+    for k, groups in sorted(by.items()):
+        grid, d = max(groups.items(), key=lambda kv: sum(kv[1]))
+        d_sorted = sorted(d)
+        shapes[k] = {"grid": list(grid), "calls": len(d), "avg_ns": round(sum(d) / len(d), 1), "min_ns": d_sorted[0],
+                     "median_ns": d_sorted[len(d) // 2], "max_ns": d_sorted[-1],
+                     "us_per_frame": round(sum(d) / len(d) / frames / 1e3, 4),
+                     "other_shapes": {"x".join(map(str, g)): {"calls": len(v), "avg_ns": round(sum(v) / len(v), 1)}
+                                      for g, v in groups.items() if g != grid},
+                     "all_calls_avg_ns": round(sum(sum(v) for v in groups.values()) / sum(len(v) for v in groups.values()), 1)}
+    json.dump({"tag": tag, "frames_per_launch": frames, "source": "rocprofv3 --kernel-trace, calls grouped by grid size; the "
+               "group with the largest total duration per kernel (the benchmark shape)", "kernels": shapes},
+              open(os.path.join(ROOT, "profiles", f"{tag}_kernel_trace_by_shape.json"), "w"), indent=1)
+    for k, v in shapes.items():
+        print(f"{k:16s} {v['calls']:4d} launches of grid {v['grid']}: {v['us_per_frame']:.3f} us/frame "
+              f"(all {sum(len(x) for x in by[k].values())} calls averaged: {v['all_calls_avg_ns'] / frames / 1e3:.3f})")
 
 
 def counter(pattern):

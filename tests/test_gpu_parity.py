@@ -1060,6 +1060,96 @@ def test_two_handles_of_different_sizes_alternate():
         e.close()
 
 
+def test_multi_pass_call_captured_into_a_graph_replays_bit_identically():
+    """A vbs_track_to_3d call that spans several internal passes on two pass streams, captured into a HIP graph (the second
+    workspace was built ahead of time by vbs_set_option(VBS_OPT_PASS_STREAMS, 2): nothing in the call allocates or
+    synchronises) and replayed twice, equals the eager call bit for bit; on a handle left at the default, whose second
+    workspace does not exist yet, a captured call runs on one stream instead of breaking the capture - same table."""
+    from vbs_amd.engine import Engine
+    from vbs_amd.pipeline import reference_from_frame0
+    spec = S.config1()
+    n = 22
+    ft = S.make_frames_torch(spec, range(n), seed=5, device="cuda")
+    cam = L.make_camera(*S.default_camera(spec), 2.0)
+    for eager_twin in (True, False):
+        eng = Engine(spec.height, spec.width, max_markers=256, max_batch=4)
+        ids, xy = reference_from_frame0(eng, ft[:1], 5, "full", "optimal")
+        xy_d = torch.as_tensor(xy, dtype=torch.float64, device="cuda")
+        if eager_twin:
+            eng.set_option(L.OPT_PASS_STREAMS, 2)            # builds the second workspace now
+            want, _, wc = eng.track_to_3d(ft, xy_d, 20.0, cam, 5.0)
+        else:
+            # the reference result from another handle: this one must meet its first multi-pass call under capture
+            e2 = Engine(spec.height, spec.width, max_markers=256, max_batch=4)
+            want, _, wc = e2.track_to_3d(ft, xy_d, 20.0, cam, 5.0)
+            torch.cuda.synchronize()
+            e2.close()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                table, _, counts = eng.track_to_3d(ft, xy_d, 20.0, cam, 5.0)
+        torch.cuda.current_stream().wait_stream(side)
+        for rep in range(2):
+            table.zero_(); counts.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert counts.tolist() == [spec.n_markers] * n, (eager_twin, rep)
+            assert torch.equal(table, want) and torch.equal(counts, wc), (eager_twin, rep)
+        del g
+        eng.close()
+
+
+def test_frame_stats_follow_the_last_pass_onto_the_second_workspace():
+    """vbs_frame_stats / vbs_stage_tables describe the LAST internal pass wherever it ran: with two pass streams and a
+    staggered first pass (4 frames at batch 8), 20 frames are passes of 4, 8, 8 - the last on the caller's workspace -
+    and 28 frames passes of 4, 8, 8, 8 - the last on the second workspace; both equal a one-stream handle's view."""
+    from vbs_amd.engine import Engine
+    spec = S.config1()
+    for n in (20, 28):
+        ft = S.make_frames_torch(spec, range(n), seed=9, device="cuda")
+        views = []
+        for ps in (1, 2):
+            eng = Engine(spec.height, spec.width, max_markers=256, max_batch=8)
+            eng.set_option(L.OPT_PASS_STREAMS, ps)
+            eng.track_to_3d(ft)
+            views.append((eng.frame_stats(8), eng.stage_tables(8)["ncomp"]))
+            eng.close()
+        # one stream: passes of 8, 8, 4 (20) / 8, 8, 8, 4 (28): its last pass holds the last 4 frames, which are also the
+        # last 4 of the staggered schedule's last pass of 8
+        k = 4
+        assert np.array_equal(views[1][0][8 - k:, [0, 2, 5, 6]], views[0][0][:k, [0, 2, 5, 6]]), n
+        assert np.array_equal(views[1][1][8 - k:], views[0][1][:k]), n
+        assert (views[1][0][:, 5] == spec.n_markers).all() and (views[1][0][:, 0] > 0).all(), n
+
+
+def test_gray_plane_is_allocated_at_first_bgr_use_and_not_under_capture():
+    """The gray plane of 3-channel input no longer exists on a handle that only sees gray frames; the first BGR call
+    allocates it - unless that call is being captured, which is refused with a message instead of breaking the capture."""
+    from vbs_amd.engine import Engine
+    spec = S.config1()
+    g1 = S.make_frames_torch(spec, range(2), seed=1, device="cuda")
+    bgr = g1.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+    eng = Engine(spec.height, spec.width, max_markers=256, max_batch=2)
+    free0 = torch.cuda.mem_get_info()[0]
+    m_gray, a_gray = eng.find_markers(g1)
+    torch.cuda.synchronize()
+    assert torch.cuda.mem_get_info()[0] == free0           # gray input: nothing was allocated by the call
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with pytest.raises(ValueError, match="outside stream capture"):
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(graph, stream=side):
+                eng.find_markers(bgr)
+    torch.cuda.synchronize()
+    m_bgr, a_bgr = eng.find_markers(bgr)                    # allocates the plane (B = G = R: the same masks)
+    assert torch.equal(m_bgr, m_gray) and torch.equal(a_bgr, a_gray)
+    eng.close()
+
+
 def test_passes_on_two_streams_equal_one():
     """VBS_OPT_PASS_STREAMS: the odd internal passes of vbs_track_to_3d on the handle's second workspace and stream
     (default) give, row for row, what all passes on the caller's stream give - tables, detections, counts and the running

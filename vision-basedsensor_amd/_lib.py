@@ -5,7 +5,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libvbs.so")
 
-VBS_OK, VBS_EINVAL, VBS_ECAPACITY, VBS_EHIP, VBS_ENOMEM = 0, -1, -2, -3, -4
+VBS_OK, VBS_EINVAL, VBS_ECAPACITY, VBS_EHIP, VBS_ENOMEM, VBS_EINTERNAL = 0, -1, -2, -3, -4, -5
 DET_COLS, TABLE_COLS, DISP_COLS, PLANE_COLS, DEVPLANE_COLS = 6, 10, 5, 5, 9
 FLAG_TRACKED, FLAG_XYZ = 1, 2
 OPT_GRAY_COEFFS, OPT_FORCE_SEQ_MATCH, OPT_GRAY_SIDE_STREAM, OPT_NCC_MARGIN, OPT_STAGE_IMPL, OPT_BLUR_IMPL, OPT_PASS_STREAMS = 1, 2, 3, 4, 5, 6, 7
@@ -27,6 +27,17 @@ class Camera(C.Structure):
 
 class VbsError(RuntimeError):
     pass
+
+
+def status_text(status: int, max_markers: int = 0) -> str:
+    """What a negative per-frame status in `counts[]` means (include/vbs.h)."""
+    if status == VBS_ECAPACITY:
+        return ("the frame exceeds the device workspace (more than 30720 runs in a mask, more than "
+                f"{max_markers or 'max_markers'} band components, or more than about 512 contours)")
+    if status == VBS_EINTERNAL:
+        return ("a kernel's internal hand-shake timed out: the frame's result is not to be trusted (bounded wait expired; "
+                "see VBS_EINTERNAL in include/vbs.h)")
+    return "unexpected device status"
 
 
 _lib = None

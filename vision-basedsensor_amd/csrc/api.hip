@@ -154,10 +154,10 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
         if (!bp.small && width >= 128 && (width & 3) == 0) blur16_fragments(ka, kb, width, &frags16h, &frags16v);
     }
 
-    const size_t B = (size_t)max_batch, HW = (size_t)height * h->WW, HP = (size_t)height * h->P;
+    const size_t B = (size_t)max_batch, HW = (size_t)height * h->WW;
     int rc;
 #define ALLOC(field, count) if ((rc = dev_alloc(h, &h->field, (count))) != VBS_OK) return rc
-    ALLOC(gray, B * HP); ALLOC(gray2, B * HP);
+    h->gray = h->gray2 = nullptr;                       // allocated at the first 3-channel / undistorted use (need_gray)
     ALLOC(area_bits, B * HW); ALLOC(mask_bits, B * HW); ALLOC(band_bits, B * HW);
     ALLOC(open_bits, B * HW);
     ALLOC(ncc_rx, (size_t)width); ALLOC(ncc_ry, (size_t)height);
@@ -234,11 +234,36 @@ static int check_launch(vbs_handle* h) {
     return VBS_OK;
 }
 
+static bool capturing(hipStream_t s) {
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
+// Gray planes of 3-channel / undistorted input ([maxb][H][P] each; the second one only serves VBS_OPT_GRAY_SIDE_STREAM):
+// gray frames never touch them, so they are allocated at the first call that needs them, or by vbs_set_undistort /
+// vbs_set_option(VBS_OPT_GRAY_SIDE_STREAM).  Never under stream capture: there the call fails and says why.
+static int need_gray(vbs_handle* h, int planes, hipStream_t s) {
+    u8** slot[2] = {&h->gray, &h->gray2};
+    for (int i = 0; i < planes; ++i) {
+        if (*slot[i]) continue;
+        if (capturing(s)) {
+            h->err = "the gray plane of 3-channel / undistorted input is allocated at first use: run one such call (or "
+                     "vbs_set_undistort) outside stream capture first";
+            return VBS_EINVAL;
+        }
+        int rc = dev_alloc(h, slot[i], (size_t)h->maxb * h->H * h->P);
+        if (rc != VBS_OK) return rc;
+    }
+    return VBS_OK;
+}
+
 // One internal pass of the detection stage.  `pre` = gray plane already converted for this pass (vbs_detect_loop's
 // side-stream pipeline), else the conversion runs here on `s`.
 static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
                        int64_t stride_row, u8* mask_u8, u8* area_u8, double* ncc_out, hipStream_t s, const u8* pre = nullptr) {
-    HIPCHK(h, hipMemsetAsync(h->fstat, 0, (size_t)nb * 8 * sizeof(u32), s));
+    if (!pre && (h->undist || channels != 1)) { int rc = need_gray(h, 1, s); if (rc != VBS_OK) return rc; }
+    h->last_ws = h; h->last_nb = nb;                     // (vbs_track_to_3d names the workspace of ITS last pass afterwards)
+    launch_fill(h->fstat, 0u, (size_t)nb * 8, s);
     if (pre) {
         launch_blur(h, pre, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
     } else if (h->undist) {                             // marker_detection.py:88-89: undistort, then cvtColor
@@ -264,6 +289,7 @@ struct GrayPipe {
     int start() {
         on = h->gray_side && !h->undist && channels == 3 && n > h->maxb;
         if (!on) return VBS_OK;
+        { int rc = need_gray(h, 2, s); if (rc != VBS_OK) { on = false; return rc; } }
         HIPCHK(h, hipEventRecord(h->ev_fork, s));
         HIPCHK(h, hipStreamWaitEvent(h->side, h->ev_fork, 0));
         return convert(0);
@@ -376,7 +402,7 @@ extern "C" int vbs_normxcorr2(vbs_handle* h, const uint8_t* area_mask, int n, do
     const size_t hw = (size_t)h->H * h->W;
     for (int off = 0; off < n; off += h->maxb) {
         int nb = std::min(h->maxb, n - off);
-        HIPCHK(h, hipMemsetAsync(h->fstat, 0, (size_t)nb * 8 * sizeof(u32), s));
+        launch_fill(h->fstat, 0u, (size_t)nb * 8, s);
         launch_threshold(h, area_mask + off * hw, area_mask + off * hw, nb, s);
         launch_popcount(h, nb, s);
         launch_ncc(h, nb, mask ? mask + off * hw : nullptr, ncc ? ncc + off * hw : nullptr, s);
@@ -386,6 +412,8 @@ extern "C" int vbs_normxcorr2(vbs_handle* h, const uint8_t* area_mask, int n, do
     return VBS_OK;
 }
 
+static int twin_of(vbs_handle* h);
+
 extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
     if (!h) return VBS_EINVAL;
     if (h->twin && option != VBS_OPT_PASS_STREAMS) (void)vbs_set_option(h->twin, option, value);   // (same checks, same answer)
@@ -393,9 +421,15 @@ extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
         case VBS_OPT_PASS_STREAMS:
             if (value != 1 && value != 2) break;
             h->pass_streams = value;
+            // an explicit 2 builds the second workspace NOW (a set-up call: allocations, copies, a device synchronisation),
+            // so that no later vbs_track_to_3d has to - and a call captured into a graph finds it in place
+            if (value == 2 && !h->is_twin) { int rc = twin_of(h); if (rc != VBS_OK) return rc; }
             return VBS_OK;
         case VBS_OPT_FORCE_SEQ_MATCH: h->force_seq_match = value != 0; return VBS_OK;
-        case VBS_OPT_GRAY_SIDE_STREAM: h->gray_side = value != 0; return VBS_OK;
+        case VBS_OPT_GRAY_SIDE_STREAM:
+            h->gray_side = value != 0;
+            if (h->gray_side) { HIPCHK(h, hipSetDevice(h->device)); int rc = need_gray(h, 2, nullptr); if (rc != VBS_OK) return rc; }
+            return VBS_OK;
         case VBS_OPT_NCC_MARGIN:
             if (value < 0 || value > 100000) break;
             h->ncc_margin_ppm = value;
@@ -470,7 +504,9 @@ extern "C" int vbs_set_undistort(vbs_handle* h, const double* K9, const double* 
         return VBS_EINVAL;
     }
     HIPCHK(h, hipSetDevice(h->device));
-    int rc = setup_undistort(h, K9, dist, ndist, (hipStream_t)stream);
+    int rc = need_gray(h, 1, (hipStream_t)stream);      // (a set-up call: the plane the undistorted frames go to)
+    if (rc != VBS_OK) return rc;
+    rc = setup_undistort(h, K9, dist, ndist, (hipStream_t)stream);
     if (rc != VBS_OK) return rc;
     h->undist = true;
     if (newK9) for (int i = 0; i < 9; ++i) newK9[i] = h->newK[i];
@@ -490,10 +526,14 @@ extern "C" int vbs_undistort_frames(vbs_handle* h, const uint8_t* frames, int n,
     return check_launch(h);
 }
 
+// the workspace the last internal pass ran in: with two pass streams that is the second workspace for an odd last pass
+static vbs_handle* last_ws(vbs_handle* h) { return (h->last_ws && (h->last_ws == h || h->last_ws == h->twin)) ? h->last_ws : h; }
+
 extern "C" int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n) {
     if (!h || !out || n < 0 || n > h->maxb) return VBS_EINVAL;
     HIPCHK(h, hipSetDevice(h->device));
-    HIPCHK(h, hipMemcpy(out, h->fstat, (size_t)n * 8 * sizeof(u32), hipMemcpyDeviceToHost));
+    HIPCHK(h, hipDeviceSynchronize());                   // (the last pass may have run on the handle's own stream)
+    HIPCHK(h, hipMemcpy(out, last_ws(h)->fstat, (size_t)n * 8 * sizeof(u32), hipMemcpyDeviceToHost));
     return VBS_OK;
 }
 
@@ -503,6 +543,9 @@ extern "C" int vbs_stage_tables(vbs_handle* h, int n, uint32_t* ncomp, uint64_t*
     HIPCHK(h, hipSetDevice(h->device));
     HIPCHK(h, hipDeviceSynchronize());
     const size_t N = (size_t)n, M = (size_t)h->maxm;
+    vbs_handle* const caller = h;
+    h = last_ws(h);
+    (void)caller;
     if (ncomp) HIPCHK(h, hipMemcpy(ncomp, h->ncomp, N * 2 * sizeof(u32), hipMemcpyDeviceToHost));
     if (band_sums) HIPCHK(h, hipMemcpy(band_sums, h->band_sums, N * M * 4 * sizeof(u64), hipMemcpyDeviceToHost));
     if (area_first) HIPCHK(h, hipMemcpy(area_first, h->area_first, N * M * sizeof(u32), hipMemcpyDeviceToHost));
@@ -553,7 +596,8 @@ extern "C" int vbs_marker_center(vbs_handle* h, const uint8_t* mask, const uint8
     const size_t hw = (size_t)h->H * h->W;
     for (int off = 0; off < n; off += h->maxb) {
         int nb = std::min(h->maxb, n - off);
-        HIPCHK(h, hipMemsetAsync(h->fstat, 0, (size_t)nb * 8 * sizeof(u32), s));
+        launch_fill(h->fstat, 0u, (size_t)nb * 8, s);
+        h->last_ws = h; h->last_nb = nb;
         launch_threshold(h, mask + off * hw, area_mask + off * hw, nb, s);
         launch_labelling(h, nb, s);
         launch_finalize(h, nb, det + (size_t)off * h->maxm * VBS_DET_COLS, counts + off, s);
@@ -601,15 +645,22 @@ static int twin_of(vbs_handle* h) {
         return rc;
     }
     t->pass_streams = 1;
+    t->is_twin = true;
     t->gray_bits = h->gray_bits; t->force_seq_match = h->force_seq_match; t->ncc_margin_ppm = h->ncc_margin_ppm;
     t->stage_impl = h->stage_impl; t->blur_impl = h->blur_impl;
-    if (hipStreamCreateWithFlags(&h->twin_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_tfork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&h->ev_tjoin, hipEventDisableTiming) != hipSuccess) {
+    hipStream_t st = nullptr;
+    hipEvent_t ef = nullptr, ej = nullptr;
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ef, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ej, hipEventDisableTiming) != hipSuccess) {
+        if (st) (void)hipStreamDestroy(st);             // (whatever of the three exists goes: nothing half-made stays on h)
+        if (ef) (void)hipEventDestroy(ef);
+        if (ej) (void)hipEventDestroy(ej);
         (void)vbs_destroy(t);
         h->err = "second pass workspace: stream / event creation failed";
         return VBS_EHIP;
     }
+    h->twin_stream = st; h->ev_tfork = ef; h->ev_tjoin = ej;
     h->twin = t;
     return VBS_OK;
 }
@@ -634,10 +685,16 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
     // round of one pass's kernels runs next to the other pass - and, for BGR frames, the bandwidth-bound conversion of one pass
     // next to the matrix-core kernels of the other (each workspace converts into its own gray plane).  Every pass writes its own slice of the
     // caller's tables; the second stream starts behind what the caller's stream holds and is joined before the return.
-    const bool two = h->pass_streams == 2 && !h->prof && !h->undist && !gp.on && n > h->maxb;     // (gp.on: BGR converted a pass ahead on h->side)
+    bool two = h->pass_streams == 2 && !h->prof && !h->undist && !gp.on && n > h->maxb;     // (gp.on: BGR converted a pass ahead on h->side)
+    if (two && !h->twin) {
+        // The second workspace normally exists by now (vbs_set_option(VBS_OPT_PASS_STREAMS, 2) builds it).  A handle left at
+        // the default builds it at its first call that spans several passes - unless the caller's stream is being captured
+        // (allocations and the device synchronisation of a set-up would break the capture), and if it cannot be built
+        // (memory) the call simply runs every pass on the caller's stream: results are identical either way.
+        if (capturing(s) || twin_of(h) != VBS_OK) { two = false; h->err.clear(); }
+    }
     if (two) {
         gp.stagger = true;
-        if ((rc = twin_of(h)) != VBS_OK) return gp.fail(rc);
         HIPCHK(h, hipEventRecord(h->ev_tfork, s));
         HIPCHK(h, hipStreamWaitEvent(h->twin_stream, h->ev_tfork, 0));
     }
@@ -657,6 +714,7 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
         rc = detect_pass(hh, frames + (int64_t)off * stride_n, nb, channels, stride_n, stride_row, nullptr, nullptr, nullptr,
                          ss, plane);
         if (rc != VBS_OK) { if (hh != h) h->err = hh->err; return join(gp.fail(rc)); }
+        h->last_ws = hh; h->last_nb = nb;                // (what vbs_frame_stats / vbs_stage_tables read)
         if ((rc = gp.release(k)) != VBS_OK) return join(gp.fail(rc));
         launch_labelling(hh, nb, ss);
         launch_finalize(hh, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr,

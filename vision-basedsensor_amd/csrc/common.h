@@ -55,7 +55,7 @@ struct vbs_handle {
     NccConst ncc;
     std::string err;
     // ---- device workspace (per internal pass of maxb frames) ----
-    u8* gray;          // [maxb][H][P]   gray plane of 3-channel / undistorted input
+    u8* gray;          // [maxb][H][P]   gray plane of 3-channel / undistorted input; null until first needed (need_gray)
     u8* gray2;         // second plane: the conversion of pass k + 1 runs on `side` while pass k computes
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_gray[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
@@ -67,6 +67,9 @@ struct vbs_handle {
     // caller's stream and a second workspace (`twin`, created at first use) on `twin_stream`
     int pass_streams = 2;
     vbs_handle* twin = nullptr;
+    bool is_twin = false;                  // this handle IS some handle's second workspace (never grows one of its own)
+    vbs_handle* last_ws = nullptr;         // workspace (this handle or its twin) and length of the last internal pass
+    int last_nb = 0;
     hipStream_t twin_stream = nullptr;
     hipEvent_t ev_tfork = nullptr, ev_tjoin = nullptr;
     u64* area_bits;    // [maxb][H][WW]
@@ -163,6 +166,10 @@ void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& ta
 void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s);
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s);
+// n 32-bit words <- value, as a KERNEL on `s`: the per-pass clears of the hot path.  (Not hipMemsetAsync: captured into a HIP
+// graph, the memset nodes of a one-stream multi-pass call left the first pass's status words holding address-like garbage
+// from the second replay on - tools/gpu_graph_debug.py, ROCm 7.2 - while kernel nodes replay exactly.)
+void launch_fill(u32* p, u32 value, size_t n, hipStream_t s);
 int launch_ncc_general(const double* T, int th, int tw, const double* I, int h, int w, int mode, double* out,
                        double* stats, hipStream_t s);
 void launch_displacement64(const double* table, int n, int m_ref, int warmup, double min_size, double max_disp,

@@ -454,7 +454,7 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                                                    const uint4* __restrict__ hfrag, const uint4* __restrict__ vfrag,
                                                    u64* __restrict__ bits, u8* __restrict__ area_u8,
                                                    u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
-                                                   int k3, int k8, int span_i, int nframes, int gx, int gy) {
+                                                   int k3, int k8, int span_i, int nframes, int gx, int gy, int dbg_drop) {
     __shared__ uint4 vf[12 * 64];
     __shared__ __align__(16) u8 stg[B16_NS][16 * B16_ROWB];
     __shared__ u32 staged;                               // tiles the loader has staged so far
@@ -551,6 +551,7 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
 #pragma unroll
         for (int j = 0; j < B16_LD; ++j) issue(j, R[j]);
         int slot = 0, gen = 0;                           // slot = tau % B16_NS, gen = tau / B16_NS
+        bool lost = false;                               // a bounded wait of this wave has expired
         for (int t0 = 0; t0 < nsteps; t0 += B16_LD) {
 #pragma unroll
             for (int j = 0; j < B16_LD; ++j) {
@@ -558,11 +559,14 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                 if (t >= nsteps) break;                  // uniform
                 if (gen > 0) {                           // the slot's last tile read by every strip?  (bounded spin)
                     const u32 want = (u32)(B16_NSW * gen);
-                    for (int spin = 0; spin < (1 << 20); ++spin) {
+                    bool ok = false;
+                    for (int spin = 0; spin < (lost ? 1 : (1 << 20)); ++spin) {
                         const u32 have = __hip_atomic_load(&done[slot], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (__builtin_amdgcn_readfirstlane(have) >= want) break;
+                        if (__builtin_amdgcn_readfirstlane(have) >= want) { ok = true; break; }
                         __builtin_amdgcn_s_sleep(1);
                     }
+                    // expired: the frame is reported, never continued silently (and later waits of this wave give up at once)
+                    if (!ok && !lost) { lost = true; if (lane == 0) atomicMin((int*)&fstat[n * 8 + 2], VBS_EINTERNAL); }
                 }
                 static_assert(B16_LD == 4, "the wait below leaves the B16_LD - 1 younger tiles' loads outstanding");
                 asm volatile("s_waitcnt vmcnt(12)" : "+v"(R[j][0]), "+v"(R[j][1]), "+v"(R[j][2]), "+v"(R[j][3]) :: "memory");
@@ -575,6 +579,11 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                                                                     R[j][k].z ^ 0x80808080u, R[j][k].w ^ 0x80808080u);
                 }
                 // (release: the rows above are in LDS before the tick is)
+#ifdef VBS_DEBUG_KNOBS
+                // tests/: VBS_BLUR16_DROP = tile whose tick the loader of workgroup 0 "forgets" - the strips' wait for it
+                // must expire into the frame's status word
+                if (!(dbg_drop > 0 && t == dbg_drop - 1 && bx == 0 && by == 0))
+#endif
                 if (lane == 0) __hip_atomic_fetch_add(&staged, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 issue(t + B16_LD, R[j]);
                 if (++slot == B16_NS) { slot = 0; ++gen; }
@@ -592,17 +601,20 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
     const u8* const rP = &stg[0][0] + B16_ROWB * q + (L0 - X0) + 16 * g + (g >= 2 ? 64 : 0);
     const u8* const rQ = &stg[0][0] + B16_ROWB * q + (L0 - X0) + 32 + 16 * g;
     // A tile is read once the loader has counted it into `staged` (the strip remembers the last count it saw and asks again
-    // only beyond it: the loader runs tiles ahead), and ticked off a step later, when its operands have been multiplied.  Bounded spins: a logic error shows up as wrong pixels in
-    // the parity tests, not as a hung GPU.
+    // only beyond it: the loader runs tiles ahead), and ticked off a step later, when its operands have been multiplied.  Bounded spins: a logic error cannot hang the GPU;
+    // a wait that expires sets the frame's status word (VBS_EINTERNAL in counts[]).
     int rslot = 0;                                       // ring slot of the NEXT tile to read
     u32 rt = 0, known = 0;                               // its index; tiles known to be staged (asked for again only beyond it)
+    bool lost = false;                                   // a bounded wait of this wave has expired
     auto read_ops = [&](uint4& p, uint4& qq) {
         if (rt >= known) {
-            for (int spin = 0; spin < (1 << 20); ++spin) {
+            for (int spin = 0; spin < (lost ? 1 : (1 << 20)); ++spin) {
                 known = (u32)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(&staged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
                 if (rt < known) break;
                 __builtin_amdgcn_s_sleep(1);
             }
+            // expired: reported in the frame's status word (k_finalize hands it to counts[]), never continued silently
+            if (rt >= known && !lost) { lost = true; if (lane == 0) atomicMin((int*)&fstat[n * 8 + 2], VBS_EINTERNAL); }
         }
         const uint2* a = reinterpret_cast<const uint2*>(rP + rslot * (16 * B16_ROWB));   // (8-byte aligned: two halves each)
         const uint2* b = reinterpret_cast<const uint2*>(rQ + rslot * (16 * B16_ROWB));
@@ -796,10 +808,10 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
         dim3 grid16 = xcd ? dim3((unsigned)((nb + 7) / 8 * 8 * gx16 * nseg)) : dim3(gx16, nseg, nb);
         if (area_u8)
             VBS_LAUNCH(h, s, "k_blur16", k_blur16<true>, grid16, dim3(64 * (B16_NSW + 1)), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
-                       h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg);
+                       h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg, VBS_KNOB("VBS_BLUR16_DROP"));
         else
             VBS_LAUNCH(h, s, "k_blur16", k_blur16<false>, grid16, dim3(64 * (B16_NSW + 1)), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
-                       h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg);
+                       h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg, VBS_KNOB("VBS_BLUR16_DROP"));
         return;
     }
     const int gx = (h->P + 127) / 128, tilesY = (h->H + 31) / 32;

@@ -871,7 +871,7 @@ bool launch_stage(vbs_handle* h, int nb, hipStream_t s);  // false: geometry out
 // flagged frame and exit).  Geometries outside the fused path - and VBS_OPT_STAGE_IMPL = 1 - take the round-2 kernels:
 // k_morph over every frame, k_ccl<0|1>, the general kernel over what those hand on.
 void launch_labelling(vbs_handle* h, int nb, hipStream_t s) {
-    (void)hipMemsetAsync(h->slow_total, 0, (size_t)(nb + 4) * sizeof(u32), s);     // the counter and the flags
+    launch_fill(h->slow_total, 0u, (size_t)nb + 4, s);                             // the counter and the flags
     int all = 0;
     const u32* nslow = nullptr;
     if (h->stage_impl == 0 && launch_stage(h, nb, s)) {

@@ -270,6 +270,33 @@ __device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, d
 }
 
 typedef int i4 __attribute__((ext_vector_type(4)));
+#ifndef NCC_LOADV
+#define NCC_LOADV 2
+#endif
+#ifndef NCC_CONV
+#define NCC_CONV 0
+#endif
+#ifndef NCC_STORE
+#define NCC_STORE 0
+#endif
+#ifndef NCC_EARLYV
+#define NCC_EARLYV 1
+#endif
+#ifndef NCC_APF
+#define NCC_APF 1
+#endif
+#ifndef NCC_LUT
+#define NCC_LUT 1
+#endif
+typedef __attribute__((address_space(1))) u8 gl_u8;                  // global memory, stated (see load_rows)
+typedef __attribute__((address_space(1))) unsigned short gl_u16;
+
+// Decision constants of the reference's two templates (marker_detection.py:120-121,125-126: l = 80, sigma = 13 and
+// l = 33, sigma = 7.4) on 2^20 G, as instruction literals: kc = tbar 2^20, ks2 = thr2 T2 / l^2 2^40, K1 = ks2 l^2.  The
+// kernel checks them against the run-time NccConst and takes the general (border) decision everywhere if they differ.
+template <int L> struct NccLit;
+template <> struct NccLit<80> { static constexpr float kc = 163.84f, ks2 = 547.2815085234848f, K1 = 3502601.654550303f; };
+template <> struct NccLit<33> { static constexpr float kc = 962.8797061524332f, ks2 = 6956.564407359948f, K1 = 7575698.639614983f; };
 
 template <int L, int LO, bool U8OUT>                    // U8OUT: also the uint8 mask of the staged API
 __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
@@ -291,12 +318,15 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     constexpr int RING = 16 * NT;
     constexpr int RSTR = RING + 8;                      // halves per ring column (+16 B: conflict-free 16-byte reads)
     constexpr int CSTR = RING + 16;                     // bytes per count-ring column (conflict-free as well)
-    constexpr int L2 = L * L;
     constexpr int ECAP = 2 * NT + 2;                    // tiles with undecided pixels a wave may queue before it drains them
     // 39.5 KB for l = 80: four workgroups (16 waves) per CU; the time of this kernel goes with 1 / waves per SIMD.
     // (One struct: the table first, so that a ring address minus one ring length is still a valid LDS address.)
     __shared__ struct __align__(16) {
-        uint4 lut[256];
+#if NCC_LUT == 0
+        uint4 lut[256];                                 // byte -> eight float16 0 / 1
+#else
+        uint4 lut[16];                                  // nibble -> four float16 0 / 1 in .x, .y (16-byte spacing, see fetch_ops)
+#endif
         _Float16 ring[4][2][16 * RSTR];
         u8 ringc[4][16 * CSTR];
         u32 elist[4][ECAP][10];                         // yo, -, uw[0..3] of a queued tile
@@ -316,7 +346,11 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
         u32 w[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) w[d] = (((u32)tid >> (2 * d)) & 1u ? 0x3C00u : 0u) | (((u32)tid >> (2 * d + 1)) & 1u ? 0x3C000000u : 0u);
+#if NCC_LUT == 0
         sm.lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);
+#else
+        if (tid < 16) sm.lut[tid] = make_uint4(w[0], w[1], 0u, 0u);
+#endif
     }
     for (int i = lane; i < 2 * 16 * RSTR / 8; i += 64) reinterpret_cast<uint4*>(&sm.ring[wave][0][0])[i] = make_uint4(0, 0, 0, 0);
     for (int i = lane; i < 16 * CSTR / 16; i += 64) reinterpret_cast<uint4*>(&sm.ringc[wave][0])[i] = make_uint4(0, 0, 0, 0);
@@ -347,16 +381,23 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     // produced.  The s_nop are the hazards the compiler pads for v_readfirstlane after a VALU write, and before a read of
     // the scalar: inside an asm they are ours.)
     auto uni = [](float v) { float o; asm("s_nop 4\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 4" : "=s"(o) : "v"(v)); return o; };
-    const float ks = (float)(sqrt(nc.thr2 * nc.T2) / (double)L * (NCC_WSCALE * NCC_WSCALE));
-    const float kc = uni((float)(nc.tbar * (NCC_WSCALE * NCC_WSCALE)));
-    const float k0 = (float)(mu * (full_t - nc.l2 * nc.tbar) / 255.0 * (NCC_WSCALE * NCC_WSCALE));
+    const float kc = uni((float)(nc.tbar * (NCC_WSCALE * NCC_WSCALE)));     // (border tiles; the plain decision uses NccLit)
     const float th0 = (float)ncc_theta(0.0, nc.l2, full_t, mu, nc);
-    const float k0e = uni(fmaxf(k0, 0.01f));
-    const float ks2 = uni(ks * ks);
     // Loop-invariant conditions as integer bounds on the tile row (a uniform bool costs a 64-bit mask in two scalar
     // registers, and this kernel has none to spare): a tile takes the plain decision for plain_lo <= yo <= plain_hi,
     // and lies wholly inside the image for yo <= valid_hi.
-    const bool th0pos = __builtin_amdgcn_readfirstlane(th0 > 0.0f ? 1 : 0) != 0;
+    // The plain decision's constants are the literals of NccLit<L>: they must be this template's (to float32 rounding),
+    // and k0 = mu (sum_t - l^2 tbar) 2^20 / 255, which the plain decision leaves out, must vanish (sum_t = l^2 tbar = 1 up
+    // to rounding for a window inside the image: k0 ~ 1e-9 against a margin of >= 3e-3); th0 > 0: an empty window
+    // (G = 0 and c = 0 exactly, so u = 0 and 0 > 0 fails) is background.
+    bool lit_ok;
+    {
+        const double ksd = sqrt(nc.thr2 * nc.T2) / (double)L * (NCC_WSCALE * NCC_WSCALE);
+        const double k0d = mu * (full_t - nc.l2 * nc.tbar) / 255.0 * (NCC_WSCALE * NCC_WSCALE);
+        lit_ok = fabs(nc.tbar * (NCC_WSCALE * NCC_WSCALE) - (double)NccLit<L>::kc) <= 2e-7 * (double)NccLit<L>::kc &&
+                 fabs(ksd * ksd - (double)NccLit<L>::ks2) <= 2e-7 * (double)NccLit<L>::ks2 && fabs(k0d) < 1e-4;
+    }
+    const bool th0pos = __builtin_amdgcn_readfirstlane((th0 > 0.0f && lit_ok) ? 1 : 0) != 0;
     const bool xin = (xw + LO >= 0) && (xw + 15 + HI <= W - 1);
 #ifdef VBS_DEBUG_KNOBS
     const int plain_lo = dbg == 10 ? -0x40000000 : (th0pos && xin && dbg != 11) ? -LO : 0x7FFFFFFF, plain_hi = dbg == 10 ? 0x40000000 : H - 1 - 15 - HI;
@@ -383,32 +424,73 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     const u8* const cbase = &sm.ringc[wave][q * CSTR];
     constexpr int LOFS = 16 * RSTR;                     // hi plane -> lo plane, in halves
     u32 amb = 0, nexact = 0;
-    const u32 sel1 = 0u - ((u32)lane & 1u), sel2 = 0u - (((u32)lane >> 1) & 1u);
     unsigned short* mb16 = reinterpret_cast<unsigned short*>(mbits) + ((int64_t)n * H * WW + blockIdx.x) * 4 + wave;   // (uniform)
-    // Row bits of a horizontal tile: lane (g, q) takes row q's window [xw + LO, xw + LO + 32 NKS) as dwords.  Strips
-    // whose window lies inside the row load them with one branch-free 16-byte load (issued a step ahead); the
-    // first / last strips of a row go through clamped 64-bit loads.
+    // Row bits of a horizontal tile: lane (g, q) needs, of row q, the BYTE (wstart + 32 s) / 8 + g for every k-step s - its
+    // eight columns of the 32 - and nothing else (wstart is a multiple of 8: xw of 16, LO of 8).  Strips whose window lies
+    // inside the row load exactly those bytes: NKS byte loads at lane offset q * rowbytes + g from a SCALAR base that
+    // moves down the strip (no vector instruction per step for the address, none to align or extract), issued a step
+    // ahead.  The first / last strips of a row go through clamped 64-bit loads.
     const int wstart = xw + LO;                          // wave-uniform
-    const int d0 = wstart >> 5, dsh = wstart & 31;
+    static_assert((LO & 7) == 0, "the window must start on a byte of the row");
+    const int rowbytes = 8 * WW, b0 = wstart >> 3;
     // (uniform conditions as INTEGERS behind an opaque move: as booleans the compiler keeps each of them - and every
     //  bounds test of the clamped loads below, hoisted out of the step loop - as a 64-bit lane mask in two scalar
     //  registers, which this kernel then spills and reloads with v_readlane in every step)
-    int wide_i = __builtin_amdgcn_readfirstlane(((d0 >= 0) && (d0 + 4 <= 2 * WW)) ? 1 : 0);
+    int wide_i = __builtin_amdgcn_readfirstlane(((b0 >= 0) && (NCC_LOADV == 0 ? b0 + 4 * (NKS - 1) + 3 < rowbytes
+                                                                               : (b0 & ~3) + 16 <= rowbytes)) ? 1 : 0);
     asm volatile("" : "+s"(wide_i));
 #define wide (wide_i != 0)
+    // (NCC_LOADV: how a wide strip gets its bytes - 0: NKS byte loads at the lane's own byte offset; 2: one aligned 16-byte
+    //  load + v_perm with a per-lane selector.  Measured)
+    u32 nby[NKS];
+#pragma unroll
+    for (int s = 0; s < NKS; ++s) nby[s] = 0;
     uint4 nraw = make_uint4(0, 0, 0, 0);
-    const u32* fb32 = reinterpret_cast<const u32*>(fbits) + d0;   // (uniform)
+    const u8* fby = reinterpret_cast<const u8*>(fbits) + (NCC_LOADV == 0 ? b0 : (b0 & ~3));   // (uniform; only dereferenced by wide strips)
+    const u32 lofs = (u32)(q * rowbytes + (NCC_LOADV == 0 ? g : 0));
+    // byte (b0 & 3) + g + 4 s of the 16 loaded: byte c = (b0 & 3) + g (< 8) of the dword pair (s + 1 : s), the same c in every
+    // step, so ONE v_perm per k-step with a per-lane selector puts it into byte 0 over zeros
+    const u32 psel = 0x0C0C0C00u | (u32)((b0 & 3) + g);
     auto load_rows = [&](int t) {
-        const int y = Y0 + LO + 16 * t + q;
-        if (wide) {                                      // (32-bit offset from a scalar base: no 64-bit multiply per step)
-            const u32* r32 = fb32 + (u32)__mul24(min(max(y, 0), H - 1), 2 * WW);
-            nraw = make_uint4(r32[0], r32[1], r32[2], r32[3]);
+        const int ytile = Y0 + LO + 16 * t;
+        if (wide) {
+            const gl_u8* pg;
+            if (ytile >= 0 && ytile + 15 < H) {          // uniform: the tile's 16 rows are inside the image
+                const u8* pb = fby + (int64_t)ytile * rowbytes;
+                asm volatile("" : "+s"(pb));             // (a scalar base: else the lane offset is folded into a 64-bit vector multiply-add)
+                // (the opaque move hides that this is global memory: say so; and the lane offset must be widened HERE, in
+                //  the block of the loads, for them to take the scalar-base + 32-bit-offset form: hoisted out of the loop
+                //  as a 64-bit pair it costs a 64-bit vector add per step)
+                u32 lo_ = lofs;
+                asm volatile("" : "+v"(lo_));
+                pg = (const gl_u8*)pb + lo_;
+            } else {
+                pg = (const gl_u8*)fby + (u32)(__mul24(min(max(ytile + q, 0), H - 1), rowbytes) + (NCC_LOADV == 0 ? g : 0));
+            }
+            if (NCC_LOADV == 0) {
+#pragma unroll
+                for (int s = 0; s < NKS; ++s) nby[s] = pg[4 * s];
+            } else {
+                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+                typedef __attribute__((address_space(1))) const u32x4 gl_u4;
+                const u32x4 rr = *(gl_u4*)pg;
+                nraw = make_uint4(rr.x, rr.y, rr.z, rr.w);
+            }
         } else {
-            const u64* row = fbits + (int64_t)min(max(y, 0), H - 1) * WW;
+            const u64* row = fbits + (int64_t)min(max(ytile + q, 0), H - 1) * WW;
             int ws = __builtin_amdgcn_readfirstlane(wstart);
             asm volatile("" : "+s"(ws));                 // (its bounds tests are redone per step on the scalar unit, not kept)
-            u64 w0 = load_bits(row, WW, ws), w1 = load_bits(row, WW, ws + 64);
-            nraw = make_uint4((u32)w0, (u32)(w0 >> 32), (u32)w1, 0u);
+            const u64 w0 = load_bits(row, WW, ws), w1 = NKS > 2 ? load_bits(row, WW, ws + 64) : 0ull;
+            const u32 dw[4] = {(u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32)};
+            if (NCC_LOADV == 0) {
+#pragma unroll
+                for (int s = 0; s < NKS; ++s) nby[s] = (dw[s] >> (8 * g)) & 255u;
+            } else {                                     // (the form the wide strips load: the window's first byte at byte b0 & 3)
+                const u32 sh = 8 * (b0 & 3);
+                nraw = make_uint4(dw[0] << sh, sh ? __builtin_amdgcn_alignbit(dw[1], dw[0], 32 - sh) : dw[1],
+                                  sh ? __builtin_amdgcn_alignbit(dw[2], dw[1], 32 - sh) : dw[2],
+                                  sh ? __builtin_amdgcn_alignbit(dw[3], dw[2], 32 - sh) : dw[3]);
+            }
         }
     };
     // Undecided pixels (a handful per frame) leave the loop: a tile that has any is queued - its row and the four masks
@@ -418,10 +500,42 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     // row sums broadcast from their lanes, template factors read as scalars), and a pixel found foreground is OR-ed
     // into the stored mask word.
     int ecnt = 0;
-    u32 pend_piece = 0, pend_off = 0xFFFFFFFFu;
+    // A finished tile's mask: the decision leaves four 64-bit lane masks pw[r] in scalar registers (bit 16 g + c <-> row
+    // 4 g + r, column c), i.e. eight dwords whose halves are the 16-bit row pieces mask_bits wants.  v_writelane puts dword
+    // k = 2 r + h into lane k of ONE vector register; lane k then stores its low half to row 8 h + r and its high half to
+    // row 8 h + r + 4 (two 2-byte stores of 8 lanes, offsets fixed per lane, base scalar) - no per-lane selection.  The
+    // stores are issued at the top of the NEXT step, behind its loads (see there).
+    constexpr int NO_TILE = 0x7FFFFFFF;
+    u32 pend_x = 0;
+    int pend_yo = NO_TILE;
+    const u32 off_lo = (u32)((8 * (lane & 1) + ((lane >> 1) & 3)) * rowbytes), off_hi = off_lo + (u32)(4 * rowbytes);   // bytes (lanes 0..7)
+#if NCC_STORE != 0
+    u32 pend_off1 = 0xFFFFFFFFu;
+#endif
     auto flush_pending = [&]() {
-        if (pend_off != 0xFFFFFFFFu) mb16[pend_off] = (unsigned short)pend_piece;
-        pend_off = 0xFFFFFFFFu;
+#if NCC_STORE != 0
+        if (pend_off1 != 0xFFFFFFFFu) mb16[pend_off1] = (unsigned short)pend_x;
+        pend_off1 = 0xFFFFFFFFu;
+        return;
+#endif
+        if (pend_yo != NO_TILE) {                        // uniform
+            u8* base = reinterpret_cast<u8*>(mb16) + (int64_t)pend_yo * rowbytes;
+            asm volatile("" : "+s"(base));               // (scalar base + 32-bit lane offset)
+            gl_u8* bg = (gl_u8*)base;
+            u32 ol_ = off_lo, oh_ = off_hi;              // (widened here, as in load_rows)
+            asm volatile("" : "+v"(ol_), "+v"(oh_));
+            if (pend_yo <= H - 16) {                     // uniform: the tile's rows are all inside the image
+                if (lane < 8) {
+                    *(gl_u16*)(bg + ol_) = (unsigned short)pend_x;
+                    *(gl_u16*)(bg + oh_) = (unsigned short)(pend_x >> 16);
+                }
+            } else {
+                const int rl = pend_yo + 8 * (lane & 1) + ((lane >> 1) & 3);
+                if (lane < 8 && rl < H) *(gl_u16*)(bg + ol_) = (unsigned short)pend_x;
+                if (lane < 8 && rl + 4 < H) *(gl_u16*)(bg + oh_) = (unsigned short)(pend_x >> 16);
+            }
+        }
+        pend_yo = NO_TILE;
     };
     auto drain = [&]() {
         __builtin_amdgcn_s_waitcnt(0x0F70);              // the plain stores of these rows are out before the atomics
@@ -479,65 +593,75 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
         }
         ecnt = 0;
     };
+    // The A operands of tile tt (its rows' bits as float16 0 / 1, one 16-byte table entry per k-step) out of the registers
+    // its row load filled; then the load of the tile after it is issued.  The bytes are taken out BEFORE the next load and
+    // the mask stores are issued (the empty asm pins that order): loads and stores share one in-order counter that the
+    // compiler can only wait on as "all done" once both kinds are in flight, so the wait must sit where everything in
+    // flight is a whole step old - behind a new load or store it would expose their full latency in every step.
+    h8 a_op[NKS];
+    auto fetch_ops = [&](int tt) {
+        u32 by[NKS];
+        if (NCC_LOADV == 0) {
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) by[s] = nby[s];
+        } else {
+            const u32 rw[5] = {nraw.x, nraw.y, nraw.z, nraw.w, 0u};
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) by[s] = __builtin_amdgcn_perm(rw[s + 1], rw[s], psel);
+        }
+#pragma unroll
+        for (int s = 0; s < NKS; ++s) asm volatile("" : "+v"(by[s]) :: "memory");
+        load_rows(tt + 1);                               // (unconditional: past the last step it reads rows nobody uses)
+        flush_pending();                                 // the finished tile's mask rows, behind the load
+        const int ytile = Y0 + LO + 16 * tt;
+        if (ytile < 0 || ytile + 15 >= H) {              // uniform: rows outside the image are empty
+            const bool rowin = (ytile + q >= 0) && (ytile + q < H);
+#pragma unroll
+            for (int s = 0; s < NKS; ++s) by[s] = rowin ? by[s] : 0u;
+        }
+#pragma unroll
+#if NCC_LUT == 0
+        for (int s = 0; s < NKS; ++s) a_op[s] = __builtin_bit_cast(h8, sm.lut[by[s]]);
+#else
+        // Two 8-byte reads of a 16-entry table per k-step instead of one 16-byte read of a 256-entry one: any two lanes
+        // read either the same entry (a broadcast) or entries in different banks (16 entries x 2 dwords, 4 banks apart),
+        // so the reads cannot conflict - the byte table's did whenever two lanes' bytes shared the low nibble (44 % of the
+        // kernel's LDS cycles, profiles/r4a_sq_counters.json, with the LDS the busiest unit of the horizontal phase).
+        // Entry n at byte 16 n: the high nibble's address is byte & 0xF0.
+        for (int s = 0; s < NKS; ++s) {
+            const char* lb = reinterpret_cast<const char*>(&sm.lut[0]);
+            const uint2 lo = *reinterpret_cast<const uint2*>(lb + ((by[s] << 4) & 0xF0u));
+            const uint2 hi = *reinterpret_cast<const uint2*>(lb + (by[s] & 0xF0u));
+            a_op[s] = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, hi.x, hi.y));
+        }
+#endif
+    };
     load_rows(0);
+#if NCC_APF
+    fetch_ops(0);
+#endif
     for (int t0 = 0; t0 < nsteps; t0 += NT) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {                   // u = ring slot of step t: a constant of this copy of the body
             const int t = t0 + u;
             if (t >= nsteps) break;                      // uniform
-            const uint4 raw = nraw;
-            const int ytile = Y0 + LO + 16 * t;
-            if (t + 1 < nsteps) load_rows(t + 1);
-            // The previous step's mask rows, stored behind this step's load: the wait for the row bits at a step's top
-            // then only ever covers a store that is a whole step old.
-            flush_pending();
-            u32 dw[3];
-            if (wide) {
-                dw[0] = __builtin_amdgcn_alignbit(raw.y, raw.x, dsh);
-                dw[1] = __builtin_amdgcn_alignbit(raw.z, raw.y, dsh);
-                dw[2] = __builtin_amdgcn_alignbit(raw.w, raw.z, dsh);
-            } else {
-                dw[0] = raw.x; dw[1] = raw.y; dw[2] = raw.z;
-            }
-            if (ytile < 0 || ytile + 15 >= H) {          // uniform: rows outside the image are empty
-                const bool rowin = (ytile + q >= 0) && (ytile + q < H);
-                dw[0] = rowin ? dw[0] : 0u; dw[1] = rowin ? dw[1] : 0u; dw[2] = rowin ? dw[2] : 0u;
-            }
-            // ---- horizontal tile t ----
-            f4 ah = {0, 0, 0, 0}, ac = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
-                const u32 byte = (dw[s] >> (8 * g)) & 255u;
-                const h8 a = __builtin_bit_cast(h8, sm.lut[byte]);
-                ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, whi[s], ah, 0, 0, 0);
-                ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, wlo[s], ah, 0, 0, 0);
-                ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, one[s], ac, 0, 0, 0);
-            }
-            {
-                // hi = the float32 cut to float16's 10 mantissa bits (exact in float16: 0.25 <= h <= 1024), lo = the
-                // rest; the count (an integer <= l) goes to the ring as a byte
-                h4 vh, vl;
-                u32 vc = 0;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float hi_f = __uint_as_float(__float_as_uint(ah[r]) & 0xFFFFE000u);
-                    vh[r] = (_Float16)hi_f;
-                    vl[r] = (_Float16)(ah[r] - hi_f);
-                    vc = __builtin_amdgcn_cvt_pk_u8_f32(ac[r], r, vc);
-                }
-                *reinterpret_cast<h4*>(wr + 16 * u) = vh;
-                *reinterpret_cast<h4*>(wr + LOFS + 16 * u) = vl;
-                *reinterpret_cast<u32*>(cw + 16 * u) = vc;
-            }
-            if (t < NT - 1 || dbg == 3) continue;        // (dbg: tools/ phase timing, always 0 in the product library)
-            // ---- vertical: output tile rows yo .. yo + 15 from ring tiles t-NT+1 .. t (slots B, B + 1, ...) ----
-            const int yo = Y0 + 16 * (t - (NT - 1));
+#if !NCC_APF
+            fetch_ops(t);
+#endif
+            // ---- horizontal tile t, and next to it the part of the vertical product that does not need it ----
+            // The output tile of this step sums ring tiles t - NT + 1 .. t, oldest first (slots B, B + 1, ...).  All but the
+            // last k-step's rows are in the ring since the previous steps: their operands are read and multiplied HERE, as a
+            // second chain of matrix instructions beside the horizontal one, instead of behind tile t's conversion and
+            // ring store - the wave is bound by the latency of its own chain (LDS -> products -> convert -> LDS -> products ->
+            // decision at four waves per SIMD), not by issue slots, so two independent chains side by side shorten the
+            // step.  Same products in the same order: G is bit for bit what the one-chain form gave.
             constexpr int dummy_nt = NT;                 // (u + 1) % NT below is a constant after unrolling
             const int B = (u + 1) % dummy_nt;
+            constexpr int NKE = NCC_EARLYV ? (RING - 16) / 32 : 0;          // float16 k-steps clear of the newest 16 rows
+            constexpr int NK8E = NCC_EARLYV ? (RING - 16) / 64 : 0;         // int8 k-steps (64 rows) clear of them
             f4 G = {0, 0, 0, 0};
             i4 C = {0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) {
+            auto vert_f16 = [&](int s) {
                 const int r0 = (16 * B + 32 * s) % RING;  // first ring row of the k-step
                 const _Float16* p = (r0 + 32 <= RING ? rd : rdw) + r0;
                 const h8 bh = *reinterpret_cast<const h8*>(p);
@@ -545,15 +669,83 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bh, G, 0, 0, 0);
                 G = __builtin_amdgcn_mfma_f32_16x16x32_f16(whi[s], bl, G, 0, 0, 0);
                 G = __builtin_amdgcn_mfma_f32_16x16x32_f16(wlo[s], bh, G, 0, 0, 0);
-            }
-#pragma unroll
-            for (int s = 0; s < NK8; ++s) {
+            };
+            auto vert_i8 = [&](int s) {
                 // 16 rows per lane group; groups past the ring carry zero weights and may read any valid 16 bytes
                 const int gi = min(4 * s + g, NT - 1);
                 const int slot = B + gi - (gi >= NT - B ? NT : 0);
                 const i4 bc = *reinterpret_cast<const i4*>(cbase + 16 * slot);
                 C = __builtin_amdgcn_mfma_i32_16x16x64_i8(one8[s], bc, C, 0, 0, 0);
+            };
+            const bool vert = !(t < NT - 1 || dbg == 3);     // (uniform; dbg: tools/ phase timing, always 0 in the product library)
+            f4 ah = {0, 0, 0, 0}, ac = {0, 0, 0, 0};
+            if (vert) {
+#pragma unroll
+                for (int s = 0; s < NKS; ++s) {
+                    ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_op[s], whi[s], ah, 0, 0, 0);
+                    if (s < NKE) vert_f16(s);
+                    ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_op[s], wlo[s], ah, 0, 0, 0);
+                    if (s < NK8E) vert_i8(s);
+                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_op[s], one[s], ac, 0, 0, 0);
+                }
+#pragma unroll
+                for (int s = NKS; s < NKE; ++s) vert_f16(s);
+            } else {
+#pragma unroll
+                for (int s = 0; s < NKS; ++s) {
+                    ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_op[s], whi[s], ah, 0, 0, 0);
+                    ah = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_op[s], wlo[s], ah, 0, 0, 0);
+                    ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_op[s], one[s], ac, 0, 0, 0);
+                }
             }
+#if NCC_APF
+            // The next tile's operands, into the registers this tile's just left: the wait for its rows (loaded a step
+            // ago), the table lookups and their LDS round trip run under this step's conversion, vertical products and
+            // decision instead of at the top of the next step, in front of its first matrix instruction.
+            fetch_ops(t + 1);
+#endif
+            {
+                // hi = the float32 cut to float16's 10 mantissa bits (round toward zero; exact in float16: 0.25 <= h <= 1024),
+                // lo = the rest (h - hi is exact in float32), rounded to float16 by the mixed-precision fma that takes hi
+                // as the float16 it is; the count (an integer <= l) goes to the ring as a byte
+                typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
+                typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
+#if NCC_CONV == 0
+                const hf2 h01 = __builtin_bit_cast(hf2, (hp2)__builtin_amdgcn_cvt_pkrtz(ah[0], ah[1]));
+                const hf2 h23 = __builtin_bit_cast(hf2, (hp2)__builtin_amdgcn_cvt_pkrtz(ah[2], ah[3]));
+                const h4 vh = {h01[0], h01[1], h23[0], h23[1]};
+                // (v_fma_mix* as inline assembly: the compiler only selects them with float32 denormals flushed.  Each reads
+                //  the cvt_pkrtz result of its own accumulator pair, so it is ordered behind a compiler-made instruction
+                //  that already waited out the matrix instruction's write of all four registers.)
+                hf2 l01, l23;
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(ah[0]));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(ah[1]));
+                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(ah[2]));
+                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(ah[3]));
+                const h4 vl = {l01[0], l01[1], l23[0], l23[1]};
+#else
+                h4 vh, vl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hi_f = __uint_as_float(__float_as_uint(ah[r]) & 0xFFFFE000u);
+                    vh[r] = (_Float16)hi_f;
+                    vl[r] = (_Float16)(ah[r] - hi_f);
+                }
+#endif
+                u32 vc = 0;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_cvt_pk_u8_f32(ac[r], r, vc);
+                *reinterpret_cast<h4*>(wr + 16 * u) = vh;
+                *reinterpret_cast<h4*>(wr + LOFS + 16 * u) = vl;
+                *reinterpret_cast<u32*>(cw + 16 * u) = vc;
+            }
+            if (!vert) continue;
+            // ---- vertical, the rest: the k-steps that take in tile t.  Output rows yo .. yo + 15 ----
+            const int yo = Y0 + 16 * (t - (NT - 1));
+#pragma unroll
+            for (int s = NKE; s < NKS; ++s) vert_f16(s);
+#pragma unroll
+            for (int s = NK8E; s < NK8; ++s) vert_i8(s);
 #ifdef VBS_DEBUG_KNOBS
             if (dbg == 8 && mask_u8) {                   // tools/gpu_mask_diff.py: the window counts instead of the mask
 #pragma unroll
@@ -567,36 +759,35 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
             if (dbg == 2) { asm volatile("" :: "v"(G[0]), "v"(G[1]), "v"(G[2]), "v"(G[3]), "v"(C[0]), "v"(C[1]), "v"(C[2]), "v"(C[3])); continue; }
             // ---- decision: lane (g, q) holds rows yo + 4g + r (r = 0..3) of column xw + q ----
             const int x = xw + q;
-            const f2 Gp[2] = {{G[0], G[1]}, {G[2], G[3]}};
-            const f2 Cp[2] = {{(float)C[0], (float)C[1]}, {(float)C[2], (float)C[3]}};
+            float cf[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cf[r] = (float)C[r];
             // pw[r] / uw[r]: 64-bit masks (wave-uniform, kept in scalar registers) of the pixels decided foreground / left
             // undecided by the filter, bit = lane
             u64 pw[4] = {0, 0, 0, 0}, uw[4] = {0, 0, 0, 0};
             if (yo >= plain_lo && yo <= plain_hi) {      // wave-uniform: windows inside the image, empty window = background
-                // G > theta(c)  <=>  u = G - (kc c + k0) > 0 and u^2 > ks^2 c (l^2 - c), taken with G (1 -+ rel): no square
-                // root, and a tile whose every u is negative (the template correlates negatively: about half of them) is
-                // background after three packed operations per pixel pair.  k0e >= 0.01 keeps an empty window (G = 0
-                // exactly) at u < 0; against kc c ~ 1e5 for c >= 1 it is far inside the margin.
-                const f2 rel2 = {rel_arg, rel_arg}, nkc2 = {-kc, -kc}, k02 = {k0e, k0e};   // rel_arg >= NCC_REL (VBS_OPT_NCC_MARGIN)
-                f2 uu[2], uhi[2];
+                // G > theta(c)  <=>  u = G - kc c > 0 and u^2 > a = ks^2 c (l^2 - c), taken with G (1 -+ rel): no square root,
+                // and a tile whose every u is negative (the template correlates negatively there) is background after two
+                // operations per pixel.  kc, ks^2 and K1 = ks^2 l^2 are instruction literals (NccLit); a = c (K1 - ks^2 c)
+                // costs two operations: its absolute error, 0.4 c for l = 80 (half an ulp of K1 and of the fma), moves the
+                // threshold on u by 0.2 sqrt(c / (ks^2 (l^2 - c))) < 8e-4 c = the 4.7e-6 G that rel leaves beyond G's own
+                // 2^-16 - for every c (l^2 - c) >= 123, i.e. every window that is neither empty nor full; those two have
+                // a = 0 and u = 0 -+ rel G and stay undecided or background as before.
+                const float rel = rel_arg;               // >= NCC_REL (VBS_OPT_NCC_MARGIN)
+                float uu[4], uhi[4];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {            // (one scalar operand per packed instruction)
-                    uu[i] = __builtin_elementwise_fma(Cp[i], nkc2, Gp[i] - k02);
-                    uhi[i] = __builtin_elementwise_fma(Gp[i], rel2, uu[i]);
+                for (int r = 0; r < 4; ++r) {
+                    uu[r] = __builtin_fmaf(cf[r], -NccLit<L>::kc, G[r]);
+                    uhi[r] = __builtin_fmaf(G[r], rel, uu[r]);
                 }
-                const float umax = fmaxf(fmaxf(uhi[0].x, uhi[0].y), fmaxf(uhi[1].x, uhi[1].y));
+                const float umax = fmaxf(fmaxf(uhi[0], uhi[1]), fmaxf(uhi[2], uhi[3]));
                 if (__ballot(umax >= 0.0f) || dbg == 12) {
-                    // (the roundings of a and of the two squares, 2.4e-7 relative, sit inside NCC_REL - 2^-16 = 4.7e-6)
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const f2 ulo = __builtin_elementwise_fma(Gp[i], -rel2, uu[i]);
-                        const f2 a = (Cp[i] * ((float)L2 - Cp[i])) * ks2;     // c (l^2 - c) is an exact integer < 2^24
-#pragma unroll
-                        for (int j = 0; j < 2; ++j) {
-                            const int r = 2 * i + j;
-                            pw[r] = __ballot(ulo[j] * fabsf(ulo[j]) > a[j]);          // ulo > 0 and ulo^2 > ks^2 p: foreground
-                            uw[r] = ~(pw[r] | __ballot(uhi[i][j] * fabsf(uhi[i][j]) <= a[j]));   // uhi < 0 or uhi^2 <= ks^2 p: background
-                        }
+                    for (int r = 0; r < 4; ++r) {
+                        const float ulo = __builtin_fmaf(G[r], -rel, uu[r]);
+                        const float a = __builtin_fmaf(cf[r], -NccLit<L>::ks2, NccLit<L>::K1) * cf[r];
+                        pw[r] = __ballot(ulo * fabsf(ulo) > a);                       // ulo > 0 and ulo^2 > a: foreground
+                        uw[r] = ~(pw[r] | __ballot(uhi[r] * fabsf(uhi[r]) <= a));     // uhi < 0 or uhi^2 <= a: background
                     }
                 }
             } else {
@@ -624,22 +815,22 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float cf = Cp[r >> 1][r & 1], kcc = kc * cf;
+                    const float kcc = kc * cf[r];
                     const float mrg = __builtin_fmaf(1e-3f, G[r] + kcc, __builtin_fmaf(1e-5f * mukf, stv[r], 2.0f));
                     uhi[r] = (G[r] - kcc) - mukf * dd0[r] + mrg;
                 }
                 if (__ballot(fmaxf(fmaxf(uhi[0], uhi[1]), fmaxf(uhi[2], uhi[3])) >= 0.0f)) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const float cf = Cp[r >> 1][r & 1];
+                        const float cfr = cf[r];
                         const float nn = nnv[r], a0 = 1.0f - nn * il2f;
-                        const float rest = -(ktf * cf) - muf * dd0[r];
-                        const float var = 65025.0f * cf * (1.0f - cf * il2f) + a0 * muf * (nn * muf - 510.0f * cf);
+                        const float rest = -(ktf * cfr) - muf * dd0[r];
+                        const float var = 65025.0f * cfr * (1.0f - cfr * il2f) + a0 * muf * (nn * muf - 510.0f * cfr);
                         const float t1 = (__builtin_amdgcn_sqrtf(fmaxf(krf * var, 0.0f)) - rest) * (float)(NCC_WSCALE * NCC_WSCALE / 255.0);
                         // empty window: G = 0, num = rest = -mu d0 and rhs = thr2 T2 a nn mu^2: background unless d0 < 0 and
                         // d0^2 > thr2 T2 a nn (mu cancels); decided here with a factor 2 to spare, else left to the exact path
                         const float t0v = ((dd0[r] > -1e-4f) | (dd0[r] * dd0[r] < 0.5f * krf * a0 * nn)) ? (float)NCC_NEVER : 0.0f;
-                        const float th = cf == 0.0f ? t0v : t1;
+                        const float th = cfr == 0.0f ? t0v : t1;
                         const float m = __builtin_fmaf(fabsf(th), 1e-3f, 2.0f), d = G[r] - th;
                         pw[r] = __ballot(d > m);
                         uw[r] = ~(pw[r] | __ballot(d < -m));
@@ -682,20 +873,30 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 }
             }
             if (dbg == 1) { asm volatile("" :: "s"(pw[0]), "s"(pw[1]), "s"(pw[2]), "s"(pw[3])); continue; }
+#if NCC_STORE == 0
             {
-                // lane j < 16 stores row yo + j: quarter j >> 2 of pw[j & 3].  Written as masked arithmetic on the two
-                // halves (a chain of ?: on the scalar masks compiles to nested branches), with a 32-bit offset from a
-                // scalar base.  (Combining the four strips' quarters of a word through LDS into 8-byte stores was measured:
-                // the barrier it needs per step costs more than the 2-byte stores.)
+                u32 xv = 0;                              // (lanes 8.. are never stored)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {            // (no builtin for v_writelane in this compiler; pure register work)
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(xv) : "s"((u32)pw[r]), "n"(2 * r));
+                    asm("v_writelane_b32 %0, %1, %2" : "+v"(xv) : "s"((u32)(pw[r] >> 32)), "n"(2 * r + 1));
+                }
+                pend_x = xv;
+                pend_yo = yo;
+            }
+#else
+            {
+                const u32 sel1 = 0u - ((u32)lane & 1u), sel2 = 0u - (((u32)lane >> 1) & 1u);
                 const u32 x01l = (u32)pw[0] ^ (u32)pw[1], x01h = (u32)(pw[0] >> 32) ^ (u32)(pw[1] >> 32);
                 const u32 x23l = (u32)pw[2] ^ (u32)pw[3], x23h = (u32)(pw[2] >> 32) ^ (u32)(pw[3] >> 32);
                 const u32 t0l = (x01l & sel1) ^ (u32)pw[0], t0h = (x01h & sel1) ^ (u32)(pw[0] >> 32);
                 const u32 t1l = (x23l & sel1) ^ (u32)pw[2], t1h = (x23h & sel1) ^ (u32)(pw[2] >> 32);
                 const u32 vl = ((t0l ^ t1l) & sel2) ^ t0l, vh = ((t0h ^ t1h) & sel2) ^ t0h;
                 const int y = yo + lane;
-                pend_piece = (lane & 8 ? vh : vl) >> (16 * ((lane >> 2) & 1));
-                pend_off = (lane < 16 && y < H) ? (u32)__mul24(y, 4 * WW) : 0xFFFFFFFFu;
+                pend_x = (lane & 8 ? vh : vl) >> (16 * ((lane >> 2) & 1));
+                pend_off1 = (lane < 16 && y < H) ? (u32)__mul24(y, 4 * WW) : 0xFFFFFFFFu;
             }
+#endif
         }
         if (t0 + NT >= nsteps || ecnt > ECAP - NT) {     // uniform
             flush_pending();

@@ -6,6 +6,8 @@
 //   k_displacement 3d_reconstruction.py:240-316 (_track_markers)
 //   k_plane_fit    ForceDistribution.py:138-162 (fit_plane_least_squares)
 //   k_deviation_plane  ForceDistribution.py:168-208 (deviation field), :218-243 (end points + plane), :262-268, :274
+#include <algorithm>
+
 #include "common.h"
 
 struct CamD {
@@ -351,10 +353,19 @@ void launch_solve3d(vbs_handle* h, float* table, int n, int m_ref, const vbs_cam
                        make_cam(cam), min_size);
 }
 
+__global__ __launch_bounds__(256) void k_fill_u32(u32* __restrict__ p, u32 value, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) p[i] = value;
+}
+
+void launch_fill(u32* p, u32 value, size_t n, hipStream_t s) {
+    if (!n) return;
+    hipLaunchKernelGGL(k_fill_u32, dim3((unsigned)std::min<size_t>((n + 255) / 256, 1024)), dim3(256), 0, s, p, value, n);
+}
+
 void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, int warmup, double min_size,
                          double max_disp, int f0, int f1, float* disp, hipStream_t s) {
     int* fmin = reinterpret_cast<int*>(h->fstat + (size_t)h->maxb * 8);      // one spare word behind the counters
-    (void)hipMemsetAsync(fmin, 0x7f, sizeof(int), s);                         // 0x7f7f7f7f: "no frame"
+    launch_fill(reinterpret_cast<u32*>(fmin), 0x7f7f7f7fu, 1, s);             // "no frame"
     VBS_LAUNCH(h, s, "k_disp_first", k_disp_first<float>, dim3(n), dim3(256), 0, s, table, n, m_ref, min_size, fmin);
     dim3 grid((f1 - f0 + 31) / 32, (m_ref + 255) / 256);
     VBS_LAUNCH(h, s, "k_displacement", k_displacement<float>, grid, dim3(256), 0, s, table, n, m_ref, warmup, min_size,
@@ -363,7 +374,7 @@ void launch_displacement(vbs_handle* h, const float* table, int n, int m_ref, in
 
 void launch_displacement64(const double* table, int n, int m_ref, int warmup, double min_size, double max_disp,
                            double* disp, int* fmin_scratch, hipStream_t s) {
-    (void)hipMemsetAsync(fmin_scratch, 0x7f, sizeof(int), s);
+    launch_fill(reinterpret_cast<u32*>(fmin_scratch), 0x7f7f7f7fu, 1, s);
     hipLaunchKernelGGL(k_disp_first<double>, dim3(n), dim3(256), 0, s, table, n, m_ref, min_size, fmin_scratch);
     dim3 grid((n + 31) / 32, (m_ref + 255) / 256);
     hipLaunchKernelGGL(k_displacement<double>, grid, dim3(256), 0, s, table, n, m_ref, warmup, min_size, max_disp, 0, n,

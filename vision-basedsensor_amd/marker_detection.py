@@ -278,7 +278,8 @@ class MarkerTracker:
         n = int(counts[0].item())
         if n < 0:
             from ._lib import VbsError
-            raise VbsError(f"_marker_center: device status {n} (capacity exceeded)")
+            from ._lib import status_text
+            raise VbsError(f"_marker_center: device status {n}: {status_text(n, eng.max_markers)}")
         holes = int(eng.frame_stats(1)[0, 4])
         if holes:
             import warnings
@@ -317,6 +318,16 @@ class MarkerTracker:
                              "major_axis": cur["major_axis"], "minor_axis": cur["minor_axis"],
                              "angle": cur["angle"]})
         return rows
+
+    # ---- overlays (`:252-273`, `:398-427`) -------------------------------------------------------------
+    # Drawing into the annotated AVI is out of scope (a15 "_draw_tracking is OUT", a16 "AVI writer OUT");
+    # the names exist so that a caller written against the reference gets a no-op instead of an AttributeError.
+    @staticmethod
+    def _draw_marker(frame, center, ellipse, major, minor, angle):
+        return None
+
+    def _draw_tracking(self, frame, ref, curr):
+        return None
 
     # ---- main loop (`:429-462`) ---------------------------------------------------------------------
     def process(self):
@@ -387,9 +398,9 @@ class MarkerTracker:
         if (counts < 0).any():                  # the reference would have emitted rows: never drop a frame silently
             from ._lib import VbsError
             bad = int(np.nonzero(counts < 0)[0][0])
-            raise VbsError(f"device status {int(counts[bad])} in frame {self.frame_count + bad}: the frame exceeds the "
-                           f"device workspace (more than 30720 runs in a mask, more than {eng.max_markers} band "
-                           f"components, or more than about 512 contours); rows of the batches before it are kept "
+            from ._lib import status_text
+            raise VbsError(f"device status {int(counts[bad])} in frame {self.frame_count + bad}: "
+                           f"{status_text(int(counts[bad]), eng.max_markers)}; rows of the batches before it are kept "
                            f"(`.rows` of this exception / the partial CSV)")
         table = table.cpu().numpy()
         det = det.cpu().numpy()                 # float64 rows: the CSV keeps the reference's precision
