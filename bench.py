@@ -37,7 +37,10 @@ Extra objects on the JSON line:
                 `cores` = the workers that ran; `oversubscribed` = a worker ran below half the single-process rate.
   (A utilisation sampler with a period of seconds can show the GPU idle throughout: the timed region is ~0.3 s of a run
    that spends two minutes rendering frames, in the CPU baseline and in the host-path leg.)
-  config        also: bgr_fps (the same workload fed as 3-channel BGR frames, the reference's input format),
+  config        N > 1 self-validation: device_uuids (all-gathered, one per rank) / distinct_devices, rccl_version,
+                gathered_table_checksum (every rank's gathered table reduced to two integers, all-gathered and ASSERTED
+                equal on every rank), pipelined_gather; frame0_ids = the device ID assignment and its host checker.
+                also: bgr_fps (the same workload fed as 3-channel BGR frames, the reference's input format),
                 host_path_fps (NumPy frames in host memory -> CSV on disk through MarkerTracker), the NCC decision
                 counters of the timed batch, world size / backend as torch.distributed reports them.
 """
@@ -234,28 +237,38 @@ def cpu_baseline(spec, seed, cam, single_frames, max_workers, per_worker, warm=2
 
 def host_path_fps(spec, n, seed, batch):
     """The drop-in's own rate from frames in HOST memory to the CSV on disk (upload over PCIe, fused kernels, row
-    building, pandas CSV writer): `MarkerTracker.process_frames` + `_save_results`."""
+    building, CSV writer): `MarkerTracker.process_frames` + `_save_results`.  Twice: frames in page-locked memory
+    (`marker_detection.pinned_frames`, what a decoder that feeds this path should fill: batch k + 1 is uploaded by DMA
+    under batch k's kernels and row building) = `fps`, and the same frames in ordinary pageable memory = `pageable`."""
     import tempfile
     import vbs_amd.synth as S
-    from vbs_amd.marker_detection import MarkerTracker
+    from vbs_amd.marker_detection import MarkerTracker, pinned_frames
     import contextlib
-    frames = S.make_frames(spec, range(n), seed=seed)
+    frames = S.make_frames_torch(spec, range(n), seed=seed, device="cuda", chunk=64).cpu().numpy()    # (same bytes as make_frames)
+    pinned = pinned_frames(frames.shape)
+    pinned[:] = frames
     # (the drop-in prints progress lines like the reference does: keep stdout for the ONE JSON line)
     with tempfile.TemporaryDirectory() as td_, contextlib.redirect_stdout(sys.stderr):
         clip = os.path.join(td_, "clip.npy")
         open(clip, "wb").close()                           # `video_path` must exist; frames are passed in memory
-        out = {}
-        for rep in range(2):                               # first repetition warms the engine / allocator
-            trk = MarkerTracker({"video_path": clip, "output_dir": os.path.join(td_, f"o{rep}"),
-                                 "crop_ratios": (0, 0, 0, 0), "id_mode": "full", "batch": batch})
-            t0 = time.perf_counter()
-            rows = trk.process_frames(frames)
-            t1 = time.perf_counter()
-            trk._save_results(rows)
-            t2 = time.perf_counter()
-            out = {"frames": n, "fps": round(n / (t2 - t0), 1), "fps_without_csv_write": round(n / (t1 - t0), 1),
-                   "csv_rows": len(rows), "batch": batch}
-    return out
+        out, texts = {}, {}
+        for name, src, reps in (("pageable", frames, 2), ("pinned", pinned, 3)):
+            for rep in range(reps):                        # first repetition warms the engine / allocator
+                trk = MarkerTracker({"video_path": clip, "output_dir": os.path.join(td_, f"o{name}{rep}"),
+                                     "crop_ratios": (0, 0, 0, 0), "id_mode": "full", "batch": batch})
+                t0 = time.perf_counter()
+                rows = trk.process_frames(src)
+                t1 = time.perf_counter()
+                trk._save_results(rows)
+                t2 = time.perf_counter()
+                out[name] = {"fps": round(n / (t2 - t0), 1), "fps_without_csv_write": round(n / (t1 - t0), 1)}
+                texts[name] = open(trk.output_csv, "rb").read()
+        assert texts["pinned"] == texts["pageable"], "the CSV must not depend on where the frames lie"
+    return {"frames": n, "fps": out["pinned"]["fps"], "fps_without_csv_write": out["pinned"]["fps_without_csv_write"],
+            "frames_memory": "page-locked (marker_detection.pinned_frames); upload of batch k+1 overlaps batch k",
+            "pageable": out["pageable"], "csv_rows": len(rows), "csv_bytes": len(texts["pinned"]),
+            "csv_identical_pinned_vs_pageable": True, "batch": batch,
+            "pcie_bound_fps": "about 42 000 gray 1280x1024 frames/s at ~55 GB/s"}
 
 
 def main():
@@ -274,14 +287,19 @@ def main():
     ap.add_argument("--cpu-workers", type=int, default=0,
                     help="0 (default) = one worker per physical core in the affinity mask (BASELINE.md 3); > 0 caps the workers")
     ap.add_argument("--cpu-frames-per-worker", type=int, default=3)
-    ap.add_argument("--host-frames", type=int, default=512)
+    ap.add_argument("--host-frames", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c5"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c1"],
                     help="c3 = BASELINE config 3/4 (1280x1024, 13x13; the headline metric); c5 = config 5 (1920x1200, 21x21, "
-                         "adds the plane-fit pose per frame; the JSON line then names that workload)")
+                         "adds the plane-fit pose per frame; the JSON line then names that workload); c1 = the reference's REAL "
+                         "configuration: 640x480 BGR frames (collecting.py:29-31) through its default crop (1/8, 1/8, 1/16, 0) "
+                         "(marker_detection.py:481) = 480 wide x 450 high, small branch, 7x7 dots; --frames defaults to 16384")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3],
                     help="1 = gray frames (headline); 3 = the whole benchmark on BGR frames (the line then says so)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) | gloo (rehearsal of N>1 on one GPU)")
+    ap.add_argument("--pipelined", type=int, default=1, choices=[0, 1],
+                    help="N > 1: 1 = one all-gather per internal pass pair, overlapping the next passes (dist.TableGather); "
+                         "0 = every pass first, then the SINGLE all-gather of SURVEY 8(e) (dist.gather_tables)")
     args = ap.parse_args()
 
     # the parallel-CPU probe of the cpu_baseline leg forks: it runs before anything touches the GPU
@@ -318,12 +336,21 @@ def main():
         else:
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    spec = S.config2() if args.workload == "c3" else S.config5()
+    spec = {"c3": S.config2, "c5": S.config5, "c1": S.config1}[args.workload]()
+    crop = None
+    if args.workload == "c1":
+        from vbs_amd.marker_detection import _crop_box
+        crop = _crop_box(spec.width, spec.height, (1 / 8, 1 / 8, 1 / 16, 0))         # left, right, top, bottom
+        args.channels = 3
+        if args.frames == 4096:
+            args.frames = 16384
     H, W, M = spec.height, spec.width, spec.n_markers
+    if crop:
+        H, W = crop[3] - crop[2], crop[1] - crop[0]
     n_local, n_total = args.frames, args.frames * world
     K, dist, R, T = S.default_camera(spec)
     cam = L.make_camera(K, dist, R, T, 2.0)
-    eng = Engine(H, W, max_markers=512 if args.workload == "c3" else 1024, max_batch=args.batch, device=local_rank)
+    eng = Engine(H, W, max_markers={"c3": 512, "c5": 1024, "c1": 256}[args.workload], max_batch=args.batch, device=local_rank)
     eng.set_option(L.OPT_PASS_STREAMS, args.pass_streams)
 
     # synthetic frames of this rank's contiguous block, rendered on the device (same bytes as NumPy)
@@ -333,19 +360,48 @@ def main():
     def as_bgr(g):
         return g.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
 
-    frames = gray if args.channels == 1 else as_bgr(gray)
-    if args.channels == 3:
+    if crop:
+        # rendered as BGR in slices (the full-size gray copy and its BGR copy would not both be needed at once); what the
+        # engine sees is the reference's cropped view: a pointer offset and the full frames' strides, no copy
+        full = torch.empty((gray.shape[0], spec.height, spec.width, 3), dtype=torch.uint8, device=dev)
+        for s0 in range(0, gray.shape[0], 1024):
+            full[s0:s0 + 1024] = gray[s0:s0 + 1024].unsqueeze(-1)
         del gray
+        frames = full[:, crop[2]:crop[3], crop[0]:crop[1], :]
+    else:
+        frames = gray if args.channels == 1 else as_bgr(gray)
+        if args.channels == 3:
+            del gray
     ids = xy = None
+    id_check = None
     if rank == 0:
-        ids, xy = reference_from_frame0(eng, frames[:1], 5, "full", "optimal")
+        # frame-0 identities on the device (vbs_assign_ids) with the host assignment as the checker: see pipeline.py
+        import vbs_amd.pipeline as P
+        ids, xy = reference_from_frame0(eng, frames[:1], 5, "full", "optimal", ids_on_device=True)
+        id_check = dict(P.ID_CHECK)
     ids, xy = D.broadcast_reference(ids, xy, dev)
     assert len(ids) == M, f"frame 0 gave {len(ids)} IDs, expected {M}"
+
+    # N > 1: the run validates itself.  Every rank reports the device it computes on (N distinct devices or the line says
+    # so), and after the timed region the gathered table of every rank is reduced to a checksum that all ranks must share.
+    dev_ids, rccl = None, None
+    if world > 1:
+        pr = torch.cuda.get_device_properties(local_rank)
+        mine = str(getattr(pr, "uuid", "")) or f"{getattr(pr, 'pci_bus_id', '?')}:{getattr(pr, 'pci_device_id', '?')}"
+        mine = f"{mine}|{pr.name}|local_rank {local_rank}"
+        got = [None] * world
+        td.all_gather_object(got, mine)
+        dev_ids = got
+        try:
+            rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+        except Exception as e:                                 # (not fatal: the line then says what failed)
+            rccl = f"unavailable: {type(e).__name__}"
 
     from vbs_amd.pipeline import track_and_gather
 
     def step(fr):
-        _, counts, table = track_and_gather(eng, fr, n_total, xy, 20.0, cam, 5.0)     # all-gather per internal pass
+        _, counts, table = track_and_gather(eng, fr, n_total, xy, 20.0, cam, 5.0,     # all-gather per internal pass pair
+                                            pipelined=bool(args.pipelined))
         disp = eng.displacement(table, 0, 5.0, 50.0, frame_range=(a, b))    # this rank's frames of the gathered table
         if args.workload == "c5":
             eng.plane_fit(table[a:b])
@@ -379,6 +435,19 @@ def main():
     solved = int(((table[..., 0].int() & 2) > 0).sum().item())
     assert int(counts.min().item()) >= 0, "a frame reported a device status"
     assert tracked == n_total * M, f"tracked {tracked} of {n_total * M} marker observations"
+    table_sums = None
+    if world > 1:
+        # the same gathered table on every rank: (sum, xor-fold) of its bits, exchanged and compared everywhere
+        bits = table.contiguous().view(torch.int32).to(torch.int64)
+        folded = bits.view(-1, M * 10)
+        x = folded[:, 0].clone()
+        for c in range(1, folded.shape[1]):
+            x ^= folded[:, c] * (c + 1)
+        mine = torch.stack([bits.sum(), x.sum()]).to(dev if args.backend != "gloo" else "cpu")
+        allsums = [torch.zeros_like(mine) for _ in range(world)]
+        td.all_gather(allsums, mine)
+        table_sums = [[int(v) for v in t.tolist()] for t in allsums]
+        assert all(t == table_sums[0] for t in table_sums), f"rank {rank}: the gathered tables differ between ranks: {table_sums}"
 
     result = None
     if rank == 0:
@@ -392,12 +461,20 @@ def main():
             "config": {"workload": (f"BASELINE config 3/4: {args.frames} synthetic 1280x1024 {fmt} frames per GPU "
                                     f"(13x13 dots, seeded jitter+noise)" if args.workload == "c3" else
                                     f"BASELINE config 5: {args.frames} synthetic 1920x1200 {fmt} frames per GPU "
-                                    f"(21x21 dots), plus plane-fit pose") +
+                                    f"(21x21 dots), plus plane-fit pose" if args.workload == "c5" else
+                                    f"the reference's real configuration (BASELINE config 1's frames in bulk): {args.frames} "
+                                    f"synthetic 640x480 {fmt} frames per GPU (7x7 dots) through the default crop "
+                                    f"(1/8, 1/8, 1/16, 0) = {W}x{H} strided views, small branch") +
                                    f", resident in HBM; fused track->3D table + "
                                    f"{'RCCL all-gather + ' if world > 1 else ''}last-seen displacement",
                        "frames_per_gpu": args.frames, "internal_batch": args.batch, "pass_streams": args.pass_streams, "markers": M, "channels": args.channels,
                        "world_size": td.get_world_size() if world > 1 else 1,
                        "backend": td.get_backend() if world > 1 else "none (single process)",
+                       "pipelined_gather": bool(args.pipelined) if world > 1 else None,
+                       "device_uuids": dev_ids, "distinct_devices": len(set(d.split("|")[0] for d in dev_ids)) if dev_ids else 1,
+                       "rccl_version": rccl, "gathered_table_checksum": table_sums[0] if table_sums else None,
+                       "gathered_table_checksum_equal_on_all_ranks": bool(table_sums) if world > 1 else None,
+                       "frame0_ids": id_check,
                        "tracked_observations": tracked, "xyz_solved": solved,
                        "us_per_frame_per_gpu": round(1e6 * elapsed / args.steps / args.frames, 2),
                        "whole_path_hbm_frac": round(fps / world * (H * W * args.channels + M * 40) / 1e9 / HBM_PEAK_GBS, 6),
@@ -407,7 +484,7 @@ def main():
         }
 
     # ---- the same workload on BGR frames (the reference's input format; gray stays the headline) ----------------------
-    if args.channels == 1 and not args.no_extras:
+    if args.channels == 1 and not args.no_extras and not crop:
         nb_ = min(n_local, 2048)
         fb = as_bgr(gray[:nb_])
         n_keep = n_total
@@ -506,7 +583,7 @@ def main():
                     "frac": round(cyc / avail, 4), "waves_per_simd": 3,
                     "source": f"{os.path.basename(sqf[-1])} (rocprofv3 --pmc passes over a {sj['frames_per_launch']}-frame launch, not this run)"}
         # the staged entry on uint8 images (the reference's `_marker_center(mask, area_mask)` interface)
-        if args.channels == 1:
+        if args.channels == 1 and not crop:
             mask, area = eng.find_markers(frames[:nk])
             torch.cuda.synchronize()
             eng.marker_center(mask, area)                       # warm
@@ -544,14 +621,14 @@ def main():
     if world > 1:
         td.barrier()
 
-    if rank == 0 and world == 1 and not args.no_extras:
+    if rank == 0 and world == 1 and not args.no_extras and not crop:
         try:
             del frames
             torch.cuda.empty_cache()
-            result["config"]["host_path_fps"] = host_path_fps(spec, args.host_frames, args.seed, 256)
+            result["config"]["host_path_fps"] = host_path_fps(spec, args.host_frames, args.seed, 128)
         except Exception as e:
             result["config"]["host_path_fps"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not crop:
         try:
             result["cpu_baseline"] = cpu_baseline(spec, args.seed, (K, dist, R, T), args.cpu_single_frames,
                                                   args.cpu_workers, args.cpu_frames_per_worker, probe=cpu_probe)

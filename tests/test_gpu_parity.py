@@ -81,30 +81,42 @@ def test_find_markers_bit_exact(tag, channels, crop):
     eng.close()
 
 
-def _textured(h, w, n, seed):
-    """frames whose difference of Gaussians crosses the inRange bounds all over: smooth random fields + noise"""
+def _textured(h, w, n, seed, fine=None):
+    """frames whose difference of Gaussians crosses the inRange bounds all over: smooth random fields + noise.  `fine`
+    (default: the small branch, h <= 480): many small dark blobs on a bright ground - the small branch's blurs (sigma 4.56 /
+    11.4, thresholds 35..180) see nothing in the broad fields that exercise the large branch; 6-8 % of the pixels land in
+    range and 3 % wrap past 255 (the mod-256 of `:128`)."""
+    fine = (h <= 480) if fine is None else fine
     rng = np.random.default_rng(seed)
     yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
     out = np.zeros((n, h, w), np.float32)
     for f in range(n):
-        for _ in range(30):
-            cx, cy, s = rng.uniform(0, w), rng.uniform(0, h), rng.uniform(6, 60)
-            out[f] += rng.uniform(-120, 160) * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
-        out[f] += 90 + rng.normal(0, 12, (h, w))
+        for _ in range(max(30, (h * w) // 700) if fine else 30):
+            cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+            s = rng.uniform(3, 9) if fine else rng.uniform(6, 60)
+            amp = rng.uniform(-170, 70) if fine else rng.uniform(-120, 160)
+            out[f] += amp * np.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * s * s))
+        out[f] += (150 if fine else 90) + rng.normal(0, 12, (h, w))
     return np.clip(out, 0, 255).astype(np.uint8)
 
 
 @pytest.mark.parametrize("h,w,view", [(600, 800, False), (1000, 1284, False), (520, 132, False), (1024, 1280, True),
-                                      (488, 240, False), (500, 248, False), (700, 1288, False)])
+                                      (488, 240, False), (500, 248, False), (700, 1288, False),
+                                      (450, 480, False), (480, 640, False), (470, 650, False), (450, 480, True),
+                                      (300, 176, False), (400, 244, False), (480, 1284, False), (700, 252, False)])
 def test_blur_strips_equal_the_32_column_kernel_and_the_oracle(h, w, view):
     """a4-a5 through both blur kernels (VBS_OPT_BLUR_IMPL): the 16-column strips (k_blur16: rows straight into the
     operands, border mirror folded into each strip's fragments, windows shifted to stay inside the row) and the 32-column
     kernel give the oracle's area mask bit for bit on frames whose DoG crosses the range bounds everywhere - widths that
-    are no multiple of 16 / 64 (1284, 132: the 32-column kernel either way), the narrowest frame the strips take (240: every
-    workgroup's window is the whole row), 248 and 1288 (a last strip of 8 columns), and a strided view of a larger buffer."""
+    are no multiple of 16 / 64, the narrowest frames the strips take (240 / 176: every workgroup's window is the whole
+    row), 248 and 1288 (a last strip of 8 columns), a strided view of a larger buffer; round 4: the SMALL branch on the
+    strips (height <= 480: 450x480 = the reference's cropped camera frame, 480x640 the uncropped one, a view, 176 and 244
+    columns), and widths that are a multiple of 4 but not of 8 on either branch (1284, 252, 244: the last workgroup's
+    staged rows at a shifted origin); 132 and 650 columns stay with the 32-column kernel (too narrow / rows that do not
+    load as aligned dwords)."""
     n = 2
     if view:
-        big = torch.from_numpy(_textured(h + 8, w + 64, n, 5)).cuda()
+        big = torch.from_numpy(_textured(h + 8, w + 64, n, 5, fine=h <= 480)).cuda()
         ft = big[:, 4:4 + h, 32:32 + w]
     else:
         ft = torch.from_numpy(_textured(h, w, n, h + w)).cuda()
@@ -127,11 +139,12 @@ def test_blur_strips_equal_the_32_column_kernel_and_the_oracle(h, w, view):
     eng.close()
 
 
-def test_blur_strips_many_frames_per_launch_equal_few():
+@pytest.mark.parametrize("h,w", [(600, 800), (450, 480)])
+def test_blur_strips_many_frames_per_launch_equal_few(h, w):
     """k_blur16 maps a launch of 32 or more frames onto a 1-D grid (frame = 8 (b / 8 / per_frame) + b % 8, so that a
     frame's workgroups share an XCD) and pads the frame count to a multiple of 8: 37 frames in one pass give, frame by
-    frame, what passes of 16 (the plain 3-D grid) give."""
-    h, w, n = 600, 800, 37
+    frame, what passes of 16 (the plain 3-D grid) give - large branch and small."""
+    n = 37
     base = _textured(h, w, 5, 77)
     host = np.stack([np.roll(base[i % 5], 13 * i, axis=1) for i in range(n)])
     ft = torch.from_numpy(host).cuda()
@@ -1148,6 +1161,40 @@ def test_gray_plane_is_allocated_at_first_bgr_use_and_not_under_capture():
     m_bgr, a_bgr = eng.find_markers(bgr)                    # allocates the plane (B = G = R: the same masks)
     assert torch.equal(m_bgr, m_gray) and torch.equal(a_bgr, a_gray)
     eng.close()
+
+
+def test_blur16_hand_shake_that_expires_is_reported_in_counts():
+    """k_blur16's loader and strips wait for each other with BOUNDED spins.  A wait that expires must not continue silently:
+    it sets the frame's status word, which k_finalize hands to counts[] (VBS_EINTERNAL), like a capacity overflow.  Shown
+    once with the debug library (-DVBS_DEBUG_KNOBS; the product library has no such knob): VBS_BLUR16_DROP=4 makes the
+    loader of a frame's first workgroup "forget" the tick of its fourth tile, so its strips run one tile behind and their
+    wait for the last tile expires.  Runs in a child process (a second copy of the library, an environment knob)."""
+    import subprocess
+    import sys
+    import vbs_amd._build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbg = B.LIB.replace(".so", "_dbg.so")
+    if not os.path.exists(dbg):
+        B.build(extra_flags=["-DVBS_DEBUG_KNOBS"], suffix="_dbg")
+    code = (
+        "import os, sys, json; sys.path.insert(0, %r)\n"
+        "import torch, vbs_amd.synth as S\n"
+        "from vbs_amd import _lib as L\n"
+        "L.LIB_PATH = %r\n"
+        "from vbs_amd.engine import Engine\n"
+        "spec = S.config2(); ft = S.make_frames_torch(spec, range(3), seed=2, device='cuda')\n"
+        "eng = Engine(spec.height, spec.width, max_markers=512, max_batch=3)\n"
+        "out = {}\n"
+        "for drop in ('0', '4'):\n"
+        "    os.environ['VBS_BLUR16_DROP'] = drop\n"
+        "    _, _, counts = eng.track_to_3d(ft); torch.cuda.synchronize()\n"
+        "    out[drop] = {'counts': counts.tolist(), 'status': eng.frame_stats(3)[:, 2].astype('int32').tolist()}\n"
+        "print(json.dumps(out))\n" % (root, dbg))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["0"] == {"counts": [169, 169, 169], "status": [0, 0, 0]}
+    assert out["4"] == {"counts": [L.VBS_EINTERNAL] * 3, "status": [L.VBS_EINTERNAL] * 3}
 
 
 def test_passes_on_two_streams_equal_one():

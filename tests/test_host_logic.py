@@ -124,6 +124,23 @@ def test_avi_reader_and_writer(tmp_path):
             assert np.array_equal(got[0], ref)
         cap.release()
         assert not cap.isOpened()
+        # the threaded batch decode (`read_batch`: what `MarkerTracker.process` uses to decode ahead of the GPU) gives the
+        # frames `read` gave, into a caller's buffer or its own, in batches that do not divide the clip
+        cap = AviReader(p)
+        buf = np.zeros((2, spec.height, spec.width, 3), np.uint8)
+        seen = []
+        while True:
+            m = cap.read_batch(2, buf, threads=2)
+            if not m:
+                break
+            seen.extend(buf[:m].copy())
+        assert len(seen) == len(got) and all(np.array_equal(a, b) for a, b in zip(seen, got))
+        assert cap.read_batch(2, buf) == 0
+        cap.release()
+        cap = AviReader(p)
+        m, own = cap.read_batch(100, threads=1)
+        assert m == len(got) and np.array_equal(own, np.stack(got))
+        cap.release()
     junk = tmp_path / "junk.avi"
     junk.write_bytes(b"RIFF\x10\x00\x00\x00AVI junkjunk")
     assert not AviReader(str(junk)).isOpened() and not AviReader(str(tmp_path / "missing.avi")).isOpened()
@@ -334,7 +351,7 @@ def test_shard_bounds():
     assert shard_bounds(32768, 8, 3) == (12288, 16384)
 
 
-def _gloo_worker(rank, world, port, n_total, out_dir):
+def _gloo_worker(rank, world, port, n_total, out_dir, chunk=3):
     import torch
     import torch.distributed as td
     sys.path.insert(0, ROOT)
@@ -353,10 +370,10 @@ def _gloo_worker(rank, world, port, n_total, out_dir):
         ids, xy = D.broadcast_reference(ids, xy, torch.device("cpu"))
         gathered = D.gather_tables(full[a:b].clone(), n_total)
         # the pass-by-pass gather (chunk 3: several passes, the last one ragged when the shards differ)
-        g = D.TableGather(n_total, m, 10, torch.device("cpu"), 3)
+        g = D.TableGather(n_total, m, 10, torch.device("cpu"), chunk)
         local = full[a:b].clone()
-        for off in range(0, g.n_max, 3):
-            g.push(off, local[off:off + 3])
+        for off in range(0, g.n_max, chunk):
+            g.push(off, local[off:off + chunk])
         piped = g.finish()
         ok = torch.equal(gathered, full) and torch.equal(piped, full) and ids.shape == (7, 2) and ids[5].tolist() == [2, 2] \
             and abs(xy[6, 1] - (1e3 + 0.123456789)) < 1e-12
@@ -376,3 +393,75 @@ def test_gather_tables_two_ranks_gloo(tmp_path, n_total):
     s.close()
     mp.spawn(_gloo_worker, args=(2, port, n_total, str(tmp_path)), nprocs=2, join=True)
     assert [open(tmp_path / f"rank{r}.txt").read() for r in range(2)] == ["ok", "ok"]
+
+
+def test_table_gather_eight_ranks_ragged_shards_gloo(tmp_path):
+    """The world size the driver's scaling run uses (8 ranks), on CPU over gloo, with ragged shards (21 frames: five ranks
+    of 3 and three of 2) and a pass width (2) that leaves some ranks without rows in the last pass: the single collective
+    (`gather_tables`) and the pass-by-pass one (`TableGather`) both rebuild the table in frame order on every rank."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_gloo_worker, args=(8, port, 21, str(tmp_path), 2), nprocs=8, join=True)
+    assert [open(tmp_path / f"rank{r}.txt").read() for r in range(8)] == ["ok"] * 8
+
+
+def _loader_asm(rotated=True, copy_in_flight=False, moved=False, touch_other=False):
+    """A stand-in for the disassembly of k_blur16's loader: four load groups, a loop of (wait, staging, refill) x 4 - with
+    the last refill in the latch block in front of the header when `rotated` - and four full waits."""
+    sets = [range(12, -1, -4), range(28, 15, -4), range(44, 31, -4), range(60, 47, -4)]
+
+    def L(k, first=None):
+        regs = list(sets[k])
+        if first is not None:
+            regs[0] = first
+        return ["\t;;#ASMSTART"] + [f"\tglobal_load_dwordx4 v[{r}:{r + 3}], v{70 + i}, s[6:7]" for i, r in enumerate(regs)] + \
+               ["\t;;#ASMEND"]
+
+    def W(n):
+        return ["\t;;#ASMSTART", f"\ts_waitcnt vmcnt({n})", "\t;;#ASMEND"]
+
+    def stage(k):
+        out = []
+        for r in sets[k]:
+            out += [f"\tv_xor_b32_e32 v{r}, 0x80808080, v{r}", f"\tds_write_b128 v80, v[{r}:{r + 3}]"]
+        return out
+
+    body = []
+    for k in range(4):
+        body += [f"\tv_add_u32_e32 v{70 + k}, s5, v65"] + L(k)
+    body += ["\ts_mov_b32 s30, 0"] + (["\tv_mov_b32_e32 v90, v60"] if copy_in_flight else []) + ["\ts_branch .LBB0_3"]
+    loop = []
+    for k in range(4):
+        loop.append(W(12) + stage(k) + (["\tv_mov_b32_e32 v91, v4"] if touch_other and k == 2 else []))
+    if rotated:
+        body += [".LBB0_2:"] + L(3, first=100 if moved else None) + [".LBB0_3:"]
+        for k in range(4):
+            body += loop[k] + (L(k) if k < 3 else ["\ts_branch .LBB0_2"])
+    else:
+        body += [".LBB0_3:"]
+        for k in range(4):
+            body += loop[k] + L(k, first=100 if moved and k == 3 else None)
+        body += ["\ts_cbranch_scc0 .LBB0_3"]
+    body += W(0) * 4 + ["\ts_endpgm"]
+    return "\n".join(["_Z8k_blur16ILb0EEvPKh:"] + body + [".Lfunc_end0:"]) + "\n"
+
+
+def test_blur16_isa_check_accepts_the_layouts_and_names_the_hazards():
+    """vbs_amd/_isa_check.py (run by build() on the real disassembly): a loader whose in-flight load registers are only
+    touched between their wait and their refill passes, rotated loop or not; a copy of a register whose load is still in
+    flight, a register set that moved between the prologue and the loop, and staging code that touches another set each
+    fail with a message that names the instruction."""
+    from vbs_amd._isa_check import check_blur16
+    for rot in (True, False):
+        assert check_blur16(_loader_asm(rotated=rot)) == []
+        p = check_blur16(_loader_asm(rotated=rot, copy_in_flight=True))
+        assert len(p) == 1 and "v_mov_b32_e32 v90, v60" in p[0]
+        p = check_blur16(_loader_asm(rotated=rot, moved=True))
+        assert p and "register set moved" in p[0]
+        p = check_blur16(_loader_asm(rotated=rot, touch_other=True))
+        assert len(p) == 1 and "v_mov_b32_e32 v91, v4" in p[0] and "another set" in p[0]
+    assert check_blur16("no kernels here\n") == ["no k_blur16 instantiation found in the assembly"]

@@ -47,9 +47,30 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), suffix: st
         for warn in ex.map(run, jobs):
             if verbose and warn:
                 print(warn, file=sys.stderr)
+    _check_isa(force or any("k_blur.hip" in " ".join(j) for j in jobs), list(extra_flags), suffix, run)
     if force or jobs or _stale(lib, objs):
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", lib] + objs)
     return lib
+
+
+def _check_isa(rebuilt: bool, extra_flags, suffix, run):
+    """k_blur16's loader keeps loads in flight across inline-asm statements: what the register allocator did with their
+    destination registers is checked in the disassembly after every (re)build of k_blur.hip (vbs_amd/_isa_check.py says
+    what is checked and why); a violation fails the build."""
+    from . import _isa_check
+    src = os.path.join(CSRC, "k_blur.hip")
+    asm = os.path.join(CSRC, "k_blur" + suffix + ".s")
+    stamp = asm + ".ok"
+    if not rebuilt and os.path.exists(stamp) and os.path.getmtime(stamp) >= os.path.getmtime(src):
+        return
+    run([HIPCC] + FLAGS + FILE_FLAGS.get("k_blur.hip", []) + extra_flags + ["--cuda-device-only", "-S", src, "-o", asm])
+    problems = _isa_check.check_blur16(open(asm).read())
+    os.remove(asm)
+    if problems:
+        if os.path.exists(stamp):
+            os.remove(stamp)
+        raise RuntimeError("k_blur16 ISA check failed (vbs_amd/_isa_check.py):\n  " + "\n  ".join(problems))
+    open(stamp, "w").write("ok\n")
 
 
 if __name__ == "__main__":

@@ -7,7 +7,8 @@ constraints.  Two silent failures were met while that was written:
 value while its load was still in flight, and a `"+v"` operand the allocator MOVED - copied before the wait, i.e. before the
 data had arrived.  Nothing in the language forbids either, so the disassembly is checked after every build:
 
-  (i)   the loader's inline-asm blocks come in the order  L L L L  (W12 L) x 4  W0 W0 W0 W0
+  (i)   the loader's inline-asm blocks come in the order  L L L L  (W12 L) x 4  W0 W0 W0 W0, the loop's eight in cyclic
+        order - a rotated loop has its last refill in front of the header -
         (L = four global_load_dwordx4, W12 / W0 = s_waitcnt vmcnt(12) / vmcnt(0));
   (ii)  load group k of the loop writes the same 16 registers as load group k of the prologue (the sets did not move);
   (iii) outside the asm blocks, a register of set k is mentioned ONLY between the loop's k-th wait and the load group
@@ -80,36 +81,60 @@ def check_blur16(asm: str):
             if t and not t.endswith(":") and not t.startswith("."):
                 items.append(("code", t, i))
             i += 1
-        kinds = [it[1] for it in items if it[0] == "asm" and it[1] != "?"]
-        want = ["L"] * 4 + ["W12", "L"] * 4 + ["W0"] * 4
-        if kinds != want:
-            problems.append(f"{name}: inline-asm blocks come as {' '.join(kinds)}, expected {' '.join(want)}")
+        A = [k for k, it in enumerate(items) if it[0] == "asm"]
+        kinds = [items[k][1] for k in A]
+        # prologue: four load groups; tail: four full waits; between them the loop's eight blocks, (W12 L) x 4 in CYCLIC
+        # order (the compiler may rotate the loop: the last refill then sits in the latch block in front of the header)
+        if len(kinds) != 16 or kinds[:4] != ["L"] * 4 or kinds[12:] != ["W0"] * 4 or \
+                sorted(kinds[4:12]) != ["L"] * 4 + ["W12"] * 4:
+            problems.append(f"{name}: inline-asm blocks come as {' '.join(kinds)}: expected L L L L, then (W12 L) x 4 in "
+                            f"cyclic order, then W0 W0 W0 W0")
             continue
-        asm_idx = [k for k, it in enumerate(items) if it[0] == "asm" and it[1] != "?"]
-        pro = [items[asm_idx[k]][2] for k in range(4)]
-        loop_w = [asm_idx[4 + 2 * k] for k in range(4)]
-        loop_l = [asm_idx[5 + 2 * k] for k in range(4)]
+        loop = A[4:12]
+        lk = kinds[4:12]
+        if any(lk[i] == lk[(i + 1) % 8] for i in range(8)):
+            problems.append(f"{name}: the loop's asm blocks do not alternate wait / load: {' '.join(lk)}")
+            continue
+        waits = [i for i in range(8) if lk[i] == "W12"]                 # in program order: tiles j = 0 .. 3
+        refill = [loop[(i + 1) % 8] for i in waits]                     # the load group that follows each wait, cyclically
+        pro = [items[A[k]][2] for k in range(4)]
         for k in range(4):
-            if items[loop_l[k]][2] != pro[k]:
-                problems.append(f"{name}: load group {k} of the loop writes {sorted(items[loop_l[k]][2])}, the prologue's "
-                                f"wrote {sorted(pro[k])}: the register set moved")
-        sets = pro
-        allregs = set().union(*sets)
-        first, last = asm_idx[0], asm_idx[-1]
-        for pos in range(first, last + 1):
+            if items[refill[k]][2] != pro[k]:
+                problems.append(f"{name}: the load group behind wait {k} writes {sorted(items[refill[k]][2])}, the prologue's "
+                                f"group {k} wrote {sorted(pro[k])}: the register set moved")
+        allregs = set().union(*pro)
+        lo, hi = A[3], A[12]                                             # region of the loop: between the prologue and the tail
+        for pos in range(A[0], len(items)):
             it = items[pos]
             if it[0] != "code":
                 continue
             used = _regs(it[1]) & allregs
             if not used:
                 continue
-            owner = [k for k in range(4) if loop_w[k] < pos < loop_l[k]]
-            if not owner:
-                problems.append(f"{name}+{it[2]}: `{it[1]}` touches in-flight load registers {sorted(used)} outside any "
-                                f"staging window (between a wait and the refill of its set)")
-            elif not used <= sets[owner[0]]:
-                problems.append(f"{name}+{it[2]}: `{it[1]}` in the staging window of set {owner[0]} touches registers "
-                                f"{sorted(used - sets[owner[0]])} of another set")
+            if pos < lo:                                 # prologue: a set is in flight from ITS load group on
+                inflight = set().union(*[pro[k] for k in range(4) if A[k] < pos])
+                if used & inflight:
+                    problems.append(f"{name}+{it[2]}: `{it[1]}` touches load registers {sorted(used & inflight)} already in "
+                                    f"flight in the prologue")
+                continue
+            if pos > hi:                                 # tail: everything has landed behind the first full wait
+                continue
+            before = [k for k in loop if k < pos]
+            after = [k for k in loop if k > pos]
+            if not before:
+                # between the prologue and the loop's first asm block: the preheader (all four sets in flight) and, in a
+                # rotated loop, the top of the latch block - nothing there has business with these registers
+                problems.append(f"{name}+{it[2]}: `{it[1]}` touches load registers {sorted(used)} between the prologue and the "
+                                f"loop's first wait / refill")
+                continue
+            prev_asm = before[-1]
+            next_asm = after[0] if after else loop[0]                    # (cyclic: a rotated loop refills in its latch block)
+            if items[prev_asm][1] != "W12" or items[next_asm][1] != "L":
+                problems.append(f"{name}+{it[2]}: `{it[1]}` touches in-flight load registers {sorted(used)} outside a staging "
+                                f"window (between a wait and the refill of its set)")
+            elif not used <= items[next_asm][2]:
+                problems.append(f"{name}+{it[2]}: `{it[1]}` in the staging window of registers {sorted(items[next_asm][2])[:1]}.. "
+                                f"touches {sorted(used - items[next_asm][2])} of another set")
     if not seen:
         problems.append("no k_blur16 instantiation found in the assembly")
     return problems

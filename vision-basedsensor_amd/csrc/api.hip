@@ -151,7 +151,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
         for (int v : kb) { sumb += v; mx = std::max(mx, v); }
         if (suma != 256 || sumb != 256 || mx > 127) { h->err = "internal: blur taps do not fit int8"; return VBS_EINVAL; }
         frags = bp.small ? blur_mfma_fragments(ka, kb, 3, 0, 3) : blur_mfma_fragments(ka, kb, 5, 1, 3);
-        if (!bp.small && width >= 128 && (width & 3) == 0) blur16_fragments(ka, kb, width, &frags16h, &frags16v);
+        if (width >= (bp.small ? 176 : 240) && (width & 3) == 0) blur16_fragments(ka, kb, width, bp.small != 0, &frags16h, &frags16v);
     }
 
     const size_t B = (size_t)max_batch, HW = (size_t)height * h->WW;

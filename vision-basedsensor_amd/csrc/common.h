@@ -161,7 +161,7 @@ void make_contour_lut(u8 out[256]);
 std::vector<u32> ncc_mfma_fragments(const NccConst& nc, int l);
 std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::vector<int>& taps_b, int nk,
                                      int sa0, int nka);
-void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& taps_l, int W, std::vector<u32>* hfrag,
+void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& taps_l, int W, bool small, std::vector<u32>* hfrag,
                       std::vector<u32>* vfrag);
 void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s);

@@ -77,8 +77,12 @@ __global__ __launch_bounds__(256) void k_gray(const u8* __restrict__ frames, int
         }
         return;
     }
-    const int x0 = (blockIdx.x * 256 + threadIdx.x) * 16, y = blockIdx.y;
-    if (x0 >= P) return;
+    // rows with their own stride (a crop view, a pitched plane): thread = (row, 16-pixel piece), pieces of consecutive rows
+    // side by side in a block - a 480-pixel row fills 30 of a block's 256 threads when every block takes one row
+    // (0.73 us per 480x450 BGR frame of the reference's cropped configuration, the largest kernel of that workload)
+    const int ppr = P >> 4, idx = blockIdx.x * 256 + threadIdx.x;
+    const int y = idx / ppr, x0 = (idx - y * ppr) * 16;
+    if (y >= H) return;
     const u8* src = frames + (int64_t)n * stride_n + (int64_t)y * stride_row;
     u8* dst = gray + ((int64_t)n * H + y) * P + x0;
     if (vec_ok && channels == 3 && x0 + 16 <= W) {
@@ -433,14 +437,29 @@ std::vector<u32> blur_mfma_fragments(const std::vector<int>& taps_a, const std::
 // Horizontal tile t = rows Y0 - 56 + 16 t ..: the output tile of step t (rows Y0 + 16 (t - 7) ..) reads tiles t-7 .. t of
 // the large kernel and tiles t-5 .. t-2 of the small one.  Ring slot = t mod 8 (mod 4), the step loop is unrolled by 8,
 // and what changes with the phase is the vertical fragment: 8 + 4 variants in LDS.
-#define B16_RL 50
-#define B16_RS 19
-#define B16_LEFT 56
+// SMALL BRANCH (round 4; 35 / 21 taps, the reference's real configuration: 640x480 through the default crop = 480 x 450):
+// the same kernel with SB = true.  A 16 + 34 pixel window fits ONE K = 64 operand (two horizontal products per step instead
+// of three or four), a 16 + 34 row window four 16-row tiles, which both kernels share (tiles t-3 .. t: one 4-tile ring per
+// byte plane, four vertical products), the workgroup's window is 176 bytes of a row (11 pieces) and the output tile of step
+// t is tile t - 3.  Everything else - loader wave, ring of eight slots, hand-shake, range test, mask stores - is the code
+// below, unchanged.
+// WIDTHS THAT ARE A MULTIPLE OF 4 BUT NOT OF 8 (round 4): the workgroup at the right end of a row has its window shifted
+// to X0 = W - 240, which is then 4 (mod 8), while the strips read their operands with 8-byte LDS loads.  The staged rows
+// keep an 8-aligned origin XB = X0 & ~7 instead (the loader stores that workgroup's pieces as dwords at byte X0 - XB),
+// so every strip's offset L0 - XB stays a multiple of 8.
 #define B16_NSW 7                                        // strips (compute waves) per workgroup; wave B16_NSW is the loader
-#define B16_NP 15                                        // 16-byte pieces of the workgroup's window per row: 112 + 128 columns
-#define B16_ROWB 272                                     // LDS bytes per staged row: 240 + pad; eight rows tile the banks
 #define B16_NS 8                                         // tiles of rows in LDS (ring slots; 4: +3 %, 6: +2 % on the kernel's time)
 #define B16_LD 4                                         // tiles the loader keeps on their way from memory
+template <bool SB> struct B16 {
+    static constexpr int LEFT = SB ? 24 : 56;            // window / tile origin left of (above) the strip's first column (row)
+    static constexpr int WIN = SB ? 64 : 128;            // a strip's window
+    static constexpr int NP = SB ? 11 : 15;              // 16-byte pieces of the workgroup's window per row: 112 + WIN columns
+    static constexpr int ROWB = SB ? 208 : 272;          // LDS bytes per staged row: pieces + pad (+ 4 for the shifted origin)
+    static constexpr int DEPTH = SB ? 3 : 7;             // the output tile of step t is tile t - DEPTH
+    static constexpr int NVF = SB ? 8 : 12;              // vertical fragment variants (ring phases of the two kernels)
+    static constexpr int WG_LEFT = SB ? 32 : 64;         // the workgroup's window starts this far left of its first strip
+};
+#define B16_LEFT 56                                      // (large branch, host side)
 
 __device__ __forceinline__ void pack16(const v4i& acc, int& hi, int& lo) {
     const u32 t01 = __builtin_amdgcn_perm((u32)acc[1], (u32)acc[0], 0x05010400u);
@@ -449,14 +468,16 @@ __device__ __forceinline__ void pack16(const v4i& acc, int& hi, int& lo) {
     hi = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
 }
 
-template <bool U8OUT>
+template <bool U8OUT, bool SB>
 __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __restrict__ gray, int64_t gstride_n, int gstride_row,
                                                    const uint4* __restrict__ hfrag, const uint4* __restrict__ vfrag,
                                                    u64* __restrict__ bits, u8* __restrict__ area_u8,
                                                    u32* __restrict__ fstat, int H, int W, int WW, int tiles_per_seg,
                                                    int k3, int k8, int span_i, int nframes, int gx, int gy, int dbg_drop) {
-    __shared__ uint4 vf[12 * 64];
-    __shared__ __align__(16) u8 stg[B16_NS][16 * B16_ROWB];
+    typedef B16<SB> G;
+    constexpr int B16_LEFT_ = G::LEFT, B16_NP = G::NP, B16_ROWB = G::ROWB, DEPTH = G::DEPTH;
+    __shared__ uint4 vf[G::NVF * 64];
+    __shared__ __align__(16) u8 stg[B16_NS][16 * G::ROWB];
     __shared__ u32 staged;                               // tiles the loader has staged so far
     __shared__ u32 done[B16_NS];                         // done[s]: reads of slot s the strips have finished, ever
     const int tid = threadIdx.x, lane = tid & 63;
@@ -477,27 +498,29 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
     const int tile0 = by * tiles_per_seg;
     const int ntiles = min(tiles_per_seg, tilesY - tile0);
     if (ntiles <= 0) return;
-    for (int i = tid; i < 12 * 64; i += 64 * (B16_NSW + 1)) vf[i] = vfrag[i];
+    for (int i = tid; i < G::NVF * 64; i += 64 * (B16_NSW + 1)) vf[i] = vfrag[i];
     const bool is_loader = wave == B16_NSW;              // (uniform)
     const int strip = bx * B16_NSW + wave, xw = 16 * strip;
-    const int Y0 = tile0 * 16, nsteps = ntiles + 7;
+    const int Y0 = tile0 * 16, nsteps = ntiles + DEPTH;
     const bool live = !is_loader && xw < W;              // (uniform) else a strip in the padding of the last mask word
     if (!is_loader && !live && xw < 64 * WW)
         for (int y = Y0 + lane; y < min(Y0 + 16 * ntiles, H); y += 64)
             reinterpret_cast<unsigned short*>(bits)[((int64_t)n * H + y) * WW * 4 + strip] = 0;
-    const int L0 = min(max(xw - B16_LEFT, 0), W - 128);  // this strip's window [L0, L0 + 128): shifted to stay inside the row
-    const bool edge = L0 != xw - B16_LEFT;               // (uniform) the 39-tap window is not all inside Q
+    const int L0 = min(max(xw - B16_LEFT_, 0), W - G::WIN);   // this strip's window [L0, L0 + WIN): shifted to stay inside the row
+    const bool edge = !SB && L0 != xw - B16_LEFT_;       // (uniform) the 39-tap window is not all inside Q
     v4i lp, lq, sq, sp = {0, 0, 0, 0};
     {
         const uint4* hf = hfrag + (size_t)min(strip, (W + 15) / 16 - 1) * 4 * 64 + lane;
-        const uint4 a = hf[0], b = hf[64], c = hf[128];
-        lp = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w};
+        const uint4 b = hf[64], c = hf[128];
         lq = v4i{(int)b.x, (int)b.y, (int)b.z, (int)b.w};
         sq = v4i{(int)c.x, (int)c.y, (int)c.z, (int)c.w};
+        lp = v4i{0, 0, 0, 0};
+        if (!SB) { const uint4 a = hf[0]; lp = v4i{(int)a.x, (int)a.y, (int)a.z, (int)a.w}; }
         if (edge) { const uint4 d = hf[192]; sp = v4i{(int)d.x, (int)d.y, (int)d.z, (int)d.w}; }
     }
     const u8* gf = gray + (int64_t)n * gstride_n;        // (uniform)
-    const int X0 = min(max(16 * B16_NSW * bx - 64, 0), W - 16 * B16_NP);   // the workgroup's window [X0, X0 + 240): inside the row
+    const int X0 = min(max(16 * B16_NSW * bx - G::WG_LEFT, 0), W - 16 * B16_NP);   // the workgroup's window [X0, X0 + 16 NP): inside the row
+    const int XB = X0 & ~7;                              // origin of the staged rows (see "widths that are a multiple of 4" above)
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // operand fragments landed (see k_blur_mfma)
     if (tid < B16_NS) done[tid] = 0;
@@ -525,16 +548,16 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
             prow[k] = pval[k] ? id / B16_NP : 0;
             const int pc = pval[k] ? id - B16_NP * prow[k] : 0;
             poff[k] = (u32)(__mul24(prow[k], gstride_row) + X0 + 16 * pc);
-            pdst[k] = &stg[0][0] + B16_ROWB * prow[k] + 16 * pc;
+            pdst[k] = &stg[0][0] + B16_ROWB * prow[k] + (X0 - XB) + 16 * pc;
         }
         u32x4 R[B16_LD][4];
 #pragma unroll
         for (int j = 0; j < B16_LD; ++j)
 #pragma unroll
             for (int k = 0; k < 4; ++k) R[j][k] = u32x4{0, 0, 0, 0};
-        auto row_of = [&](int t, int r) { return reflect101(Y0 - B16_LEFT + 16 * t + r, H); };
+        auto row_of = [&](int t, int r) { return reflect101(Y0 - B16_LEFT_ + 16 * t + r, H); };
         auto issue = [&](int t, u32x4 (&Rt)[4]) {
-            const int yt = Y0 - B16_LEFT + 16 * t;       // (uniform)
+            const int yt = Y0 - B16_LEFT_ + 16 * t;      // (uniform)
             u32 o[4];
             if (yt >= 0 && yt + 15 < H) {
 #pragma unroll
@@ -574,9 +597,14 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     u8* dst = pdst[k] + sb;
-                    if (pval[k])
-                        *reinterpret_cast<uint4*>(dst) = make_uint4(R[j][k].x ^ 0x80808080u, R[j][k].y ^ 0x80808080u,
-                                                                    R[j][k].z ^ 0x80808080u, R[j][k].w ^ 0x80808080u);
+                    const uint4 v = make_uint4(R[j][k].x ^ 0x80808080u, R[j][k].y ^ 0x80808080u,
+                                               R[j][k].z ^ 0x80808080u, R[j][k].w ^ 0x80808080u);
+                    if (X0 == XB) {                      // (uniform)
+                        if (pval[k]) *reinterpret_cast<uint4*>(dst) = v;
+                    } else if (pval[k]) {                // the shifted origin: 4-byte aligned pieces
+                        u32* d32 = reinterpret_cast<u32*>(dst);
+                        d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
+                    }
                 }
                 // (release: the rows above are in LDS before the tick is)
 #ifdef VBS_DEBUG_KNOBS
@@ -598,8 +626,8 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
     // ================================ the strips ======================================================================
     // LDS row: pixel x of the workgroup's window at byte 8 + (x - X0), so that every strip's operand window (it starts
     // 8 + 16 wave pixels in) is 16-byte aligned.  Lane (g, q) takes row q: P = window bytes 16 g (+ 64 for g >= 2), Q = 32 + 16 g.
-    const u8* const rP = &stg[0][0] + B16_ROWB * q + (L0 - X0) + 16 * g + (g >= 2 ? 64 : 0);
-    const u8* const rQ = &stg[0][0] + B16_ROWB * q + (L0 - X0) + 32 + 16 * g;
+    const u8* const rP = &stg[0][0] + B16_ROWB * q + (L0 - XB) + 16 * g + (g >= 2 ? 64 : 0);
+    const u8* const rQ = &stg[0][0] + B16_ROWB * q + (L0 - XB) + (SB ? 0 : 32) + 16 * g;
     // A tile is read once the loader has counted it into `staged` (the strip remembers the last count it saw and asks again
     // only beyond it: the loader runs tiles ahead), and ticked off a step later, when its operands have been multiplied.  Bounded spins: a logic error cannot hang the GPU;
     // a wait that expires sets the frame's status word (VBS_EINTERNAL in counts[]).
@@ -616,11 +644,14 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
             // expired: reported in the frame's status word (k_finalize hands it to counts[]), never continued silently
             if (rt >= known && !lost) { lost = true; if (lane == 0) atomicMin((int*)&fstat[n * 8 + 2], VBS_EINTERNAL); }
         }
-        const uint2* a = reinterpret_cast<const uint2*>(rP + rslot * (16 * B16_ROWB));   // (8-byte aligned: two halves each)
-        const uint2* b = reinterpret_cast<const uint2*>(rQ + rslot * (16 * B16_ROWB));
-        const uint2 a0 = a[0], a1 = a[1], b0 = b[0], b1 = b[1];
-        p = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        const uint2* b = reinterpret_cast<const uint2*>(rQ + rslot * (16 * B16_ROWB));   // (8-byte aligned: two halves each)
+        const uint2 b0 = b[0], b1 = b[1];
         qq = make_uint4(b0.x, b0.y, b1.x, b1.y);
+        if (!SB) {
+            const uint2* a = reinterpret_cast<const uint2*>(rP + rslot * (16 * B16_ROWB));
+            const uint2 a0 = a[0], a1 = a[1];
+            p = make_uint4(a0.x, a0.y, a1.x, a1.y);
+        }
         ++rt;
         if (++rslot == B16_NS) rslot = 0;
     };
@@ -643,12 +674,12 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
     auto flush_rows = [&](int tg) {                      // tiles of steps tg .. tg + 7
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
-            const int y = Y0 + 16 * (tg + k - 7) + lane;
-            if (live && lane < 16 && tg + k >= 7 && tg + k < nsteps && y < H)
+            const int y = Y0 + 16 * (tg + k - DEPTH) + lane;
+            if (live && lane < 16 && tg + k >= DEPTH && tg + k < nsteps && y < H)
                 mb16[(u32)__mul24(y, 4 * WW)] = (unsigned short)(pp[k >> 1] >> (16 * (k & 1)));
         }
     };
-    uint4 aP_, aQ_;
+    uint4 aP_ = make_uint4(0, 0, 0, 0), aQ_;
     read_ops(aP_, aQ_);                                  // tile 0
     for (int t0 = 0; t0 < nsteps; t0 += 8) {
 #pragma unroll
@@ -656,6 +687,9 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
             const int t = t0 + u;
             if (t >= nsteps) break;                      // uniform
             const v4i aP = v4i{(int)aP_.x, (int)aP_.y, (int)aP_.z, (int)aP_.w}, aQ = v4i{(int)aQ_.x, (int)aQ_.y, (int)aQ_.z, (int)aQ_.w};
+            v4i d8 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
+            int yo;
+            if (!SB) {
             // this step's vertical fragments, asked for here and used after the horizontal products
             const uint4 fa_ = vf[u * 64 + lane], fb_ = vf[((u + 4) & 7) * 64 + lane], fs_ = vf[(8 + (u & 3)) * 64 + lane];
             // ---- horizontal tile t ----
@@ -676,12 +710,11 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                 S4h[(u + 2) & 3] = Sdh[(u + 2) & 3];     // tile t - 2 (zeros for t < 2) takes the place of tile t - 6
                 S4l[(u + 2) & 3] = Sdl[(u + 2) & 3];
             }
-            if (t >= 7) {
+            if (t < DEPTH) { if (u == 7) flush_rows(t0); continue; }
             // ---- vertical: output rows yo .. yo + 15, lane (g, q) gets rows yo + 4 g + i of column xw + q ----
-            const int yo = Y0 + 16 * (t - 7);
+            yo = Y0 + 16 * (t - DEPTH);
             const v4i fa = v4i{(int)fa_.x, (int)fa_.y, (int)fa_.z, (int)fa_.w}, fb = v4i{(int)fb_.x, (int)fb_.y, (int)fb_.z, (int)fb_.w};
             const v4i fs = v4i{(int)fs_.x, (int)fs_.y, (int)fs_.z, (int)fs_.w};
-            v4i d8 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
             d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LhA, d8, 0, 0, 0);
             d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4h, d3, 0, 0, 0);
             d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, LhB, d8, 0, 0, 0);
@@ -692,6 +725,35 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
             for (int i = 0; i < 4; ++i) d8[i] = (d8[i] << 8) + k8;
             d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LlA, d8, 0, 0, 0);
             d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, LlB, d8, 0, 0, 0);
+            } else {
+            // small branch: one window operand, both kernels over the same four tiles (ring slot u & 3; LhA / LlA hold the
+            // 35-tap kernel's byte planes, S4h / S4l the 21-tap kernel's)
+            const uint4 fa_ = vf[(u & 3) * 64 + lane], fs_ = vf[(4 + (u & 3)) * 64 + lane];
+            v4i accL = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
+            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, lq, accL, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, sq, accS, 0, 0, 0);
+            tick_done();
+            if (t + 1 < nsteps) read_ops(aP_, aQ_);
+            {
+                int hi, lo;
+                pack16(accL, hi, lo);
+                LhA[u & 3] = hi; LlA[u & 3] = lo;
+                pack16(accS, hi, lo);
+                S4h[u & 3] = hi; S4l[u & 3] = lo;
+            }
+            if (t < DEPTH) { if (u == 7) flush_rows(t0); continue; }
+            yo = Y0 + 16 * (t - DEPTH);
+            const v4i fa = v4i{(int)fa_.x, (int)fa_.y, (int)fa_.z, (int)fa_.w}, fs = v4i{(int)fs_.x, (int)fs_.y, (int)fs_.z, (int)fs_.w};
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LhA, d8, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4h, d3, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d8[i] = (d8[i] << 8) + k8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d3[i] = (d3[i] << 8) + k3;
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LlA, d8, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4l, d3, 0, 0, 0);
+            }
+            {
             u64 pw[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -733,21 +795,25 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
 //     entry for window pixel x_in and output column x is the sum of the taps j with reflect101(x + j - R) = x_in
 //   vertical: A operands, output row on the lane; byte 4 pos + i of lane group g is row 4 g + i of the tile in ring slot
 //     pos; variant psi for the phase of the ring (8 for the large kernel's two groups, 4 for the small kernel's)
-void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& taps_l, int W, std::vector<u32>* hfrag,
+void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& taps_l, int W, bool small, std::vector<u32>* hfrag,
                       std::vector<u32>* vfrag) {
     const int nstrips = (W + 15) / 16;
+    const int LEFT = small ? B16<true>::LEFT : B16<false>::LEFT, WIN = small ? B16<true>::WIN : B16<false>::WIN;
     auto refl = [&](int i) { if (i < 0) i = -i; if (i >= W) i = 2 * (W - 1) - i; return std::min(std::max(i, 0), W - 1); };
     hfrag->assign((size_t)nstrips * 4 * 64 * 4, 0);
     for (int s = 0; s < nstrips; ++s) {
-        const int xw = 16 * s, L0 = std::min(std::max(xw - B16_LEFT, 0), W - 128);
+        const int xw = 16 * s, L0 = std::min(std::max(xw - LEFT, 0), W - WIN);
         for (int f = 0; f < 4; ++f) {
+            // large branch: LP, LQ, SQ, SP over the two operands of the 128-pixel window; small branch: slots 1 and 2 are
+            // the 35- and the 21-tap kernel over the ONE 64-pixel operand, slots 0 and 3 stay empty
+            if (small && (f == 0 || f == 3)) continue;
             const std::vector<int>& taps = f < 2 ? taps_l : taps_s;
             const int R = (int)taps.size() / 2;
             const bool useP = (f == 0 || f == 3);
             for (int lane = 0; lane < 64; ++lane) {
                 const int g = lane >> 4, x = std::min(xw + (lane & 15), W - 1);
                 for (int e = 0; e < 16; ++e) {
-                    const int k = 16 * g + e, w = useP ? (k < 32 ? k : k + 64) : 32 + k, xin = L0 + w;
+                    const int k = 16 * g + e, w = small ? k : (useP ? (k < 32 ? k : k + 64) : 32 + k), xin = L0 + w;
                     int c = 0;
                     for (int j = 0; j <= 2 * R; ++j) if (refl(x + j - R) == xin) c += taps[j];
                     (*hfrag)[(((size_t)s * 4 + f) * 64 + lane) * 4 + (e >> 2)] |= (u32)(c & 255) << (8 * (e & 3));
@@ -755,16 +821,21 @@ void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& ta
             }
         }
     }
-    vfrag->assign((size_t)12 * 64 * 4, 0);
-    for (int v = 0; v < 12; ++v) {
-        const std::vector<int>& taps = v < 8 ? taps_l : taps_s;
+    // vertical variants: ring phase psi; large branch 8 (101 taps over eight tiles) + 4 (39 taps over tiles t-5 .. t-2),
+    // small branch 4 + 4 (both kernels over tiles t-3 .. t)
+    const int nv = small ? 8 : 12, nl = small ? 4 : 8;
+    vfrag->assign((size_t)nv * 64 * 4, 0);
+    for (int v = 0; v < nv; ++v) {
+        const std::vector<int>& taps = v < nl ? taps_l : taps_s;
         const int R = (int)taps.size() / 2;
         for (int lane = 0; lane < 64; ++lane) {
             const int g = lane >> 4, m = lane & 15;
             for (int e = 0; e < 16; ++e) {
                 const int pos = e >> 2, i = e & 3;
-                const int a = v < 8 ? ((v - pos) % 8 + 8) % 8 : 2 + (((v - 8) - pos - 2) % 4 + 4) % 4;
-                const int k = R + B16_LEFT - 16 * a + 4 * g + i - m;
+                int a;                                   // age of the tile in ring slot `pos`: 0 = this step's
+                if (small) a = (((v < nl ? v : v - nl) - pos) % 4 + 4) % 4;
+                else a = v < 8 ? ((v - pos) % 8 + 8) % 8 : 2 + (((v - 8) - pos - 2) % 4 + 4) % 4;
+                const int k = R + LEFT - 16 * a + 4 * g + i - m;
                 const u32 c = (k >= 0 && k <= 2 * R) ? (u32)taps[k] : 0u;
                 (*vfrag)[((size_t)v * 64 + lane) * 4 + (e >> 2)] |= c << (8 * (e & 3));
             }
@@ -772,9 +843,11 @@ void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& ta
     }
 }
 
-// the strips kernel takes the large branch on frames whose rows load as aligned dwords (else k_blur_mfma)
+// the strips kernel takes frames whose rows load as aligned dwords (else k_blur_mfma): large branch from 240 columns,
+// small branch from 176; widths that are a multiple of 4
 static bool blur16_takes(const vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstride_row) {
-    return h->blur_impl == 0 && h->blur16_h && !h->bp.small && h->W >= 16 * B16_NP && (h->W & 7) == 0 && h->H >= 64 &&
+    const int minw = 16 * (h->bp.small ? B16<true>::NP : B16<false>::NP);
+    return h->blur_impl == 0 && h->blur16_h && h->W >= minw && (h->W & 3) == 0 && h->H >= 64 &&
            (reinterpret_cast<uintptr_t>(gray) & 3) == 0 && (gstride_n & 3) == 0 && (gstride_row & 3) == 0 &&
            gstride_row >= h->W && gstride_row < (1 << 23) && (int64_t)h->H * gstride_row < (1ll << 31);
 }
@@ -789,7 +862,8 @@ void launch_gray(vbs_handle* h, const u8* frames, int nb, int channels, int64_t 
                    gray, npx, gray_coef(h->gray_bits));
         return;
     }
-    dim3 grid = flat ? dim3((unsigned)(((int64_t)h->H * h->W + 8191) / 8192), 1, nb) : dim3((h->P / 16 + 255) / 256, h->H, nb);
+    dim3 grid = flat ? dim3((unsigned)(((int64_t)h->H * h->W + 8191) / 8192), 1, nb)
+                     : dim3((unsigned)(((int64_t)h->H * (h->P / 16) + 255) / 256), 1, nb);
     VBS_LAUNCH(h, s, "k_gray", k_gray, grid, dim3(256), 0, s, frames, channels, stride_n, stride_row, gray,
                        h->H, h->W, h->P, gray_coef(h->gray_bits), vec_ok, flat);
 }
@@ -806,12 +880,13 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
         // many frames: a 1-D grid that the kernel maps to (frame, strip group, segment) with a frame's workgroups on one XCD
         const int xcd = nb >= 32 ? nb : 0;
         dim3 grid16 = xcd ? dim3((unsigned)((nb + 7) / 8 * 8 * gx16 * nseg)) : dim3(gx16, nseg, nb);
-        if (area_u8)
-            VBS_LAUNCH(h, s, "k_blur16", k_blur16<true>, grid16, dim3(64 * (B16_NSW + 1)), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
-                       h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg, VBS_KNOB("VBS_BLUR16_DROP"));
-        else
-            VBS_LAUNCH(h, s, "k_blur16", k_blur16<false>, grid16, dim3(64 * (B16_NSW + 1)), 0, s, gray, gstride_n, (int)gstride_row, h->blur16_h,
-                       h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8, h->bp.hi - h->bp.thresh, xcd, gx16, nseg, VBS_KNOB("VBS_BLUR16_DROP"));
+#define B16_GO(U8, SB_)                                                                                                       \
+    VBS_LAUNCH(h, s, "k_blur16", (k_blur16<U8, SB_>), grid16, dim3(64 * (B16_NSW + 1)), 0, s, gray, gstride_n, (int)gstride_row, \
+               h->blur16_h, h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8,                       \
+               h->bp.hi - h->bp.thresh, xcd, gx16, nseg, VBS_KNOB("VBS_BLUR16_DROP"))
+        if (h->bp.small) { if (area_u8) B16_GO(true, true); else B16_GO(false, true); }
+        else { if (area_u8) B16_GO(true, false); else B16_GO(false, false); }
+#undef B16_GO
         return;
     }
     const int gx = (h->P + 127) / 128, tilesY = (h->H + 31) / 32;

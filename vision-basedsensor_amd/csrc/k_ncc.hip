@@ -270,24 +270,6 @@ __device__ __forceinline__ double ncc_theta(double c, double nn, double sum_t, d
 }
 
 typedef int i4 __attribute__((ext_vector_type(4)));
-#ifndef NCC_LOADV
-#define NCC_LOADV 2
-#endif
-#ifndef NCC_CONV
-#define NCC_CONV 0
-#endif
-#ifndef NCC_STORE
-#define NCC_STORE 0
-#endif
-#ifndef NCC_EARLYV
-#define NCC_EARLYV 1
-#endif
-#ifndef NCC_APF
-#define NCC_APF 1
-#endif
-#ifndef NCC_LUT
-#define NCC_LUT 1
-#endif
 typedef __attribute__((address_space(1))) u8 gl_u8;                  // global memory, stated (see load_rows)
 typedef __attribute__((address_space(1))) unsigned short gl_u16;
 
@@ -322,11 +304,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     // 39.5 KB for l = 80: four workgroups (16 waves) per CU; the time of this kernel goes with 1 / waves per SIMD.
     // (One struct: the table first, so that a ring address minus one ring length is still a valid LDS address.)
     __shared__ struct __align__(16) {
-#if NCC_LUT == 0
         uint4 lut[256];                                 // byte -> eight float16 0 / 1
-#else
-        uint4 lut[16];                                  // nibble -> four float16 0 / 1 in .x, .y (16-byte spacing, see fetch_ops)
-#endif
         _Float16 ring[4][2][16 * RSTR];
         u8 ringc[4][16 * CSTR];
         u32 elist[4][ECAP][10];                         // yo, -, uw[0..3] of a queued tile
@@ -346,11 +324,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
         u32 w[4];
 #pragma unroll
         for (int d = 0; d < 4; ++d) w[d] = (((u32)tid >> (2 * d)) & 1u ? 0x3C00u : 0u) | (((u32)tid >> (2 * d + 1)) & 1u ? 0x3C000000u : 0u);
-#if NCC_LUT == 0
         sm.lut[tid] = make_uint4(w[0], w[1], w[2], w[3]);
-#else
-        if (tid < 16) sm.lut[tid] = make_uint4(w[0], w[1], 0u, 0u);
-#endif
     }
     for (int i = lane; i < 2 * 16 * RSTR / 8; i += 64) reinterpret_cast<uint4*>(&sm.ring[wave][0][0])[i] = make_uint4(0, 0, 0, 0);
     for (int i = lane; i < 16 * CSTR / 16; i += 64) reinterpret_cast<uint4*>(&sm.ringc[wave][0])[i] = make_uint4(0, 0, 0, 0);
@@ -427,29 +401,25 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     unsigned short* mb16 = reinterpret_cast<unsigned short*>(mbits) + ((int64_t)n * H * WW + blockIdx.x) * 4 + wave;   // (uniform)
     // Row bits of a horizontal tile: lane (g, q) needs, of row q, the BYTE (wstart + 32 s) / 8 + g for every k-step s - its
     // eight columns of the 32 - and nothing else (wstart is a multiple of 8: xw of 16, LO of 8).  Strips whose window lies
-    // inside the row load exactly those bytes: NKS byte loads at lane offset q * rowbytes + g from a SCALAR base that
-    // moves down the strip (no vector instruction per step for the address, none to align or extract), issued a step
-    // ahead.  The first / last strips of a row go through clamped 64-bit loads.
+    // inside the row load the aligned 16 bytes around it with ONE load at lane offset q * rowbytes from a SCALAR base that
+    // moves down the strip (no vector instruction per step for the address), issued a step ahead; the byte sits at
+    // position c = (b0 & 3) + g + 4 s of the 16, i.e. byte c (< 8, the same in every step) of the dword pair (s + 1 : s):
+    // one v_perm per k-step with a per-lane selector puts it into byte 0 over zeros - no alignbit, no bfe.  (Loading the
+    // NKS bytes themselves - three byte loads at the lane's own byte offset, nothing to extract - was measured 12 % slower:
+    // three times the address work in the texture path)  The first / last strips of a row go through
+    // clamped 64-bit loads and build the same 16-byte form.
     const int wstart = xw + LO;                          // wave-uniform
     static_assert((LO & 7) == 0, "the window must start on a byte of the row");
     const int rowbytes = 8 * WW, b0 = wstart >> 3;
     // (uniform conditions as INTEGERS behind an opaque move: as booleans the compiler keeps each of them - and every
     //  bounds test of the clamped loads below, hoisted out of the step loop - as a 64-bit lane mask in two scalar
     //  registers, which this kernel then spills and reloads with v_readlane in every step)
-    int wide_i = __builtin_amdgcn_readfirstlane(((b0 >= 0) && (NCC_LOADV == 0 ? b0 + 4 * (NKS - 1) + 3 < rowbytes
-                                                                               : (b0 & ~3) + 16 <= rowbytes)) ? 1 : 0);
+    int wide_i = __builtin_amdgcn_readfirstlane(((b0 >= 0) && ((b0 & ~3) + 16 <= rowbytes)) ? 1 : 0);
     asm volatile("" : "+s"(wide_i));
 #define wide (wide_i != 0)
-    // (NCC_LOADV: how a wide strip gets its bytes - 0: NKS byte loads at the lane's own byte offset; 2: one aligned 16-byte
-    //  load + v_perm with a per-lane selector.  Measured)
-    u32 nby[NKS];
-#pragma unroll
-    for (int s = 0; s < NKS; ++s) nby[s] = 0;
     uint4 nraw = make_uint4(0, 0, 0, 0);
-    const u8* fby = reinterpret_cast<const u8*>(fbits) + (NCC_LOADV == 0 ? b0 : (b0 & ~3));   // (uniform; only dereferenced by wide strips)
-    const u32 lofs = (u32)(q * rowbytes + (NCC_LOADV == 0 ? g : 0));
-    // byte (b0 & 3) + g + 4 s of the 16 loaded: byte c = (b0 & 3) + g (< 8) of the dword pair (s + 1 : s), the same c in every
-    // step, so ONE v_perm per k-step with a per-lane selector puts it into byte 0 over zeros
+    const u8* fby = reinterpret_cast<const u8*>(fbits) + (b0 & ~3);     // (uniform; only dereferenced by wide strips)
+    const u32 lofs = (u32)(q * rowbytes);
     const u32 psel = 0x0C0C0C00u | (u32)((b0 & 3) + g);
     auto load_rows = [&](int t) {
         const int ytile = Y0 + LO + 16 * t;
@@ -465,32 +435,22 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 asm volatile("" : "+v"(lo_));
                 pg = (const gl_u8*)pb + lo_;
             } else {
-                pg = (const gl_u8*)fby + (u32)(__mul24(min(max(ytile + q, 0), H - 1), rowbytes) + (NCC_LOADV == 0 ? g : 0));
+                pg = (const gl_u8*)fby + (u32)__mul24(min(max(ytile + q, 0), H - 1), rowbytes);
             }
-            if (NCC_LOADV == 0) {
-#pragma unroll
-                for (int s = 0; s < NKS; ++s) nby[s] = pg[4 * s];
-            } else {
-                typedef u32 u32x4 __attribute__((ext_vector_type(4)));
-                typedef __attribute__((address_space(1))) const u32x4 gl_u4;
-                const u32x4 rr = *(gl_u4*)pg;
-                nraw = make_uint4(rr.x, rr.y, rr.z, rr.w);
-            }
+            typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+            typedef __attribute__((address_space(1))) const u32x4 gl_u4;
+            const u32x4 rr = *(gl_u4*)pg;
+            nraw = make_uint4(rr.x, rr.y, rr.z, rr.w);
         } else {
             const u64* row = fbits + (int64_t)min(max(ytile + q, 0), H - 1) * WW;
             int ws = __builtin_amdgcn_readfirstlane(wstart);
             asm volatile("" : "+s"(ws));                 // (its bounds tests are redone per step on the scalar unit, not kept)
             const u64 w0 = load_bits(row, WW, ws), w1 = NKS > 2 ? load_bits(row, WW, ws + 64) : 0ull;
             const u32 dw[4] = {(u32)w0, (u32)(w0 >> 32), (u32)w1, (u32)(w1 >> 32)};
-            if (NCC_LOADV == 0) {
-#pragma unroll
-                for (int s = 0; s < NKS; ++s) nby[s] = (dw[s] >> (8 * g)) & 255u;
-            } else {                                     // (the form the wide strips load: the window's first byte at byte b0 & 3)
-                const u32 sh = 8 * (b0 & 3);
-                nraw = make_uint4(dw[0] << sh, sh ? __builtin_amdgcn_alignbit(dw[1], dw[0], 32 - sh) : dw[1],
-                                  sh ? __builtin_amdgcn_alignbit(dw[2], dw[1], 32 - sh) : dw[2],
-                                  sh ? __builtin_amdgcn_alignbit(dw[3], dw[2], 32 - sh) : dw[3]);
-            }
+            const u32 sh = 8 * (b0 & 3);                 // (the form the wide strips load: the window's first byte at byte b0 & 3)
+            nraw = make_uint4(dw[0] << sh, sh ? __builtin_amdgcn_alignbit(dw[1], dw[0], 32 - sh) : dw[1],
+                              sh ? __builtin_amdgcn_alignbit(dw[2], dw[1], 32 - sh) : dw[2],
+                              sh ? __builtin_amdgcn_alignbit(dw[3], dw[2], 32 - sh) : dw[3]);
         }
     };
     // Undecided pixels (a handful per frame) leave the loop: a tile that has any is queued - its row and the four masks
@@ -509,15 +469,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     u32 pend_x = 0;
     int pend_yo = NO_TILE;
     const u32 off_lo = (u32)((8 * (lane & 1) + ((lane >> 1) & 3)) * rowbytes), off_hi = off_lo + (u32)(4 * rowbytes);   // bytes (lanes 0..7)
-#if NCC_STORE != 0
-    u32 pend_off1 = 0xFFFFFFFFu;
-#endif
     auto flush_pending = [&]() {
-#if NCC_STORE != 0
-        if (pend_off1 != 0xFFFFFFFFu) mb16[pend_off1] = (unsigned short)pend_x;
-        pend_off1 = 0xFFFFFFFFu;
-        return;
-#endif
         if (pend_yo != NO_TILE) {                        // uniform
             u8* base = reinterpret_cast<u8*>(mb16) + (int64_t)pend_yo * rowbytes;
             asm volatile("" : "+s"(base));               // (scalar base + 32-bit lane offset)
@@ -601,14 +553,9 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     h8 a_op[NKS];
     auto fetch_ops = [&](int tt) {
         u32 by[NKS];
-        if (NCC_LOADV == 0) {
+        const u32 rw[5] = {nraw.x, nraw.y, nraw.z, nraw.w, 0u};
 #pragma unroll
-            for (int s = 0; s < NKS; ++s) by[s] = nby[s];
-        } else {
-            const u32 rw[5] = {nraw.x, nraw.y, nraw.z, nraw.w, 0u};
-#pragma unroll
-            for (int s = 0; s < NKS; ++s) by[s] = __builtin_amdgcn_perm(rw[s + 1], rw[s], psel);
-        }
+        for (int s = 0; s < NKS; ++s) by[s] = __builtin_amdgcn_perm(rw[s + 1], rw[s], psel);
 #pragma unroll
         for (int s = 0; s < NKS; ++s) asm volatile("" : "+v"(by[s]) :: "memory");
         load_rows(tt + 1);                               // (unconditional: past the last step it reads rows nobody uses)
@@ -620,34 +567,15 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
             for (int s = 0; s < NKS; ++s) by[s] = rowin ? by[s] : 0u;
         }
 #pragma unroll
-#if NCC_LUT == 0
         for (int s = 0; s < NKS; ++s) a_op[s] = __builtin_bit_cast(h8, sm.lut[by[s]]);
-#else
-        // Two 8-byte reads of a 16-entry table per k-step instead of one 16-byte read of a 256-entry one: any two lanes
-        // read either the same entry (a broadcast) or entries in different banks (16 entries x 2 dwords, 4 banks apart),
-        // so the reads cannot conflict - the byte table's did whenever two lanes' bytes shared the low nibble (44 % of the
-        // kernel's LDS cycles, profiles/r4a_sq_counters.json, with the LDS the busiest unit of the horizontal phase).
-        // Entry n at byte 16 n: the high nibble's address is byte & 0xF0.
-        for (int s = 0; s < NKS; ++s) {
-            const char* lb = reinterpret_cast<const char*>(&sm.lut[0]);
-            const uint2 lo = *reinterpret_cast<const uint2*>(lb + ((by[s] << 4) & 0xF0u));
-            const uint2 hi = *reinterpret_cast<const uint2*>(lb + (by[s] & 0xF0u));
-            a_op[s] = __builtin_bit_cast(h8, make_uint4(lo.x, lo.y, hi.x, hi.y));
-        }
-#endif
     };
     load_rows(0);
-#if NCC_APF
     fetch_ops(0);
-#endif
     for (int t0 = 0; t0 < nsteps; t0 += NT) {
 #pragma unroll
         for (int u = 0; u < NT; ++u) {                   // u = ring slot of step t: a constant of this copy of the body
             const int t = t0 + u;
             if (t >= nsteps) break;                      // uniform
-#if !NCC_APF
-            fetch_ops(t);
-#endif
             // ---- horizontal tile t, and next to it the part of the vertical product that does not need it ----
             // The output tile of this step sums ring tiles t - NT + 1 .. t, oldest first (slots B, B + 1, ...).  All but the
             // last k-step's rows are in the ring since the previous steps: their operands are read and multiplied HERE, as a
@@ -657,8 +585,8 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
             // step.  Same products in the same order: G is bit for bit what the one-chain form gave.
             constexpr int dummy_nt = NT;                 // (u + 1) % NT below is a constant after unrolling
             const int B = (u + 1) % dummy_nt;
-            constexpr int NKE = NCC_EARLYV ? (RING - 16) / 32 : 0;          // float16 k-steps clear of the newest 16 rows
-            constexpr int NK8E = NCC_EARLYV ? (RING - 16) / 64 : 0;         // int8 k-steps (64 rows) clear of them
+            constexpr int NKE = (RING - 16) / 32;          // float16 k-steps clear of the newest 16 rows
+            constexpr int NK8E = (RING - 16) / 64;         // int8 k-steps (64 rows) clear of them
             f4 G = {0, 0, 0, 0};
             i4 C = {0, 0, 0, 0};
             auto vert_f16 = [&](int s) {
@@ -698,19 +626,16 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                     ac = __builtin_amdgcn_mfma_f32_16x16x32_f16(a_op[s], one[s], ac, 0, 0, 0);
                 }
             }
-#if NCC_APF
             // The next tile's operands, into the registers this tile's just left: the wait for its rows (loaded a step
             // ago), the table lookups and their LDS round trip run under this step's conversion, vertical products and
             // decision instead of at the top of the next step, in front of its first matrix instruction.
             fetch_ops(t + 1);
-#endif
             {
                 // hi = the float32 cut to float16's 10 mantissa bits (round toward zero; exact in float16: 0.25 <= h <= 1024),
                 // lo = the rest (h - hi is exact in float32), rounded to float16 by the mixed-precision fma that takes hi
                 // as the float16 it is; the count (an integer <= l) goes to the ring as a byte
                 typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
                 typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
-#if NCC_CONV == 0
                 const hf2 h01 = __builtin_bit_cast(hf2, (hp2)__builtin_amdgcn_cvt_pkrtz(ah[0], ah[1]));
                 const hf2 h23 = __builtin_bit_cast(hf2, (hp2)__builtin_amdgcn_cvt_pkrtz(ah[2], ah[3]));
                 const h4 vh = {h01[0], h01[1], h23[0], h23[1]};
@@ -723,15 +648,6 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(ah[2]));
                 asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(ah[3]));
                 const h4 vl = {l01[0], l01[1], l23[0], l23[1]};
-#else
-                h4 vh, vl;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float hi_f = __uint_as_float(__float_as_uint(ah[r]) & 0xFFFFE000u);
-                    vh[r] = (_Float16)hi_f;
-                    vl[r] = (_Float16)(ah[r] - hi_f);
-                }
-#endif
                 u32 vc = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_cvt_pk_u8_f32(ac[r], r, vc);
@@ -873,7 +789,6 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 }
             }
             if (dbg == 1) { asm volatile("" :: "s"(pw[0]), "s"(pw[1]), "s"(pw[2]), "s"(pw[3])); continue; }
-#if NCC_STORE == 0
             {
                 u32 xv = 0;                              // (lanes 8.. are never stored)
 #pragma unroll
@@ -884,19 +799,6 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                 pend_x = xv;
                 pend_yo = yo;
             }
-#else
-            {
-                const u32 sel1 = 0u - ((u32)lane & 1u), sel2 = 0u - (((u32)lane >> 1) & 1u);
-                const u32 x01l = (u32)pw[0] ^ (u32)pw[1], x01h = (u32)(pw[0] >> 32) ^ (u32)(pw[1] >> 32);
-                const u32 x23l = (u32)pw[2] ^ (u32)pw[3], x23h = (u32)(pw[2] >> 32) ^ (u32)(pw[3] >> 32);
-                const u32 t0l = (x01l & sel1) ^ (u32)pw[0], t0h = (x01h & sel1) ^ (u32)(pw[0] >> 32);
-                const u32 t1l = (x23l & sel1) ^ (u32)pw[2], t1h = (x23h & sel1) ^ (u32)(pw[2] >> 32);
-                const u32 vl = ((t0l ^ t1l) & sel2) ^ t0l, vh = ((t0h ^ t1h) & sel2) ^ t0h;
-                const int y = yo + lane;
-                pend_x = (lane & 8 ? vh : vl) >> (16 * ((lane >> 2) & 1));
-                pend_off1 = (lane < 16 && y < H) ? (u32)__mul24(y, 4 * WW) : 0xFFFFFFFFu;
-            }
-#endif
         }
         if (t0 + NT >= nsteps || ecnt > ECAP - NT) {     // uniform
             flush_pending();

@@ -334,6 +334,8 @@ class MarkerTracker:
         self._init_video()
         if self._frames is not None:
             data = self.process_frames(self._frames).blocks
+        elif hasattr(self.cap, "read_batch"):
+            data = self._process_decoding_ahead(int(self.config.get("batch", 64)))
         else:
             batch = int(self.config.get("batch", 64))
             data, buf = [], []
@@ -357,6 +359,34 @@ class MarkerTracker:
         self._save_results(data)
         self._cleanup()
 
+    def _process_decoding_ahead(self, batch):
+        """`process` on the package's own AVI reader (no OpenCV): batch k + 1 is decoded by the reader's thread pool into
+        the other of two page-locked buffers while batch k is uploaded, computed and turned into rows."""
+        from concurrent.futures import ThreadPoolExecutor
+        shape = (batch, self.height, self.width, 3)
+        try:
+            bufs = [pinned_frames(shape), pinned_frames(shape)]
+        except Exception:                                   # (no GPU runtime to pin with: ordinary memory)
+            bufs = [np.empty(shape, np.uint8), np.empty(shape, np.uint8)]
+        data, k = [], 0
+        with ThreadPoolExecutor(1) as ahead:
+            fut = ahead.submit(self.cap.read_batch, batch, bufs[0])
+            while True:
+                m = fut.result()
+                if not m:
+                    break
+                fut = ahead.submit(self.cap.read_batch, batch, bufs[(k + 1) & 1])
+                try:
+                    data.append(self._process_batch(bufs[k & 1][:m]))
+                except Exception:
+                    fut.cancel()
+                    if data:                               # the rows of the batches before the failing frame are kept
+                        self._save_results(data)
+                    self._cleanup()
+                    raise
+                k += 1
+        return data
+
     def process_frames(self, frames):
         """In-memory variant of `process`: frames uint8 [N,H,W(,3)] (NumPy or a torch device tensor)."""
         if not hasattr(self, "width"):
@@ -365,9 +395,9 @@ class MarkerTracker:
             self.crop_width, self.crop_height = right - left, bottom - top
         batch = int(self.config.get("batch", 256))
         data = []
-        for s in range(0, frames.shape[0], batch):
+        for part in _upload_ahead(frames, batch, self.config.get("device")):
             try:
-                data.append(self._process_batch(frames[s:s + batch]))
+                data.append(self._process_batch(part))
             except Exception as e:
                 e.rows = _Rows(data)                    # what the batches before the failing frame produced
                 if getattr(self, "_frames", None) is not None and data:
@@ -391,6 +421,18 @@ class MarkerTracker:
                 from ._lib import VbsError
                 raise VbsError(f"device status {n0} in frame 0")
             self._process_first_frame(_det_to_markers(det[0].cpu().numpy(), n0))
+            # f4: the same assignment on the device (vbs_assign_ids), checked against the host table that is kept (the
+            # reference's own order: the two may only differ in the order of markers at mathematically equal angles)
+            if self.config.get("kmeans", "optimal") == "optimal" and self.config.get("ids_on_device", True):
+                ids_h, xy_h = _ids.reference_arrays(self.first_frame_markers)
+                ids_d, xy_d = eng.assign_ids(det, counts, self.config.get("num_layers", 5),
+                                             self.config.get("id_mode", "as_written"))
+                ids_d, xy_d = ids_d.cpu().numpy().astype(np.int64), xy_d.cpu().numpy()
+                if ids_d.shape != np.asarray(ids_h).shape or not np.array_equal(ids_d, ids_h):
+                    from ._lib import VbsError
+                    raise VbsError("vbs_assign_ids disagrees with the host assignment on the marker IDs of frame 0")
+                self.ids_device_check = {"equal_to_host": bool(np.array_equal(xy_d, xy_h)),
+                                         "slots_in_another_order": int((xy_d != np.asarray(xy_h)).any(axis=1).sum())}
         ids, ref_xy = _ids.reference_arrays(self.first_frame_markers)
         table, det, counts = eng.track_to_3d(ft, ref_xy, self.config.get("min_marker_distance", 20),
                                              want_det=True)
@@ -403,7 +445,7 @@ class MarkerTracker:
                            f"{status_text(int(counts[bad]), eng.max_markers)}; rows of the batches before it are kept "
                            f"(`.rows` of this exception / the partial CSV)")
         table = table.cpu().numpy()
-        det = det.cpu().numpy()                 # float64 rows: the CSV keeps the reference's precision
+        det = det[:, :max(int(counts.max()), 1)].cpu().numpy()      # float64 rows in use: the CSV keeps the reference's precision
         # all rows of the batch at once: (frame, slot) pairs in frame-major, reference-dict order
         fi, si = np.nonzero(table[:, :, 0].astype(np.int64) & 1)
         d = det[fi, table[fi, si, 9].astype(np.int64)]
@@ -435,6 +477,56 @@ class MarkerTracker:
     def _cleanup(self):
         if getattr(self, "cap", None) is not None:
             self.cap.release()
+
+
+def pinned_frames(shape):
+    """A uint8 NumPy array in page-locked host memory (decode / read frames into it): `process_frames` then uploads batch
+    k + 1 by DMA on a copy stream while batch k computes and its rows are built.  Pageable arrays work as before (their
+    upload is a staged, synchronous copy)."""
+    import torch
+    return torch.empty(tuple(shape), dtype=torch.uint8, pin_memory=True).numpy()
+
+
+def _upload_ahead(frames, batch, device=None):
+    """Batches of `frames` as the tracker wants them.  NumPy frames with a GPU present: two device buffers and a copy
+    stream; the upload of batch k + 1 is enqueued BEFORE batch k is handed out, so it runs under batch k's kernels, the
+    download of its tables and the row building on the host (`_process_batch` blocks on its own results, which also means
+    the buffer of batch k - 1 is free again by the time batch k + 1 is written into it).  From page-locked memory
+    (`pinned_frames`) that upload is an asynchronous DMA at PCIe speed; from pageable memory the runtime stages it."""
+    n = int(frames.shape[0])
+    try:
+        import torch
+        gpu = isinstance(frames, np.ndarray) and frames.dtype == np.uint8 and torch.cuda.is_available() and n > batch
+    except ImportError:
+        gpu = False
+    if not gpu:
+        for s in range(0, n, batch):
+            yield frames[s:s + batch]
+        return
+    dev = torch.device("cuda", torch.cuda.current_device() if device is None else
+                       (device if isinstance(device, int) else torch.device(device).index or 0))
+    host = torch.from_numpy(np.ascontiguousarray(frames))
+    bufs = [torch.empty((min(batch, n),) + tuple(host.shape[1:]), dtype=torch.uint8, device=dev) for _ in range(2)]
+    copy = torch.cuda.Stream(device=dev)
+    done = [None, None]
+
+    def start(k):
+        s = k * batch
+        m = min(batch, n - s)
+        with torch.cuda.stream(copy):
+            bufs[k & 1][:m].copy_(host[s:s + m], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(copy)
+        done[k & 1] = (ev, m)
+
+    nb = (n + batch - 1) // batch
+    start(0)
+    for k in range(nb):
+        ev, m = done[k & 1]
+        if k + 1 < nb:
+            start(k + 1)
+        torch.cuda.current_stream(dev).wait_event(ev)
+        yield bufs[k & 1][:m]
 
 
 # Names `tracking.py:7` imports (absent from the published module, SURVEY.md §2.3)

@@ -27,21 +27,40 @@ class TrackResult:
     counts: Optional[torch.Tensor] = None   # [n_local] int32 detections per frame of this rank (never negative here)
 
 
+ID_CHECK = {}                  # what the last reference_from_frame0 found (bench.py reports it)
+
+
 def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mode="full", kmeans="optimal",
-                          ids_on_device=False):
-    """Detect frame 0 on the device and assign the identities (once per video).  `ids_on_device` runs the assignment
-    on the GPU as well (`vbs_assign_ids`, deterministic clustering only); it equals the host result except that
-    markers at mathematically equal angles (collinear with the centre) are ordered by the device's atan2 instead of
-    libm's, whose last bit decides such ties on the host."""
+                          ids_on_device=True):
+    """Detect frame 0 on the device and assign the identities (once per video, `marker_detection.py:275-347`).
+    `ids_on_device` (default) runs the assignment on the GPU (`vbs_assign_ids`, deterministic clustering only) WITH THE HOST
+    ASSIGNMENT AS ITS CHECKER: the host restatement (`ids.assign_ids`, pinned to the reference body's golden) runs on the
+    same detections, and what is returned is always the host's table - the reference's own order.  The two differ at most
+    among markers whose angles are mathematically equal (collinear with the centre), which np.arctan2's last bit orders
+    on the host and the device's atan2 on the GPU; `ID_CHECK` says whether they agreed and in how many slots not."""
     _, det, counts = eng.track_to_3d(frame0[:1], None, want_det=True)
+    dev = None
     if ids_on_device and kmeans == "optimal":
-        ids, xy = eng.assign_ids(det, counts, num_layers, id_mode)
-        return ids.cpu().numpy().astype("int64"), xy.cpu().numpy()
+        ids_d, xy_d = eng.assign_ids(det, counts, num_layers, id_mode)      # raises the reference's ValueError on no markers
+        dev = (ids_d.cpu().numpy().astype("int64"), xy_d.cpu().numpy())
     n0 = int(counts[0].item())
     if n0 < 0:
-        raise L.VbsError(f"device status {n0} in frame 0")
+        raise L.VbsError(f"device status {n0} in frame 0: {L.status_text(n0, eng.max_markers)}")
     table = _ids.assign_ids(_det_to_markers(det[0].cpu().numpy(), n0), num_layers, id_mode, kmeans)
-    return _ids.reference_arrays(table)
+    ids, xy = _ids.reference_arrays(table)
+    ID_CHECK.clear()
+    ID_CHECK.update({"on_device": dev is not None})
+    if dev is not None:
+        same_ids = dev[0].shape == np.asarray(ids).shape and bool(np.array_equal(dev[0], ids))
+        if not same_ids:
+            raise L.VbsError("vbs_assign_ids disagrees with the host assignment on the marker IDs (not only on the order of "
+                             "markers at equal angles): the device path must not be trusted on this frame 0")
+        differ = int((dev[1] != np.asarray(xy)).any(axis=1).sum())
+        # a slot may only differ by holding ANOTHER marker of the same layer (a swap among equal angles)
+        if differ and sorted(map(tuple, dev[1].tolist())) != sorted(map(tuple, np.asarray(xy).tolist())):
+            raise L.VbsError("vbs_assign_ids returned reference coordinates the host assignment does not have")
+        ID_CHECK.update({"equal_to_host": differ == 0, "slots_in_another_order": differ, "markers": int(len(ids))})
+    return ids, xy
 
 
 def track_and_gather(eng: Engine, frames_local: torch.Tensor, n_total: int, xy, min_dist=20.0, cam=None,
@@ -92,7 +111,8 @@ def track_shard(eng: Engine, frames_local: torch.Tensor, n_total: int, ref=None,
     if bad.numel():
         f = int(bad[0].item())
         raise L.VbsError(f"device status {int(counts[f].item())} in frame {D.shard_bounds(n_total, ws, rank)[0] + f} "
-                         f"(capacity exceeded): the reference would have emitted rows for it")
+                         f"({L.status_text(int(counts[f].item()), eng.max_markers)}): the reference would have emitted rows "
+                         f"for it")
     a, b = D.shard_bounds(n_total, ws, rank)
     disp = plane = None
     if cam is not None:

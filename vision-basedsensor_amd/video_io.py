@@ -118,7 +118,55 @@ class AviReader:
             return True, np.ascontiguousarray(np.repeat(g[:, :, None], 3, axis=2))
         return False, None
 
+    def _decode_into(self, index: int, dst: np.ndarray):
+        """frame `index` -> dst [H,W,3] BGR (any memory, e.g. a row of a page-locked batch buffer)"""
+        off, size = self._frames[index]
+        data = self._buf[off:off + size]
+        if self._codec.upper() == b"MJPG":
+            from PIL import Image
+            im = Image.open(io.BytesIO(bytes(data)))
+            dst[...] = np.asarray(im.convert("RGB"))[:, :, ::-1]            # BGR like cv2
+            return
+        stride = (self.width * self._bits // 8 + 3) & ~3
+        rows = np.frombuffer(data, dtype=np.uint8, count=stride * self.height).reshape(self.height, stride)[::-1]
+        if self._bits == 24:
+            dst[...] = rows[:, :self.width * 3].reshape(self.height, self.width, 3)
+        elif self._bits == 8:
+            dst[...] = rows[:, :self.width, None]
+        else:
+            raise IOError(f"unsupported DIB depth {self._bits}")
+
+    def read_batch(self, n: int, out: np.ndarray | None = None, threads: int | None = None):
+        """The next up to `n` frames, decoded by a pool of threads (libjpeg runs outside the GIL) straight into `out`
+        [>= n, H, W, 3] - e.g. `marker_detection.pinned_frames`, from where the tracker uploads by DMA.  Returns the
+        number of frames decoded (0 at the end); without `out` returns (count, array).  Not part of cv2's interface:
+        `MarkerTracker.process` uses it when the capture object has it, to decode batch k + 1 while batch k computes."""
+        import os
+        from concurrent.futures import ThreadPoolExecutor
+        m = max(0, min(int(n), len(self._frames) - self._next)) if self._ok else 0
+        own = out is None
+        if own:
+            out = np.empty((m, self.height, self.width, 3), dtype=np.uint8)
+        if m:
+            first = self._next
+            self._next += m
+            workers = max(1, min(m, threads or min(16, os.cpu_count() or 1)))
+            if workers == 1:
+                for i in range(m):
+                    self._decode_into(first + i, out[i])
+            else:
+                pool = getattr(self, "_pool", None)
+                if pool is None or getattr(self, "_pool_workers", 0) != workers:
+                    pool = self._pool = ThreadPoolExecutor(workers)
+                    self._pool_workers = workers
+                list(pool.map(lambda i: self._decode_into(first + i, out[i]), range(m)))
+        return (m, out) if own else m
+
     def release(self):
+        pool = getattr(self, "_pool", None)
+        if pool is not None:
+            pool.shutdown(wait=False)
+            self._pool = None
         self._buf = memoryview(b"")
         self._frames = []
         self._ok = False
