@@ -59,6 +59,19 @@ STAGE = ("k_stage", "k_morph", "k_ccl_band", "k_ccl_open", "k_slow_list", "k_lab
          "k_finalize")
 
 
+def _newest(pattern):
+    """profiles/ files are named <round tag>_...: r1a < r1b < ... < r3pre < r3a < ... < r4a; the newest one matching."""
+    import re
+
+    def key(path):
+        m = re.match(r"r(\d+)([a-z]*)_", os.path.basename(path))
+        if not m:
+            return (-1, 0, "")
+        return (int(m.group(1)), 0 if m.group(2).startswith("pre") else 1, m.group(2))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=key)
+    return files[-1] if files else None
+
+
 def _cpu_worker(args):
     """Oracle over a few frames in one process (cpu_baseline leg only); the first `warm` frames are not timed."""
     import numpy as np
@@ -529,11 +542,11 @@ def main():
         alg_bytes_frame = H * W + 24 * M                                     # image read + moment sums
         achieved = alg_bytes_frame * fpl / (stage_ms_launch * 1e-3) / 1e9
         traffic = traffic_src = None
-        pm = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_pmc_traffic_{args.workload}.json")))
+        pm = _newest(f"*_pmc_traffic_{args.workload}.json")
         if pm:
-            pj = json.load(open(pm[-1]))
+            pj = json.load(open(pm))
             traffic = round(pj["traffic_bytes_per_frame"] * fpl)
-            traffic_src = os.path.basename(pm[-1])
+            traffic_src = os.path.basename(pm)
         result["roofline"] = {
             "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "traffic_source": traffic_src,
@@ -549,10 +562,10 @@ def main():
         #     after the band half's sums are out, `stop 10`); `opened_half_us_per_frame` is the rest of the live time.
         # (b) the stage reads 0.3 x its algorithmic bytes and is bound by vector-instruction issue: `valu` = the share of the
         #     SIMDs' cycles in which k_stage issues a vector instruction, from the newest committed SQ counters.
-        ph = sorted(glob.glob(os.path.join(ROOT, "profiles", f"*_stage_phase_timing_{args.workload}.log")))
+        ph = _newest(f"*_stage_phase_timing_{args.workload}.log")
         if ph:
             stops = {}
-            for line in open(ph[-1]):
+            for line in open(ph):
                 parts = line.split(None, 2)
                 if len(parts) == 3 and parts[0] == "stop":
                     try:
@@ -567,10 +580,10 @@ def main():
                     "what": "band + 4-connected labels + count / sum x / sum y per label: the SURVEY 8(d) stage proper",
                     "us_per_frame": band_us, "frac": round(alg_bytes_frame / (band_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
                     "opened_half_us_per_frame": round(max(live_us - band_us, 0.0), 3),
-                    "source": f"{os.path.basename(ph[-1])} (stop {pick}; debug library, batch 512, not measured in this run)"}
-        sqf = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters_stage.json")))
+                    "source": f"{os.path.basename(ph)} (stop {pick}; debug library, batch 512, not measured in this run)"}
+        sqf = _newest("*_sq_counters_stage.json")
         if sqf and args.workload == "c3":
-            sj = json.load(open(sqf[-1]))
+            sj = json.load(open(sqf))
             ks = sj.get("kernels", {}).get("k_stage", {})
             if ks.get("SQ_INSTS_VALU") and ks.get("GRBM_GUI_ACTIVE"):
                 cyc = 4.0 * ks["SQ_ACTIVE_INST_VALU"]                       # the counter is in quad-cycles
@@ -581,7 +594,7 @@ def main():
                     "cycles_per_instruction": round(cyc / ks["SQ_INSTS_VALU"], 2),
                     "simd_cycles_per_frame": round(avail / sj["frames_per_launch"]),
                     "frac": round(cyc / avail, 4), "waves_per_simd": 3,
-                    "source": f"{os.path.basename(sqf[-1])} (rocprofv3 --pmc passes over a {sj['frames_per_launch']}-frame launch, not this run)"}
+                    "source": f"{os.path.basename(sqf)} (rocprofv3 --pmc passes over a {sj['frames_per_launch']}-frame launch, not this run)"}
         # the staged entry on uint8 images (the reference's `_marker_center(mask, area_mask)` interface)
         if args.channels == 1 and not crop:
             mask, area = eng.find_markers(frames[:nk])

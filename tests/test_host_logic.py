@@ -465,3 +465,38 @@ def test_blur16_isa_check_accepts_the_layouts_and_names_the_hazards():
         p = check_blur16(_loader_asm(rotated=rot, touch_other=True))
         assert len(p) == 1 and "v_mov_b32_e32 v91, v4" in p[0] and "another set" in p[0]
     assert check_blur16("no kernels here\n") == ["no k_blur16 instantiation found in the assembly"]
+
+
+def test_bench_cpu_limits_and_profile_selection(tmp_path, monkeypatch):
+    """bench.py's measurement hygiene: the cgroup CPU quota / cpuset are parsed (v2 `cpu.max` and v1
+    `cfs_quota_us` forms), the parallel-CPU probe reports a sane figure and the worker count is the smallest limit; the
+    newest profiles/ file of a kind is chosen by round tag (r3pre < r3a < r3i < r4a), not by spelling."""
+    sys.path.insert(0, ROOT)
+    import bench
+    quota, cpuset = bench._cgroup_quota_cpus()
+    assert quota is None or quota > 0
+    assert cpuset is None or cpuset >= 1
+    pr = bench.probe_parallel_cpus(2, seconds=0.05)
+    assert pr["effective_cpus"] >= 0.5 and "1" in pr["rate_vs_one_process"]
+    # profile selection
+    prof = tmp_path / "profiles"
+    prof.mkdir()
+    for tag in ("r1a", "r3pre", "r3a", "r3i", "r4a", "r2b"):
+        (prof / f"{tag}_pmc_traffic_c3.json").write_text("{}")
+    (prof / "notes_pmc_traffic_c3.json").write_text("{}")
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert os.path.basename(bench._newest("*_pmc_traffic_c3.json")) == "r4a_pmc_traffic_c3.json"
+    os.remove(prof / "r4a_pmc_traffic_c3.json")
+    assert os.path.basename(bench._newest("*_pmc_traffic_c3.json")) == "r3i_pmc_traffic_c3.json"
+    os.remove(prof / "r3i_pmc_traffic_c3.json"); os.remove(prof / "r3a_pmc_traffic_c3.json")
+    assert os.path.basename(bench._newest("*_pmc_traffic_c3.json")) == "r3pre_pmc_traffic_c3.json"
+    assert bench._newest("*_nothing.json") is None
+
+
+def test_status_text_names_every_per_frame_status():
+    from vbs_amd import _lib as L
+    assert "workspace" in L.status_text(L.VBS_ECAPACITY, 512) and "512" in L.status_text(L.VBS_ECAPACITY, 512)
+    assert "hand-shake" in L.status_text(L.VBS_EINTERNAL)
+    assert L.VBS_EINTERNAL == -5
+    hdr = open(os.path.join(ROOT, "include", "vbs.h")).read()
+    assert "#define VBS_EINTERNAL  -5" in hdr

@@ -32,3 +32,26 @@ for impl in (int(x) for x in os.environ.get('STAGE_IMPLS', '0').split(',')):
   print(f"one frame, call + synchronise: {dt * 1e6:.1f} us ({1 / dt:.0f} frames/s one at a time); tracked {int((table[..., 0].int() & 1).sum())} of {len(ids)}")
   print("stage impl", impl, {k: round(1e3 * v[1] / v[0], 1) for k, v in p.items()}, "us per launch")
   eng.profile(False)
+
+# the same call captured into a HIP graph once and replayed per frame (the frame copied into a fixed buffer first): what a
+# caller that feeds one frame at a time (marker_detection.py:434-453) can do about launch latency
+xy_d = torch.as_tensor(xy, dtype=torch.float64, device="cuda")
+buf = ft[:1].clone()
+eng.set_option(L.OPT_STAGE_IMPL, 0)
+eng.track_to_3d(buf, xy_d, 20.0, cam, 5.0); torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    with torch.cuda.graph(g, stream=side):
+        gtable, _, gcounts = eng.track_to_3d(buf, xy_d, 20.0, cam, 5.0)
+torch.cuda.current_stream().wait_stream(side)
+for i in range(5):
+    buf.copy_(ft[i % 8:i % 8 + 1]); g.replay()
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(reps):
+    buf.copy_(ft[i % 8:i % 8 + 1]); g.replay(); torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / reps
+want, _, _ = eng.track_to_3d(ft[(reps - 1) % 8:(reps - 1) % 8 + 1], xy_d, 20.0, cam, 5.0)
+torch.cuda.synchronize()
+print(f"one frame, copy into the graph's buffer + replay + synchronise: {dt * 1e6:.1f} us ({1 / dt:.0f} frames/s); equal to the eager call: {bool(torch.equal(want, gtable))}")

@@ -548,7 +548,7 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
             prow[k] = pval[k] ? id / B16_NP : 0;
             const int pc = pval[k] ? id - B16_NP * prow[k] : 0;
             poff[k] = (u32)(__mul24(prow[k], gstride_row) + X0 + 16 * pc);
-            pdst[k] = &stg[0][0] + B16_ROWB * prow[k] + (X0 - XB) + 16 * pc;
+            pdst[k] = &stg[0][0] + B16_ROWB * prow[k] + 16 * pc;      // (16-byte aligned; + X0 - XB where the origin is shifted)
         }
         u32x4 R[B16_LD][4];
 #pragma unroll
@@ -599,10 +599,11 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                     u8* dst = pdst[k] + sb;
                     const uint4 v = make_uint4(R[j][k].x ^ 0x80808080u, R[j][k].y ^ 0x80808080u,
                                                R[j][k].z ^ 0x80808080u, R[j][k].w ^ 0x80808080u);
-                    if (X0 == XB) {                      // (uniform)
-                        if (pval[k]) *reinterpret_cast<uint4*>(dst) = v;
+                    if (X0 == XB) {                      // (uniform) one 16-byte store: the pointer must be KNOWN to be aligned,
+                        // or the compiler splits it into 12 + 4 bytes and the loader falls behind the strips (+20 % on the kernel)
+                        if (pval[k]) *reinterpret_cast<uint4*>(__builtin_assume_aligned(dst, 16)) = v;
                     } else if (pval[k]) {                // the shifted origin: 4-byte aligned pieces
-                        u32* d32 = reinterpret_cast<u32*>(dst);
+                        u32* d32 = reinterpret_cast<u32*>(dst + (X0 - XB));
                         d32[0] = v.x; d32[1] = v.y; d32[2] = v.z; d32[3] = v.w;
                     }
                 }
@@ -679,81 +680,9 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                 mb16[(u32)__mul24(y, 4 * WW)] = (unsigned short)(pp[k >> 1] >> (16 * (k & 1)));
         }
     };
-    uint4 aP_ = make_uint4(0, 0, 0, 0), aQ_;
-    read_ops(aP_, aQ_);                                  // tile 0
-    for (int t0 = 0; t0 < nsteps; t0 += 8) {
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {                    // u = ring slot of step t: a constant of this copy of the body
-            const int t = t0 + u;
-            if (t >= nsteps) break;                      // uniform
-            const v4i aP = v4i{(int)aP_.x, (int)aP_.y, (int)aP_.z, (int)aP_.w}, aQ = v4i{(int)aQ_.x, (int)aQ_.y, (int)aQ_.z, (int)aQ_.w};
-            v4i d8 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
-            int yo;
-            if (!SB) {
-            // this step's vertical fragments, asked for here and used after the horizontal products
-            const uint4 fa_ = vf[u * 64 + lane], fb_ = vf[((u + 4) & 7) * 64 + lane], fs_ = vf[(8 + (u & 3)) * 64 + lane];
-            // ---- horizontal tile t ----
-            v4i accL = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
-            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aP, lp, accL, 0, 0, 0);
-            accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, sq, accS, 0, 0, 0);
-            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, lq, accL, 0, 0, 0);
-            if (edge) accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aP, sp, accS, 0, 0, 0);
-            // behind the products: tile t's slot is free (its operands have been multiplied), tile t + 1 into next step's operands
-            tick_done();
-            if (t + 1 < nsteps) read_ops(aP_, aQ_);
-            {
-                int hi, lo;
-                pack16(accL, hi, lo);
-                if (u < 4) { LhA[u & 3] = hi; LlA[u & 3] = lo; } else { LhB[u & 3] = hi; LlB[u & 3] = lo; }
-                pack16(accS, hi, lo);
-                Sdh[u & 3] = hi; Sdl[u & 3] = lo;
-                S4h[(u + 2) & 3] = Sdh[(u + 2) & 3];     // tile t - 2 (zeros for t < 2) takes the place of tile t - 6
-                S4l[(u + 2) & 3] = Sdl[(u + 2) & 3];
-            }
-            if (t < DEPTH) { if (u == 7) flush_rows(t0); continue; }
-            // ---- vertical: output rows yo .. yo + 15, lane (g, q) gets rows yo + 4 g + i of column xw + q ----
-            yo = Y0 + 16 * (t - DEPTH);
-            const v4i fa = v4i{(int)fa_.x, (int)fa_.y, (int)fa_.z, (int)fa_.w}, fb = v4i{(int)fb_.x, (int)fb_.y, (int)fb_.z, (int)fb_.w};
-            const v4i fs = v4i{(int)fs_.x, (int)fs_.y, (int)fs_.z, (int)fs_.w};
-            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LhA, d8, 0, 0, 0);
-            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4h, d3, 0, 0, 0);
-            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, LhB, d8, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d3[i] = (d3[i] << 8) + k3;
-            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4l, d3, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d8[i] = (d8[i] << 8) + k8;
-            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LlA, d8, 0, 0, 0);
-            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, LlB, d8, 0, 0, 0);
-            } else {
-            // small branch: one window operand, both kernels over the same four tiles (ring slot u & 3; LhA / LlA hold the
-            // 35-tap kernel's byte planes, S4h / S4l the 21-tap kernel's)
-            const uint4 fa_ = vf[(u & 3) * 64 + lane], fs_ = vf[(4 + (u & 3)) * 64 + lane];
-            v4i accL = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
-            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, lq, accL, 0, 0, 0);
-            accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, sq, accS, 0, 0, 0);
-            tick_done();
-            if (t + 1 < nsteps) read_ops(aP_, aQ_);
-            {
-                int hi, lo;
-                pack16(accL, hi, lo);
-                LhA[u & 3] = hi; LlA[u & 3] = lo;
-                pack16(accS, hi, lo);
-                S4h[u & 3] = hi; S4l[u & 3] = lo;
-            }
-            if (t < DEPTH) { if (u == 7) flush_rows(t0); continue; }
-            yo = Y0 + 16 * (t - DEPTH);
-            const v4i fa = v4i{(int)fa_.x, (int)fa_.y, (int)fa_.z, (int)fa_.w}, fs = v4i{(int)fs_.x, (int)fs_.y, (int)fs_.z, (int)fs_.w};
-            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LhA, d8, 0, 0, 0);
-            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4h, d3, 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d8[i] = (d8[i] << 8) + k8;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) d3[i] = (d3[i] << 8) + k3;
-            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LlA, d8, 0, 0, 0);
-            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4l, d3, 0, 0, 0);
-            }
-            {
+    // range test of a finished tile (d8 / d3: the two blurs' vertical results, rows yo + 4 g + i of column xw + q) and its
+    // 16-bit mask pieces into pp[] (slot u of the eight-step group)
+    auto finish_tile = [&](const v4i& d8, const v4i& d3, int yo, int u) {
             u64 pw[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
@@ -781,6 +710,82 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                 const u32 vl = ((t0l ^ t1l) & sel2) ^ t0l, vh = ((t0h ^ t1h) & sel2) ^ t0h;
                 const u32 piece = ((lane & 8 ? vh : vl) >> (16 * ((lane >> 2) & 1))) & 0xFFFFu;
                 pp[u >> 1] = (u & 1) ? (pp[u >> 1] | (piece << 16)) : piece;
+            }
+    };
+    uint4 aP_ = make_uint4(0, 0, 0, 0), aQ_;
+    read_ops(aP_, aQ_);                                  // tile 0
+    for (int t0 = 0; t0 < nsteps; t0 += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {                    // u = ring slot of step t: a constant of this copy of the body
+            const int t = t0 + u;
+            if (t >= nsteps) break;                      // uniform
+            const v4i aP = v4i{(int)aP_.x, (int)aP_.y, (int)aP_.z, (int)aP_.w}, aQ = v4i{(int)aQ_.x, (int)aQ_.y, (int)aQ_.z, (int)aQ_.w};
+            if (!SB) {
+            // this step's vertical fragments, asked for here and used after the horizontal products
+            const uint4 fa_ = vf[u * 64 + lane], fb_ = vf[((u + 4) & 7) * 64 + lane], fs_ = vf[(8 + (u & 3)) * 64 + lane];
+            // ---- horizontal tile t ----
+            v4i accL = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
+            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aP, lp, accL, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, sq, accS, 0, 0, 0);
+            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, lq, accL, 0, 0, 0);
+            if (edge) accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aP, sp, accS, 0, 0, 0);
+            // behind the products: tile t's slot is free (its operands have been multiplied), tile t + 1 into next step's operands
+            tick_done();
+            if (t + 1 < nsteps) read_ops(aP_, aQ_);
+            {
+                int hi, lo;
+                pack16(accL, hi, lo);
+                if (u < 4) { LhA[u & 3] = hi; LlA[u & 3] = lo; } else { LhB[u & 3] = hi; LlB[u & 3] = lo; }
+                pack16(accS, hi, lo);
+                Sdh[u & 3] = hi; Sdl[u & 3] = lo;
+                S4h[(u + 2) & 3] = Sdh[(u + 2) & 3];     // tile t - 2 (zeros for t < 2) takes the place of tile t - 6
+                S4l[(u + 2) & 3] = Sdl[(u + 2) & 3];
+            }
+            if (t >= DEPTH) {
+            // ---- vertical: output rows yo .. yo + 15, lane (g, q) gets rows yo + 4 g + i of column xw + q ----
+            const v4i fa = v4i{(int)fa_.x, (int)fa_.y, (int)fa_.z, (int)fa_.w}, fb = v4i{(int)fb_.x, (int)fb_.y, (int)fb_.z, (int)fb_.w};
+            const v4i fs = v4i{(int)fs_.x, (int)fs_.y, (int)fs_.z, (int)fs_.w};
+            v4i d8 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LhA, d8, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4h, d3, 0, 0, 0);
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, LhB, d8, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d3[i] = (d3[i] << 8) + k3;
+            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4l, d3, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d8[i] = (d8[i] << 8) + k8;
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LlA, d8, 0, 0, 0);
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fb, LlB, d8, 0, 0, 0);
+            finish_tile(d8, d3, Y0 + 16 * (t - DEPTH), u);
+            }
+            } else {
+            // small branch: one window operand, both kernels over the same four tiles (ring slot u & 3; LhA / LlA hold the
+            // 35-tap kernel's byte planes, S4h / S4l the 21-tap kernel's)
+            const uint4 fa_ = vf[(u & 3) * 64 + lane], fs_ = vf[(4 + (u & 3)) * 64 + lane];
+            v4i accL = {0, 0, 0, 0}, accS = {0, 0, 0, 0};
+            accL = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, lq, accL, 0, 0, 0);
+            accS = __builtin_amdgcn_mfma_i32_16x16x64_i8(aQ, sq, accS, 0, 0, 0);
+            tick_done();
+            if (t + 1 < nsteps) read_ops(aP_, aQ_);
+            {
+                int hi, lo;
+                pack16(accL, hi, lo);
+                LhA[u & 3] = hi; LlA[u & 3] = lo;
+                pack16(accS, hi, lo);
+                S4h[u & 3] = hi; S4l[u & 3] = lo;
+            }
+            if (t >= DEPTH) {
+            const v4i fa = v4i{(int)fa_.x, (int)fa_.y, (int)fa_.z, (int)fa_.w}, fs = v4i{(int)fs_.x, (int)fs_.y, (int)fs_.z, (int)fs_.w};
+            v4i d8 = {0, 0, 0, 0}, d3 = {0, 0, 0, 0};
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LhA, d8, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4h, d3, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d8[i] = (d8[i] << 8) + k8;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) d3[i] = (d3[i] << 8) + k3;
+            d8 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fa, LlA, d8, 0, 0, 0);
+            d3 = __builtin_amdgcn_mfma_i32_16x16x64_i8(fs, S4l, d3, 0, 0, 0);
+            finish_tile(d8, d3, Y0 + 16 * (t - DEPTH), u);
             }
             }
             if (u == 7) flush_rows(t0);

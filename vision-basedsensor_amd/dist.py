@@ -78,8 +78,10 @@ class TableGather:
     the chunk).  Every pass is ONE `all_gather_into_tensor` into its own staging tensor [world x width, M, C] (each rank
     pads its rows of the pass to the widest rank's, so ragged shards take the same collective); `finish` waits and copies
     every rank's rows into its frames' rows of the final [n_total, M, C] tensor.  No tensor-list outputs: nothing relies on
-    how a backend flattens and copies them.  NOTE: this branch has run under gloo (CPU tensors, 2 ranks) and, through host
-    copies, with two ranks sharing one GPU; it has not yet run under RCCL on several GPUs (no multi-GPU box in this build).
+    how a backend flattens and copies them.  NOTE: this branch has run under gloo (CPU tensors, 2 and 8 ranks, ragged
+    shards) and, through host copies, with two ranks sharing one GPU; it has NOT yet run under RCCL on several GPUs (no
+    multi-GPU box in this build): unverified there until the driver's scaling run, which checks itself (bench.py: the
+    gathered table's checksum is compared across ranks; `--pipelined 0` falls back to the single collective).
 
         g = TableGather(n_total, M, C, device, chunk)
         for off in range(0, g.n_max, chunk):
@@ -116,9 +118,23 @@ class TableGather:
             td.all_gather_into_tensor(stage, src.cpu())
             self._scatter(stage.to(self.out.device), off, cnt)
             return
+        self._reap()                                    # passes whose exchange has finished give their staging tensor back
         stage = torch.empty((self.ws * width,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device)       # rank-major
         work = td.all_gather_into_tensor(stage, src, async_op=True)
         self.pending.append((work, stage, src, off, cnt))
+
+    def _reap(self):
+        """Copy the rows of every pass whose collective has completed into place and drop its staging tensor, so that the
+        staging memory in flight stays at the few passes the exchange lags behind, not a second copy of the whole table."""
+        keep = []
+        for item in self.pending:
+            work, stage, _src, off, cnt = item
+            if work.is_completed():
+                work.wait()                             # (orders the copy below behind the collective on this stream)
+                self._scatter(stage, off, cnt)
+            else:
+                keep.append(item)
+        self.pending = keep
 
     def _scatter(self, stage, off, cnt):
         width = stage.shape[0] // self.ws
