@@ -451,12 +451,11 @@ def main():
     table_sums = None
     if world > 1:
         # the same gathered table on every rank: (sum, xor-fold) of its bits, exchanged and compared everywhere
-        bits = table.contiguous().view(torch.int32).to(torch.int64)
-        folded = bits.view(-1, M * 10)
-        x = folded[:, 0].clone()
-        for c in range(1, folded.shape[1]):
-            x ^= folded[:, c] * (c + 1)
-        mine = torch.stack([bits.sum(), x.sum()]).to(dev if args.backend != "gloo" else "cpu")
+        bits = table.contiguous().view(torch.int32).to(torch.int64).view(-1, M * 10)
+        wcol = torch.arange(1, M * 10 + 1, dtype=torch.int64, device=bits.device)
+        wrow = torch.arange(1, bits.shape[0] + 1, dtype=torch.int64, device=bits.device)
+        # (int64 arithmetic wraps: a position-weighted sum, so that two tables with the same rows in another order differ)
+        mine = torch.stack([bits.sum(), ((bits * wcol).sum(dim=1) * wrow).sum()]).to(dev if args.backend != "gloo" else "cpu")
         allsums = [torch.zeros_like(mine) for _ in range(world)]
         td.all_gather(allsums, mine)
         table_sums = [[int(v) for v in t.tolist()] for t in allsums]

@@ -468,7 +468,7 @@ __device__ __forceinline__ void pack16(const v4i& acc, int& hi, int& lo) {
     hi = (int)__builtin_amdgcn_perm(t23, t01, 0x07060302u);
 }
 
-template <bool U8OUT, bool SB>
+template <bool U8OUT, bool SB, bool SHIFT>               // SHIFT: widths that are 4 (mod 8) - the last workgroup's shifted origin
 __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __restrict__ gray, int64_t gstride_n, int gstride_row,
                                                    const uint4* __restrict__ hfrag, const uint4* __restrict__ vfrag,
                                                    u64* __restrict__ bits, u8* __restrict__ area_u8,
@@ -520,7 +520,7 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
     }
     const u8* gf = gray + (int64_t)n * gstride_n;        // (uniform)
     const int X0 = min(max(16 * B16_NSW * bx - G::WG_LEFT, 0), W - 16 * B16_NP);   // the workgroup's window [X0, X0 + 16 NP): inside the row
-    const int XB = X0 & ~7;                              // origin of the staged rows (see "widths that are a multiple of 4" above)
+    const int XB = SHIFT ? (X0 & ~7) : X0;               // origin of the staged rows (see "widths that are a multiple of 4" above)
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     __builtin_amdgcn_s_waitcnt(0x0F70);                  // operand fragments landed (see k_blur_mfma)
     if (tid < B16_NS) done[tid] = 0;
@@ -599,8 +599,11 @@ __global__ __launch_bounds__(64 * (B16_NSW + 1), 4) void k_blur16(const u8* __re
                     u8* dst = pdst[k] + sb;
                     const uint4 v = make_uint4(R[j][k].x ^ 0x80808080u, R[j][k].y ^ 0x80808080u,
                                                R[j][k].z ^ 0x80808080u, R[j][k].w ^ 0x80808080u);
-                    if (X0 == XB) {                      // (uniform) one 16-byte store: the pointer must be KNOWN to be aligned,
-                        // or the compiler splits it into 12 + 4 bytes and the loader falls behind the strips (+20 % on the kernel)
+                    // (The loader is as heavy as a strip and sits on the kernel's critical path: every instruction added per
+                    //  tile shows.  Widths that are a multiple of 8 - SHIFT = false - compile to the four plain 16-byte stores;
+                    //  the pointer must be KNOWN to be aligned, or the compiler splits each store into 12 + 4 bytes: +20 %
+                    //  on the kernel, and a run-time test per piece cost +17 %.)
+                    if (!SHIFT || X0 == XB) {            // (uniform)
                         if (pval[k]) *reinterpret_cast<uint4*>(__builtin_assume_aligned(dst, 16)) = v;
                     } else if (pval[k]) {                // the shifted origin: 4-byte aligned pieces
                         u32* d32 = reinterpret_cast<u32*>(dst + (X0 - XB));
@@ -885,12 +888,14 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
         // many frames: a 1-D grid that the kernel maps to (frame, strip group, segment) with a frame's workgroups on one XCD
         const int xcd = nb >= 32 ? nb : 0;
         dim3 grid16 = xcd ? dim3((unsigned)((nb + 7) / 8 * 8 * gx16 * nseg)) : dim3(gx16, nseg, nb);
-#define B16_GO(U8, SB_)                                                                                                       \
-    VBS_LAUNCH(h, s, "k_blur16", (k_blur16<U8, SB_>), grid16, dim3(64 * (B16_NSW + 1)), 0, s, gray, gstride_n, (int)gstride_row, \
-               h->blur16_h, h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8,                       \
+#define B16_GO(U8, SB_, SH_)                                                                                                  \
+    VBS_LAUNCH(h, s, "k_blur16", (k_blur16<U8, SB_, SH_>), grid16, dim3(64 * (B16_NSW + 1)), 0, s, gray, gstride_n,              \
+               (int)gstride_row, h->blur16_h, h->blur16_v, h->area_bits, area_u8, h->fstat, h->H, h->W, h->WW, tps, k3, k8,     \
                h->bp.hi - h->bp.thresh, xcd, gx16, nseg, VBS_KNOB("VBS_BLUR16_DROP"))
-        if (h->bp.small) { if (area_u8) B16_GO(true, true); else B16_GO(false, true); }
-        else { if (area_u8) B16_GO(true, false); else B16_GO(false, false); }
+#define B16_GO2(U8, SB_) do { if (h->W & 7) B16_GO(U8, SB_, true); else B16_GO(U8, SB_, false); } while (0)
+        if (h->bp.small) { if (area_u8) B16_GO2(true, true); else B16_GO2(false, true); }
+        else { if (area_u8) B16_GO2(true, false); else B16_GO2(false, false); }
+#undef B16_GO2
 #undef B16_GO
         return;
     }
