@@ -631,23 +631,17 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
             // decision instead of at the top of the next step, in front of its first matrix instruction.
             fetch_ops(t + 1);
             {
-                // hi = the float32 cut to float16's 10 mantissa bits (round toward zero; exact in float16: 0.25 <= h <= 1024),
-                // lo = the rest (h - hi is exact in float32), rounded to float16 by the mixed-precision fma that takes hi
-                // as the float16 it is; the count (an integer <= l) goes to the ring as a byte
-                typedef __fp16 hp2 __attribute__((ext_vector_type(2)));
-                typedef _Float16 hf2 __attribute__((ext_vector_type(2)));
-                const hf2 h01 = __builtin_bit_cast(hf2, (hp2)__builtin_amdgcn_cvt_pkrtz(ah[0], ah[1]));
-                const hf2 h23 = __builtin_bit_cast(hf2, (hp2)__builtin_amdgcn_cvt_pkrtz(ah[2], ah[3]));
-                const h4 vh = {h01[0], h01[1], h23[0], h23[1]};
-                // (v_fma_mix* as inline assembly: the compiler only selects them with float32 denormals flushed.  Each reads
-                //  the cvt_pkrtz result of its own accumulator pair, so it is ordered behind a compiler-made instruction
-                //  that already waited out the matrix instruction's write of all four registers.)
-                hf2 l01, l23;
-                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l01) : "v"(h01), "v"(ah[0]));
-                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l01) : "v"(h01), "v"(ah[1]));
-                asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l23) : "v"(h23), "v"(ah[2]));
-                asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l23) : "v"(h23), "v"(ah[3]));
-                const h4 vl = {l01[0], l01[1], l23[0], l23[1]};
+                // hi = the float32 cut to float16's 10 mantissa bits (exact in float16: 0.25 <= h <= 1024), lo = the rest
+                // (h - hi is exact in float32), rounded to float16; the count (an integer <= l) goes to the ring as a byte
+                // (v_cvt_pkrtz + v_fma_mixlo/hi would be 6 instructions instead of these 12, and was built: no faster - a
+                //  v_fma_mix costs 3 x a v_fma on this chip, tools/ubench_valu.hip - and it needed inline assembly)
+                h4 vh, vl;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float hi_f = __uint_as_float(__float_as_uint(ah[r]) & 0xFFFFE000u);
+                    vh[r] = (_Float16)hi_f;
+                    vl[r] = (_Float16)(ah[r] - hi_f);
+                }
                 u32 vc = 0;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vc = __builtin_amdgcn_cvt_pk_u8_f32(ac[r], r, vc);
