@@ -10,11 +10,12 @@ from vbs_amd.engine import Engine
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 192
 rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 bad = 0
-for (h, w) in ((1024, 1280), (1200, 1920), (600, 808)):
+for (h, w) in ((1024, 1280), (1200, 1920), (600, 808), (450, 480), (480, 644), (1000, 1284)):      # large, small branch, widths 4 (mod 8)
     eng = Engine(h, w, max_markers=512, max_batch=n)
     for r in range(rounds):
         g = torch.Generator(device="cuda").manual_seed(1000 * r + h)
-        lo = torch.randn((n, 1, h // 24 + 2, w // 24 + 2), device="cuda", generator=g) * 55 + 100
+        cell = 24 if h > 480 else 9                     # (the small branch's blurs see nothing in the broad fields)
+        lo = torch.randn((n, 1, h // cell + 2, w // cell + 2), device="cuda", generator=g) * 55 + 100
         fr = torch.nn.functional.interpolate(lo, size=(h, w), mode="bicubic", align_corners=False)[:, 0]
         fr = (fr + torch.randn((n, h, w), device="cuda", generator=g) * 10).clamp(0, 255).to(torch.uint8).contiguous()
         out = {}
