@@ -92,7 +92,9 @@ int vbs_version(void);
  * call: allocations, copies, one device synchronisation; VBS_ENOMEM / VBS_EHIP if it cannot be built).  A handle left at
  * the default builds it at its first call that spans several passes; if that call's stream is being captured, or the
  * workspace cannot be built, the call runs every pass on the caller's stream instead.  (With vbs_profile on, passes run on
- * one stream: the per-kernel event timings would otherwise overlap.) */
+ * one stream: the per-kernel event timings would otherwise overlap.)  VBS_OPT_LATENCY_FRAMES (tuning, results identical):
+ * an internal pass of at most this many frames (default 4, at most 8; the reference calls process() with ONE,
+ * marker_detection.py:434-453) labels every frame with several workgroups (k_stage_lat) instead of one (k_stage); 0 = never. */
 #define VBS_OPT_GRAY_COEFFS      1
 #define VBS_OPT_FORCE_SEQ_MATCH  2
 #define VBS_OPT_GRAY_SIDE_STREAM 3
@@ -100,6 +102,7 @@ int vbs_version(void);
 #define VBS_OPT_STAGE_IMPL       5
 #define VBS_OPT_BLUR_IMPL        6
 #define VBS_OPT_PASS_STREAMS     7
+#define VBS_OPT_LATENCY_FRAMES   8
 int vbs_set_option(vbs_handle* h, int option, int value);
 /* host-only helper: the 256-entry table that classifies a border pixel's 8-neighbourhood into the
  * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain

@@ -969,6 +969,85 @@ def test_fused_stage_equals_separate_kernels():
         eng.close()
 
 
+def test_latency_stage_equals_the_batch_stage():
+    """A pass of a few frames labels every frame with SEVERAL workgroups (k_stage_lat: tiles of ~8 rows, the shared tables
+    in global memory, the last workgroup of a frame to arrive resolves it) instead of one (k_stage).  VBS_OPT_LATENCY_FRAMES = 8
+    against 0 on the same inputs: every per-component table, every detection row and every count identical - marker frames of
+    the three sizes one and several per call, crops, ragged blobs, and the adverse patterns (whatever either kernel cannot
+    take goes to the general kernel with the same result)."""
+    from vbs_amd.engine import Engine
+
+    def both(eng, run, n):
+        out = []
+        for lat in (8, 0):
+            eng.set_option(L.OPT_LATENCY_FRAMES, lat)
+            res = run()
+            torch.cuda.synchronize()
+            out.append((res, eng.stage_tables(n)))
+        eng.set_option(L.OPT_LATENCY_FRAMES, 4)
+        return out
+
+    def same_tables(t0, t1):
+        for i in range(t0["ncomp"].shape[0]):
+            nb, na = (int(v) for v in t0["ncomp"][i])
+            assert (nb, na) == tuple(int(v) for v in t1["ncomp"][i]), i
+            assert np.array_equal(t0["band_sums"][i][:nb, :3], t1["band_sums"][i][:nb, :3]), i
+            assert np.array_equal(t0["area_first"][i][:na], t1["area_first"][i][:na]), i
+            assert np.array_equal(t0["area_sums"][i][:na, :15], t1["area_sums"][i][:na, :15]), i
+            assert np.array_equal(t0["probe"][i][:nb], t1["probe"][i][:nb]), i
+
+    for tag, crop, n in (("c1", None, 1), ("c1", None, 5), ("c2", None, 1), ("c2", None, 4), ("c2", (64, 1024, 160, 1120), 2),
+                         ("c2", (0, 450, 0, 480), 3), ("c5", None, 1), ("c5", None, 3)):
+        spec = {"c1": S.config1, "c2": S.config2, "c5": S.config5}[tag]()
+        ft = S.make_frames_torch(spec, range(n), seed=5, device="cuda")
+        if crop:
+            ft = ft[:, crop[0]:crop[1], crop[2]:crop[3]]
+        eng = Engine(ft.shape[1], ft.shape[2], max_markers=1024 if tag == "c5" else 512, max_batch=n)
+        ((_, d0, c0), t0), ((_, d1, c1), t1) = both(eng, lambda: eng.track_to_3d(ft, want_det=True), n)
+        assert np.array_equal(t0["slow"], t1["slow"]), (tag, crop, t0["slow"], t1["slow"])
+        if crop is None:
+            assert int(t0["slow"].sum()) == 0, ("a marker frame left the several-workgroups path", tag, t0["slow"])
+        keep = t0["slow"] == 0                               # (the 450x480 corner of large-marker frames: holes, general kernel)
+        same_tables({k: v[keep] for k, v in t0.items()}, {k: v[keep] for k, v in t1.items()})
+        assert torch.equal(c0, c1) and torch.equal(d0, d1) and int(c0.min()) > 0
+        eng.close()
+    rng = np.random.default_rng(11)
+    for (h, w) in ((450, 480), (700, 900), (1000, 1200)):
+        n = 6
+        mask = np.zeros((n, h, w), np.uint8); area = np.zeros((n, h, w), np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        for f in range(n):
+            for _ in range(int(rng.integers(5, 50))):
+                cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+                a, b, th = rng.uniform(4, 40), rng.uniform(4, 40), rng.uniform(0, np.pi)
+                u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th); v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+                area[f][(u / a) ** 2 + (v / b) ** 2 <= 1] = 255
+                mask[f][(u / (0.7 * a)) ** 2 + (v / (0.7 * b)) ** 2 <= 1] = 1
+        eng = Engine(h, w, max_markers=512, max_batch=n)
+        mt, at = torch.from_numpy(mask).cuda(), torch.from_numpy(area).cuda()
+        ((d0, c0), t0), ((d1, c1), t1) = both(eng, lambda: eng.marker_center(mt, at), n)
+        keep = (t0["slow"] == 0) & (t1["slow"] == 0)          # frames neither kernel handed to the general one
+        assert int(keep.sum()) > 0
+        same_tables({k: v[keep] for k, v in t0.items()}, {k: v[keep] for k, v in t1.items()})
+        assert torch.equal(c0, c1) and torch.equal(d0, d1)
+        eng.close()
+    for (h, w) in ((480, 640), (1024, 1280)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        pats = [np.ones((h, w), bool), np.zeros((h, w), bool), (xx // 64) % 2 == 0, (yy // 8) % 2 == 0,
+                ((xx // 8) + (yy // 8)) % 2 == 0, rng.random((h, w)) < 0.5, ((xx % 12) < 6) & ((yy % 97) > 5),
+                (((xx - w // 2) ** 2 + (yy - h // 2) ** 2) < (min(h, w) // 2 - 3) ** 2)]
+        n = len(pats)
+        area = np.stack([(p * 255).astype(np.uint8) for p in pats]); mask = np.stack([p.astype(np.uint8) for p in pats])
+        eng = Engine(h, w, max_markers=1024, max_batch=n)
+        mt, at = torch.from_numpy(mask).cuda(), torch.from_numpy(area).cuda()
+        ((d0, c0), t0), ((d1, c1), t1) = both(eng, lambda: eng.marker_center(mt, at), n)
+        assert torch.equal(c0, c1), (c0.tolist(), c1.tolist())
+        for i in range(n):
+            k = max(int(c0[i]), 0)
+            assert torch.equal(d0[i, :k], d1[i, :k]), i
+        eng.close()
+
+
 @pytest.mark.parametrize("shape", [(480, 640), (1024, 1280)])
 def test_stage_on_adverse_patterns(shape):
     """Inputs far from marker frames - all ones, stripes one tile wide, blocks touching at their corners, dense noise, a comb

@@ -31,7 +31,7 @@ def test_option_and_status_constants_match_the_header():
     for name in ("GRAY_COEFFS", "FORCE_SEQ_MATCH", "GRAY_SIDE_STREAM", "NCC_MARGIN", "STAGE_IMPL", "BLUR_IMPL", "PASS_STREAMS"):
         assert getattr(L, "OPT_" + name) == defs["VBS_OPT_" + name], name
     opts = [v for k, v in defs.items() if k.startswith("VBS_OPT_")]
-    assert len(opts) == len(set(opts)) == 7
+    assert len(opts) == len(set(opts)) == 8
     for k, v in defs.items():
         if hasattr(L, k[4:]) and isinstance(getattr(L, k[4:]), int) and not k.startswith("VBS_OPT_"):
             assert getattr(L, k[4:]) == v, k

@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvbs.so")
-SOURCES = ("api.hip", "k_blur.hip", "k_ncc.hip", "k_label.hip", "k_ccl.hip", "k_stage.hip", "k_solve.hip", "k_undistort.hip", "k_ids.hip", "host_csv.hip")
+SOURCES = ("api.hip", "k_blur.hip", "k_ncc.hip", "k_label.hip", "k_ccl.hip", "k_stage.hip", "k_stage_lat.hip", "k_solve.hip", "k_undistort.hip", "k_ids.hip", "host_csv.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # k_ncc.hip: no SLP pairings (they cost registers, 127 -> 108, and instructions) and no packed float32 instructions at all:
@@ -25,7 +25,7 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = False, extra_flags=(), suffix: str = "") -> str:
     """`extra_flags` / `suffix`: a second library next to the product one, e.g. tools/ build `libvbs_dbg.so` with
     -DVBS_DEBUG_KNOBS (phase-timing early exits read from the environment); the product library never has them."""
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ccl_common.h"), os.path.join(CSRC, "..", "..", "include", "vbs.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ccl_common.h"), os.path.join(CSRC, "stage_common.h"), os.path.join(CSRC, "..", "..", "include", "vbs.h")]
     lib = LIB.replace(".so", suffix + ".so")
     objs, jobs = [], []
     for src in SOURCES:

@@ -8,7 +8,7 @@ LIB_PATH = os.path.join(_HERE, "csrc", "libvbs.so")
 VBS_OK, VBS_EINVAL, VBS_ECAPACITY, VBS_EHIP, VBS_ENOMEM, VBS_EINTERNAL = 0, -1, -2, -3, -4, -5
 DET_COLS, TABLE_COLS, DISP_COLS, PLANE_COLS, DEVPLANE_COLS = 6, 10, 5, 5, 9
 FLAG_TRACKED, FLAG_XYZ = 1, 2
-OPT_GRAY_COEFFS, OPT_FORCE_SEQ_MATCH, OPT_GRAY_SIDE_STREAM, OPT_NCC_MARGIN, OPT_STAGE_IMPL, OPT_BLUR_IMPL, OPT_PASS_STREAMS = 1, 2, 3, 4, 5, 6, 7
+OPT_GRAY_COEFFS, OPT_FORCE_SEQ_MATCH, OPT_GRAY_SIDE_STREAM, OPT_NCC_MARGIN, OPT_STAGE_IMPL, OPT_BLUR_IMPL, OPT_PASS_STREAMS, OPT_LATENCY_FRAMES = 1, 2, 3, 4, 5, 6, 7, 8
 
 # every symbol include/vbs.h declares (tests check the export list against the header)
 SYMBOLS = ("vbs_create", "vbs_destroy", "vbs_last_error", "vbs_version", "vbs_contour_lut",

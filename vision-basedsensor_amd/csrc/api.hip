@@ -169,8 +169,10 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(area_first, B * max_markers); ALLOC(area_sums, B * max_markers * VBS_AREA_SUMS);
     ALLOC(ell, B * max_markers * 8); ALLOC(det64, B * max_markers * 6);
     ALLOC(cnt, B);
-    ALLOC(probe, B * max_markers * 4); ALLOC(slow_total, B + 4); ALLOC(ncc_tot, 4);
-    h->slow_flag = h->slow_total + 4;                    // (one memset clears both)
+    ALLOC(probe, B * max_markers * 4); ALLOC(lat_hdr, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + B + 4); ALLOC(ncc_tot, 4);
+    h->slow_total = h->lat_hdr + (size_t)VBS_LAT_MAXN * VBS_LAT_HDR;
+    h->slow_flag = h->slow_total + 4;                    // (one fill clears both - and the headers in front when k_stage_lat runs)
+    if (const size_t per = stage_lat_scratch(h)) ALLOC(lat_scratch, per * (size_t)std::min<size_t>(B, VBS_LAT_MAXN));
     ALLOC(lut, 256);
     ALLOC(blur_frags, frags.size() / 4);
     if (!frags16h.empty()) { ALLOC(blur16_h, frags16h.size() / 4); ALLOC(blur16_v, frags16v.size() / 4); }
@@ -438,6 +440,11 @@ extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
             if (value != 0 && value != 1) break;
             h->stage_impl = value;
             return VBS_OK;
+        case VBS_OPT_LATENCY_FRAMES:
+            if (value < 0 || value > VBS_LAT_MAXN) break;
+            h->lat_frames = value;
+            if (h->twin) h->twin->lat_frames = value;
+            return VBS_OK;
         case VBS_OPT_BLUR_IMPL:
             if (value != 0 && value != 1) break;
             h->blur_impl = value;
@@ -647,7 +654,7 @@ static int twin_of(vbs_handle* h) {
     t->pass_streams = 1;
     t->is_twin = true;
     t->gray_bits = h->gray_bits; t->force_seq_match = h->force_seq_match; t->ncc_margin_ppm = h->ncc_margin_ppm;
-    t->stage_impl = h->stage_impl; t->blur_impl = h->blur_impl;
+    t->stage_impl = h->stage_impl; t->blur_impl = h->blur_impl; t->lat_frames = h->lat_frames;
     hipStream_t st = nullptr;
     hipEvent_t ef = nullptr, ej = nullptr;
     if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess ||

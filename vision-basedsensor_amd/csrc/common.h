@@ -15,6 +15,8 @@ typedef uint8_t u8;
 #define VBS_NCC_MAXL 80
 #define VBS_RUN_CAP 30720          // union-find nodes (runs) per mask per frame kept in LDS
 #define VBS_AREA_SUMS 16           // n, 14 moments up to order 4, spare
+#define VBS_LAT_MAXN 8             // passes of at most this many frames may take the few-frames labelling kernel (k_stage_lat.hip)
+#define VBS_LAT_HDR 128            // dwords of counters / flags per frame of that kernel
 
 struct BranchParams {              // marker_detection.py:117-126,129,170
     int taps_a, taps_b;            // GaussianBlur sizes
@@ -95,6 +97,10 @@ struct vbs_handle {
     int32_t* cnt;      // [maxb]
     unsigned short* probe;   // [maxb][maxm][4]  component ids of the 2x2 cell around every band centroid
     u64* ncc_tot;      // [4]  running NCC decision counters (vbs_ncc_counters)
+    u32* lat_hdr;      // [VBS_LAT_MAXN][VBS_LAT_HDR] k_stage_lat's per-frame counters; slow_total / slow_flag follow (one fill clears all)
+    unsigned char* lat_scratch = nullptr;   // [VBS_LAT_MAXN][stage_lat_scratch()] what the workgroups of a frame share; null = path not available
+    int lat_frames = 4;             // vbs_set_option(VBS_OPT_LATENCY_FRAMES): passes of <= this many frames take k_stage_lat (0: never)
+    size_t lat_lds_set = 0;
     u32* slow_total;   // [1]  frames of this pass the fused kernel handed on (lets the general kernels leave at once)
     u32* slow_flag;    // [maxb]  non-zero = the fast labelling path handed the frame on (the value says why)
     size_t stage_lds_set = 0, ccl_lds_set[2] = {0, 0};   // dynamic LDS declared for k_stage / k_ccl<0|1> through this handle
@@ -166,6 +172,7 @@ void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& ta
 void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s);
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s);
+size_t stage_lat_scratch(const vbs_handle* h);          // bytes of scratch per frame k_stage_lat needs for this geometry (0: not taken)
 // n 32-bit words <- value, as a KERNEL on `s`: the per-pass clears of the hot path.  (Not hipMemsetAsync: captured into a HIP
 // graph, the memset nodes of a one-stream multi-pass call left the first pass's status words holding address-like garbage
 // from the second replay on - tools/gpu_graph_debug.py, ROCm 7.2 - while kernel nodes replay exactly.)

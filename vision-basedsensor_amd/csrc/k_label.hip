@@ -865,16 +865,20 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
 
 bool launch_ccl(vbs_handle* h, int nb, hipStream_t s);   // false: geometry outside the round-2 fast path
 bool launch_stage(vbs_handle* h, int nb, hipStream_t s);  // false: geometry outside the fused path
+bool launch_stage_lat(vbs_handle* h, int nb, hipStream_t s);   // k_stage_lat.hip; false: not for this pass
 
 // a9-a12: band / opened planes, labelling, per-component sums.  The fused kernel (k_stage.hip) takes the pass; k_morph and
 // the general kernel then run over the frames it handed on (none on marker frames: their waves / workgroups find no
 // flagged frame and exit).  Geometries outside the fused path - and VBS_OPT_STAGE_IMPL = 1 - take the round-2 kernels:
 // k_morph over every frame, k_ccl<0|1>, the general kernel over what those hand on.
 void launch_labelling(vbs_handle* h, int nb, hipStream_t s) {
-    launch_fill(h->slow_total, 0u, (size_t)nb + 4, s);                             // the counter and the flags
+    // a pass of a few frames (MarkerTracker.process: ONE) spreads each frame over several workgroups: k_stage_lat.hip
+    const bool lat = h->stage_impl == 0 && nb <= h->lat_frames && h->lat_scratch != nullptr;
+    if (lat) launch_fill(h->lat_hdr, 0u, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + nb + 4, s);     // its headers, the counter and the flags
+    else launch_fill(h->slow_total, 0u, (size_t)nb + 4, s);                       // the counter and the flags
     int all = 0;
     const u32* nslow = nullptr;
-    if (h->stage_impl == 0 && launch_stage(h, nb, s)) {
+    if (h->stage_impl == 0 && ((lat && launch_stage_lat(h, nb, s)) || launch_stage(h, nb, s))) {
         launch_morph(h, nb, h->slow_flag, s);
         nslow = h->slow_total;
     } else {

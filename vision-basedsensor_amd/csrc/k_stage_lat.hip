@@ -1,0 +1,795 @@
+// a9-a13 for a FEW frames per call (marker_detection.py:170-196 as MarkerTracker.process calls it, one frame at a time,
+// :434-453): k_stage.hip's method with a frame spread over C workgroups of four waves instead of one workgroup of twelve.
+//
+// k_stage labels a frame on ONE compute unit - the right shape for a batch (one frame per CU, 256 CUs), 190 us for a
+// single frame.  Here a thread's tile is 64 px x ~8 rows instead of x 29, a frame has 256 C threads (C = 11 at
+// 1280x1024) and every wave has a SIMD to itself; what the workgroups of a frame share lives in global memory:
+//   walk      as k_stage (same helpers, stage_common.h): rows through register delay lines, segments in slots, what
+//             crosses a tile only NOTED.  Records, pairs and moment records go to the workgroup's own region of the
+//             frame's scratch (index from an LDS counter: no global atomic on the walk), last-row slots, first rows and
+//             segment counts to per-thread cells.
+//   resolve   the LAST workgroup of a frame to finish a walk (an arrival counter, nobody waits for a workgroup that has
+//             not started) does what k_stage does after it, alone: parents in its LDS, tile links + queued pairs,
+//             flatten, number the roots, first pixel, rank, sums.  After the band walk the other workgroups of the frame
+//             wait for it (the probe requests of the opened walk come out of the band centroids); after the opened walk
+//             they simply leave.  A wait that expires reports VBS_EINTERNAL in the frame's status, never a wrong table.
+// Results are bit-identical to k_stage's (tests/test_gpu_parity.py::test_latency_stage_equals_the_batch_stage), frames
+// it cannot take are handed on with the same slow flags.
+#include "stage_common.h"
+
+#define LT_NT 256                  // threads per workgroup: four waves, one per SIMD
+#define LT_CMAX 16                 // workgroups per frame, at most: segment ids 8 x 256 x 16 = 2^15 (bit 15 marks a root)
+#define LT_REC 512                 // band segment records per workgroup
+#define LT_PQ 1024                 // queued pairs per workgroup and walk
+#define LT_MREC 512                // moment records per workgroup
+#define LT_ROWS 8                  // rows per thread aimed at
+// header words of a frame (VBS_LAT_HDR each, cleared by launch_labelling's fill together with the slow flags)
+#define LH_ARRIVE1 0
+#define LH_ARRIVE2 1
+#define LH_FLAG 2                  // 1: band components are out, go on; 2: the frame was handed on, leave
+#define LH_WHY 3
+#define LH_EULER 4
+#define LH_NREC 16                 // [C] band records / pairs of the band walk / moment records / pairs of the opened walk
+#define LH_NPQB 32
+#define LH_NMREC 48
+#define LH_NPQO 64
+
+struct LatGeom {
+    int H, W, WW, G, NB, R, C, FT, maxm;                  // FT = 256 C threads per frame, NB = 4 C G row blocks of R rows
+    u32 mom_comps;
+    u32 stride;                                           // bytes of scratch per frame
+    u32 o_nseg, o_first, o_botm, o_bots, o_rsid, o_rpos, o_rcnt, o_rsx, o_rsy, o_pq, o_segpos, o_mbcnt, o_mbreq, o_mrec;
+    u32 l_nseg, l_comp, l_acc, l_tmp;                     // byte offsets into the dynamic LDS (parents at 0)
+};
+
+// exclusive prefix sum over the LT_NT threads; tmp holds >= 8 words
+__device__ __forceinline__ u32 lt_scan(u32 v, u32* tmp, u32* total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    u32 inc = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const u32 t = __shfl_up(inc, d);
+        if (lane >= d) inc += t;
+    }
+    if (lane == 63) tmp[wave] = inc;
+    __syncthreads();
+    u32 before = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < LT_NT / 64; ++w) { const u32 t = tmp[w]; if (w < wave) before += t; tot += t; }
+    __syncthreads();
+    *total = tot;
+    return inc - v + before;
+}
+
+// the tile of frame-thread ft
+struct LatTile { int g, j, blk, bj; bool act, hasl, hasr, hasu; };
+__device__ __forceinline__ LatTile lat_tile(u32 ft, int WW, int G) {
+    LatTile t;
+    const int lane = (int)(ft & 63u);
+    t.g = lane / WW; t.j = lane - t.g * WW;
+    t.act = t.g < G;
+    t.blk = (int)(ft >> 6) * G + t.g;
+    t.hasl = t.j > 0; t.hasr = t.act && t.j + 1 < WW;
+    t.hasu = t.act && t.blk > 0;
+    t.bj = t.act ? t.blk * WW + t.j : 0;
+    return t;
+}
+
+// After a walk, by ONE workgroup: the components of the frame's segments.  P (LDS) = parents over 8 FT segment ids; the
+// unions are the first row of every tile against the last-row slots of the tile above (C8: with the diagonal neighbours
+// across the word edges) and the pairs the walks queued.  Then as k_stage's seg_resolve: flatten, number the roots (an
+// entry becomes its root's number, bit 15 marks the root), comp_pos[c] = first pixel of component c (band: minimum over
+// its records' first pixels; opened: over its segments'), cidmap[c] = rank of that pixel = the component's id.
+// Workgroup-uniform return: components, or NONE32 when there are more than `limit`.
+template <int K, bool C8>
+__device__ __forceinline__ u32 lat_resolve(const LatGeom& geo, unsigned short* P, unsigned char* nsegL,
+                                           const unsigned char* nsegG, const u64* firstG, const u64* botm,
+                                           const unsigned short* bots, const u32* pq, const u32* npq,
+                                           const unsigned short* rsid, const u32* rpos, const u32* nrec, const u32* segpos,
+                                           u32* comp_pos, unsigned short* cidmap, u32* tmp, u32 limit) {
+    const int tid = threadIdx.x;
+    const u32 FT = (u32)geo.FT, NS = 8u * FT;
+    const int WW = geo.WW;
+    for (u32 s = tid; s < NS; s += LT_NT) P[s] = (unsigned short)s;
+    for (u32 ft = tid; ft < FT; ft += LT_NT) nsegL[ft] = nsegG[ft];
+    __syncthreads();
+    for (u32 ft = tid; ft < FT; ft += LT_NT) {
+        const LatTile t = lat_tile(ft, WW, geo.G);
+        if (!t.hasu) continue;
+        u64 N = firstG[ft];
+        u32 i = 0;
+        const int up = t.bj - WW;
+        while (N) {                                      // the runs of the tile's first row are its segments 0, 1, .. in order
+            const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+            N &= t2;
+            const u64 ga = C8 ? (gg | (gg << 1) | (gg >> 1)) : gg;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                if (ga & botm[(size_t)k * FT + up]) ccl_union(P, 8u * ft + i, bots[(size_t)k * FT + up]);
+                if (C8) {
+                    if ((gg & 1ull) && t.hasl && (botm[(size_t)k * FT + up - 1] >> 63)) ccl_union(P, 8u * ft + i, bots[(size_t)k * FT + up - 1]);
+                    if ((gg >> 63) && t.hasr && (botm[(size_t)k * FT + up + 1] & 1ull)) ccl_union(P, 8u * ft + i, bots[(size_t)k * FT + up + 1]);
+                }
+            }
+            ++i;
+        }
+    }
+    for (int w = 0; w < geo.C; ++w) {
+        const u32 np = min(npq[w], (u32)LT_PQ);
+        for (u32 i = tid; i < np; i += LT_NT) { const u32 pr = pq[(size_t)w * LT_PQ + i]; ccl_union(P, pr >> 16, pr & 0xFFFFu); }
+    }
+    __syncthreads();
+    auto valid = [&](u32 s) -> bool { return (s & 7u) < (u32)nsegL[s >> 3]; };
+    for (u32 s = tid; s < NS; s += LT_NT) {              // flatten (no halving: a late store must be a root)
+        if (!valid(s)) continue;
+        u32 x = s, p;
+        while ((p = ((volatile unsigned short*)P)[x]) != x) x = p;
+        if (x != s) P[s] = (unsigned short)x;
+    }
+    __syncthreads();
+    const u32 per = NS / LT_NT, s0 = (u32)tid * per;     // a contiguous run of ids per thread: the roots are numbered in id order
+    u32 nroot = 0;
+    for (u32 s = s0; s < s0 + per; ++s) nroot += valid(s) && P[s] == s;
+    u32 ncomp;
+    u32 c0 = lt_scan(nroot, tmp, &ncomp);
+    if (ncomp > limit) return NONE32;
+    for (u32 s = s0; s < s0 + per; ++s)
+        if (valid(s) && P[s] == s) { comp_pos[c0] = NONE32; P[s] = (unsigned short)(0x8000u | c0++); }
+    __syncthreads();
+    for (u32 s = tid; s < NS; s += LT_NT) {
+        if (!valid(s)) continue;
+        const u32 v = P[s];
+        if (!(v & 0x8000u)) P[s] = (unsigned short)(P[v] & 0x7FFFu);
+    }
+    __syncthreads();
+    if (segpos) {
+        for (u32 s = tid; s < NS; s += LT_NT)
+            if (valid(s)) atomicMin(&comp_pos[P[s] & 0x7FFFu], segpos[s]);
+    } else {
+        for (int w = 0; w < geo.C; ++w) {
+            const u32 nr = min(nrec[w], (u32)LT_REC);
+            for (u32 r = tid; r < nr; r += LT_NT)
+                atomicMin(&comp_pos[P[rsid[(size_t)w * LT_REC + r]] & 0x7FFFu], rpos[(size_t)w * LT_REC + r]);
+        }
+    }
+    __syncthreads();
+    for (u32 c = tid; c < ncomp; c += LT_NT) {           // rank by first pixel (positions are distinct)
+        const u32 p = comp_pos[c];
+        u32 rank = 0;
+        for (u32 q = 0; q < ncomp; ++q) rank += comp_pos[q] < p;
+        cidmap[c] = (unsigned short)rank;
+    }
+    __syncthreads();
+    return ncomp;
+}
+
+template <int NS>
+__global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ mask_all, const u64* __restrict__ area_all,
+                                                        u32* __restrict__ ncomp_all, u64* __restrict__ band_sums,
+                                                        u32* __restrict__ area_first, i64* __restrict__ area_sums,
+                                                        unsigned short* __restrict__ probe_all, u32* __restrict__ fstat,
+                                                        u32* __restrict__ slow_flag, u32* __restrict__ slow_total,
+                                                        u32* __restrict__ hdr_all, unsigned char* __restrict__ scratch_all,
+                                                        LatGeom geo) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int misc[16];         // [0] Euler sum, [4] records, [5] queued pairs, [6] why the frame is handed on, [7] moment records,
+                                     // [8] this workgroup is the last of its frame, [9] the flag the others waited for
+    unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [8 FT] segment parents (resolving workgroup)
+    unsigned char* nsegL = smem + geo.l_nseg;                                            // [FT]
+    u32* comp_pos = reinterpret_cast<u32*>(smem + geo.l_comp);                            // [1024] first pixel of a component
+    unsigned short* cidmap = reinterpret_cast<unsigned short*>(smem + geo.l_comp + 4096); // [1024] its rank = component id
+    unsigned char* accb = smem + geo.l_acc;                                              // band sums | anchors + moments
+    u32* tmp = reinterpret_cast<u32*>(smem + geo.l_tmp);                                  // [8]
+    const int wg = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const int H = geo.H, W = geo.W, WW = geo.WW, G = geo.G, R = geo.R, maxm = geo.maxm, C = geo.C;
+    const u32 FT = (u32)geo.FT, ftid = (u32)wg * LT_NT + (u32)tid;
+    const LatTile T = lat_tile(ftid, WW, G);
+    const int j = T.j, bj = T.bj, y0 = T.blk * R;
+    const bool act = T.act, hasl = T.hasl, hasr = T.hasr;
+    const u64 vm = act ? valid_mask(j, W) : 0ull;
+    const u32 sbase = ftid * SG_SEGMAX;
+    // the frame's scratch
+    u32* hdr = hdr_all + (size_t)n * VBS_LAT_HDR;
+    unsigned char* sc = scratch_all + (size_t)n * geo.stride;
+    unsigned char* nsegG = sc + geo.o_nseg;                                              // [2][FT]   band | opened
+    u64* firstG = reinterpret_cast<u64*>(sc + geo.o_first);                               // [2][FT]
+    u64* botm = reinterpret_cast<u64*>(sc + geo.o_botm);                                  // [4][FT] last-row slots of every tile
+    unsigned short* bots = reinterpret_cast<unsigned short*>(sc + geo.o_bots);            // [4][FT]
+    unsigned short* rsid = reinterpret_cast<unsigned short*>(sc + geo.o_rsid);            // [C][LT_REC] band records
+    u32* rpos = reinterpret_cast<u32*>(sc + geo.o_rpos);
+    u32* rcnt = reinterpret_cast<u32*>(sc + geo.o_rcnt);
+    u32* rsx = reinterpret_cast<u32*>(sc + geo.o_rsx);
+    u32* rsy = reinterpret_cast<u32*>(sc + geo.o_rsy);
+    u32* pqg = reinterpret_cast<u32*>(sc + geo.o_pq);                                     // [C][LT_PQ]
+    u32* segpos = reinterpret_cast<u32*>(sc + geo.o_segpos);                              // [8 FT] opened mask: first pixel by segment id
+    u32* mbcnt = reinterpret_cast<u32*>(sc + geo.o_mbcnt);                                // [FT] probe requests
+    u32* mbreq = reinterpret_cast<u32*>(sc + geo.o_mbreq);                                // [FT][ST_MB_CAP]
+    u32* mrec = reinterpret_cast<u32*>(sc + geo.o_mrec);                                  // [C][LT_MREC][16]  segment id, 15 moments
+    PairQ Q;
+    Q.q = pqg + (size_t)wg * LT_PQ;
+    Q.cap = LT_PQ;
+    Q.n = &misc[5];
+    if (tid < 16) misc[tid] = 0;
+    const int64_t fo = (int64_t)n * H * WW;
+    auto hand_on = [&](u32 why) {                        // (the resolving workgroup, uniformly)
+        if (tid == 0) { slow_flag[n] = why; atomicAdd(slow_total, 1u); }
+    };
+    // every store of this workgroup out, then one arrival; true in the workgroup that arrived last
+    auto arrive = [&](int which) -> bool {
+        __threadfence();
+        __syncthreads();
+        if (tid == 0) misc[8] = atomicAdd(&hdr[which], 1u) == (u32)(C - 1);
+        __syncthreads();
+        const bool last = misc[8] != 0;
+        if (last) __threadfence();
+        return last;
+    };
+    __syncthreads();
+
+    // ================================ band plane ====================================================================
+    {
+        constexpr int NA = NS / 2, NBL = NS / 2 - 1;     // rows of the window above / below its row
+        const u64* M = mask_all + fo;
+        auto ldraw = [&](int r) -> u64 {
+            const int y = min(max(y0 + r, 0), H - 1);
+            return M[(int64_t)y * WW + (act ? j : 0)];
+        };
+        auto rowval = [&](u64 raw, int r) -> u64 {       // source row y0 + r; outside the image: ones (ignored by the erosion)
+            const int y = y0 + r;
+            return (act && y >= 0 && y < H) ? (raw | ~vm) : ~0ull;
+        };
+        u64 pf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pf[i] = ldraw(-NA + i);
+        u64 cr[NBL + 1];
+#pragma unroll
+        for (int i = 0; i <= NBL; ++i) cr[i] = ~0ull;
+        u64 h1 = ~0ull, a2[2] = {~0ull, ~0ull}, a4[4] = {~0ull, ~0ull, ~0ull, ~0ull};
+        u64 a8[6] = {~0ull, ~0ull, ~0ull, ~0ull, ~0ull, ~0ull};
+        u64 pm[SG_KB];
+        u32 sid[SG_KB], cnt[SG_KB], sy[SG_KB], sk[SG_KB], pos[SG_KB];
+#pragma unroll
+        for (int k = 0; k < SG_KB; ++k) { pm[k] = 0; sid[k] = 0; cnt[k] = 0; sy[k] = 0; sk[k] = 0; pos[k] = 0; }
+        u32 nseg = 0, la = NONE16, lb = NONE16, p63 = NONE16, prs0 = NONE16;
+        bool fail = false;
+        u64 firstB = 0;
+        auto emit = [&](u32 sid_, u32 pos_, u32 cnt_, u32 sk_, u32 sy_) {
+            const int r = atomicAdd(&misc[4], 1);
+            if (r < LT_REC) {
+                const size_t o = (size_t)wg * LT_REC + r;
+                rsid[o] = (unsigned short)sid_; rpos[o] = pos_; rcnt[o] = cnt_;
+                rsx[o] = 64u * (u32)j * cnt_ + sk_; rsy[o] = sy_;
+            } else fail = true;
+        };
+#pragma unroll 1
+        for (int q = 0; q < R + NS - 1; ++q) {
+            const int r = q - NA;                        // source row of this step
+            const u64 v = rowval(pf[0], r);
+            pf[0] = pf[1]; pf[1] = pf[2]; pf[2] = pf[3]; pf[3] = ldraw(r + 4);
+#pragma unroll
+            for (int i = NBL; i > 0; --i) cr[i] = cr[i - 1];
+            cr[0] = v;
+            const u64 n2 = h1 & v, n4 = a2[1] & n2;
+            u64 e;
+            if (NS == 14) {
+                const u64 n8 = a4[3] & n4;
+                e = a8[5] & n8;                          // rows r - 13 .. r
+                a8[5] = a8[4]; a8[4] = a8[3]; a8[3] = a8[2]; a8[2] = a8[1]; a8[1] = a8[0]; a8[0] = n8;
+            } else {
+                e = a4[3] & n4;                          // ns = 8: rows r - 7 .. r
+            }
+            a4[3] = a4[2]; a4[2] = a4[1]; a4[1] = a4[0]; a4[0] = n4;
+            a2[1] = a2[0]; a2[0] = n2;
+            h1 = v;
+            const int t = r - NBL;                       // the row whose window ends at r
+            if (t < 0) continue;                         // (uniform)
+            const u64 eh = hwin<NS, true>(e, hasl, hasr);
+            const u64 B = (act && y0 + t < H) ? (cr[NBL] & ~eh & vm) : 0ull;      // :171-174  maxima = mask & (window holds a 0)
+            if (t == 0) firstB = B;
+            bool live = false;
+#pragma unroll
+            for (int k = 0; k < SG_KB; ++k) live |= pm[k] != 0ull;
+            if (!__any(B != 0ull || live)) continue;     // (wave-uniform)
+            const u32 y = (u32)(y0 + t);
+            const u64 rB = brev64(B);
+            u64 Rn[SG_KB];
+            const u64 claimed = seg_update<SG_KB, false, true>(B, rB, pm, sid, Rn, Q);
+#pragma unroll
+            for (int k = 0; k < SG_KB; ++k) {
+                const u64 Rk = Rn[k];
+                if (k < 2 || __any(Rk != 0ull)) {
+                    const u32 c = (u32)__popcll(Rk);
+                    cnt[k] += c; sy[k] += c * y; sk[k] += sum_bitpos(Rk);
+                }
+                pm[k] = Rk;
+            }
+            u64 N = B & ~claimed;
+            while (N) {                                  // runs no segment reaches: new segments
+                const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                N &= t2;
+                bool done = false;
+#pragma unroll
+                for (int k = 0; k < SG_KB; ++k) {
+                    if (!done && pm[k] == 0ull) {
+                        if (cnt[k]) emit(sid[k], pos[k], cnt[k], sk[k], sy[k]);
+                        if (nseg < SG_SEGMAX) sid[k] = sbase + nseg;
+                        else fail = true;
+                        ++nseg;
+                        const u32 c = (u32)__popcll(gg);
+                        pos[k] = y * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
+                        pm[k] = gg; cnt[k] = c; sy[k] = c * y; sk[k] = sum_bitpos(gg);
+                        done = true;
+                    }
+                }
+                if (!done) fail = true;
+            }
+            if (__any(((B >> 63) | B) & 1ull)) seg_hlinks<SG_KB, false>(pm, sid, hasr, p63, prs0, la, lb, Q);    // (wave-uniform)
+        }
+#pragma unroll
+        for (int k = 0; k < SG_KB; ++k) {
+            if (cnt[k]) emit(sid[k], pos[k], cnt[k], sk[k], sy[k]);
+            if (act) { botm[(size_t)k * FT + bj] = pm[k]; bots[(size_t)k * FT + bj] = (unsigned short)sid[k]; }
+        }
+        nsegG[ftid] = (unsigned char)min(nseg, (u32)SG_SEGMAX);
+        firstG[ftid] = firstB;
+        if (fail) misc[6] = SLOW_SLOTS;
+        __syncthreads();
+        if (tid == 0) {
+            if (misc[5] > LT_PQ) misc[6] = SLOW_SLOTS;
+            hdr[LH_NREC + wg] = (u32)min(misc[4], LT_REC);
+            hdr[LH_NPQB + wg] = (u32)min(misc[5], LT_PQ);
+            if (misc[6]) atomicMax(&hdr[LH_WHY], (u32)misc[6]);
+        }
+        const bool last = arrive(LH_ARRIVE1);
+        if (last) {
+            // ---- the frame's band components, by this workgroup alone ------------------------------------------------------
+            u32 go = 1;
+            const u32 whyw = __atomic_load_n(&hdr[LH_WHY], __ATOMIC_RELAXED);
+            u32 ncomp = 0;
+            if (whyw) { hand_on(whyw); go = 2; }
+            else {
+                for (u32 ft = tid; ft < FT; ft += LT_NT) mbcnt[ft] = 0;
+                ncomp = lat_resolve<SG_KB, false>(geo, P, nsegL, nsegG, firstG, botm, bots, pqg, hdr + LH_NPQB, rsid, rpos,
+                                                  hdr + LH_NREC, nullptr, comp_pos, cidmap, tmp, min((u32)maxm, 1024u));
+                if (ncomp == NONE32) { hand_on(SLOW_NCOMP); go = 2; }
+            }
+            if (go == 1) {
+                // ---- component sums (center_of_mass :181) ------------------------------------------------------------------
+                u32* acnt = reinterpret_cast<u32*>(accb);                                // [maxm]
+                u64* asx = reinterpret_cast<u64*>(accb + 8 * ((maxm + 1) / 2));           // [maxm]
+                u64* asy = asx + maxm;                                                   // [maxm]
+                for (u32 c = tid; c < ncomp; c += LT_NT) { acnt[c] = 0; asx[c] = 0; asy[c] = 0; }
+                __threadfence();                         // (the cleared request counters, before anybody adds to them)
+                __syncthreads();
+                for (int w = 0; w < C; ++w) {
+                    const u32 nr = hdr[LH_NREC + w];
+                    for (u32 r = tid; r < nr; r += LT_NT) {
+                        const size_t o = (size_t)w * LT_REC + r;
+                        const u32 cid = cidmap[P[rsid[o]] & 0x7FFFu];
+                        atomicAdd(&acnt[cid], rcnt[o]); atomicAdd(&asx[cid], (u64)rsx[o]); atomicAdd(&asy[cid], (u64)rsy[o]);
+                    }
+                }
+                __syncthreads();
+                // the sums go out; the probe requests (2x2 pixel cell around every centroid) go to the threads that own the pixels
+                u64* bs = band_sums + (int64_t)n * maxm * 4;
+                unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
+                for (u32 c = tid; c < ncomp; c += LT_NT) {
+                    const u32 cn_ = acnt[c];
+                    const u64 sx = asx[c], sy_ = asy[c];
+                    bs[c * 4 + 0] = cn_; bs[c * 4 + 1] = sx; bs[c * 4 + 2] = sy_;
+                    const double cn = (double)cn_;
+                    const float xf = (float)((double)sx / cn), yf = (float)((double)sy_ / cn);
+                    const int ix = (int)floorf(xf), iy = (int)floorf(yf);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int px = ix + (q & 1), py = iy + (q >> 1);
+                        if (px < 0 || py < 0 || px >= W || py >= H) { pr[c * 4 + q] = (unsigned short)NONE16; continue; }
+                        // one request per row and word: the pixel (ix + 1, py) rides along when it lies in the same word
+                        const bool pair = (q & 1) == 0 && px + 1 < W && (px & 63) != 63;
+                        if ((q & 1) && px > 0 && (px & 63) != 0) continue;                   // rode along with (ix, py)
+                        const int ob = py / R, oi = py - ob * R, ow = ob / G, og = ob - ow * G;
+                        const int owner = ow * 64 + og * WW + (px >> 6);
+                        const u32 slot = atomicAdd(&mbcnt[owner], 1u);
+                        if (slot < ST_MB_CAP)
+                            mbreq[owner * ST_MB_CAP + slot] = c | ((u32)q << 10) | ((u32)oi << 12) | ((u32)(px & 63) << 19) | ((u32)pair << 25);
+                        else misc[6] = SLOW_MAILBOX;
+                    }
+                }
+                if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; }
+                __syncthreads();
+                if (misc[6]) { hand_on(SLOW_MAILBOX); go = 2; }      // a crowded mailbox
+            }
+            __threadfence();
+            __syncthreads();
+            if (tid == 0) { atomicExch(&hdr[LH_FLAG], go); misc[9] = (int)go; }
+            __syncthreads();
+        } else {
+            if (tid == 0) {
+                u32 f = 0;
+                for (int it = 0; it < (1 << 19); ++it) {
+                    f = __atomic_load_n(&hdr[LH_FLAG], __ATOMIC_RELAXED);
+                    if (f) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+                misc[9] = (int)f;
+            }
+            __syncthreads();
+            __threadfence();
+        }
+        const int f = misc[9];
+        if (f != 1) {
+            // 2: the frame was handed on.  0: the wait ran out (a workgroup of the frame never arrived): say so, never go on
+            if (f == 0 && tid == 0) atomicMin((int*)&fstat[n * 8 + 2], VBS_EINTERNAL);
+            return;
+        }
+        if (tid < 16 && tid != 9) misc[tid] = 0;
+        __syncthreads();
+    }
+
+    // ================================ opened area plane =============================================================
+    unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
+    Q.q = pqg + (size_t)wg * LT_PQ;
+    {
+        const u64* A = area_all + fo;
+        auto ldraw = [&](int r) -> u64 {
+            const int y = min(max(y0 + r, 0), H - 1);
+            return A[(int64_t)y * WW + (act ? j : 0)];
+        };
+        auto rowval = [&](u64 raw, int r) -> u64 {
+            const int y = y0 + r;
+            return (act && y >= 0 && y < H) ? (raw | ~vm) : ~0ull;
+        };
+        u64 pf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) pf[i] = ldraw(-5 + i);
+        u64 e5[4] = {~0ull, ~0ull, ~0ull, ~0ull}, d5[4] = {0, 0, 0, 0};
+        u64 o1 = 0, o2 = 0;                              // the opened rows before the newest one
+        u32 l1 = 0, l2 = 0, r1 = 0, r2 = 0;              // bit 63 of the word to the left / bit 0 of the word to the right in those rows
+        // this thread's probe requests (in registers: a request read from memory where its row comes by would stall the wave)
+        u64 rowm[2] = {0, 0};                            // (R <= 128)
+        const u32 nreq = min(mbcnt[ftid], (u32)ST_MB_CAP);
+        u32 req[ST_MB_CAP];
+#pragma unroll
+        for (u32 q = 0; q < ST_MB_CAP; ++q) {
+            req[q] = q < nreq ? mbreq[ftid * ST_MB_CAP + q] : 0u;
+            if (q < nreq) {
+                const u32 rr = (req[q] >> 12) & 127u;
+                if (rr < 64) rowm[0] |= 1ull << rr; else rowm[1] |= 1ull << (rr - 64);
+            }
+        }
+        auto row_asked = [&](int c) -> bool { return ((c < 64 ? rowm[0] >> c : rowm[1] >> (c - 64)) & 1ull) != 0; };
+        u64 pm[SG_KO];
+        u32 sid[SG_KO];
+        int mo[SG_KO][NMOM];                             // vertex moments about the tile's centre
+#pragma unroll
+        for (int k = 0; k < SG_KO; ++k) {
+            pm[k] = 0; sid[k] = 0;
+#pragma unroll
+            for (int q = 0; q < NMOM; ++q) mo[k][q] = 0;
+        }
+        u32 nseg = 0, la = NONE16, lb = NONE16, p63 = NONE16, prs0 = NONE16;
+        u32 why = 0;
+        u64 firstB = 0;
+        int e4 = 0;
+        const int tch = R >> 1;
+        const int mthr = R <= 64 ? 900 : 56;             // vertices (with multiplicity) an entry may hold: its sums stay below 2^31
+        auto emit_mom = [&](u32 sid_, int (&m)[NMOM]) {
+            const int r = atomicAdd(&misc[7], 1);
+            if (r < LT_MREC) {
+                uint4* dst = reinterpret_cast<uint4*>(mrec + ((size_t)wg * LT_MREC + r) * 16);
+                dst[0] = make_uint4(sid_, (u32)m[0], (u32)m[1], (u32)m[2]);
+                dst[1] = make_uint4((u32)m[3], (u32)m[4], (u32)m[5], (u32)m[6]);
+                dst[2] = make_uint4((u32)m[7], (u32)m[8], (u32)m[9], (u32)m[10]);
+                dst[3] = make_uint4((u32)m[11], (u32)m[12], (u32)m[13], (u32)m[14]);
+            } else why = SLOW_SLOTS;
+#pragma unroll
+            for (int q = 0; q < NMOM; ++q) m[q] = 0;
+        };
+#pragma unroll 1
+        for (int q = 0; q < R + 10; ++q) {
+            const int r = q - 5;                         // source row of this step
+            const u64 v = rowval(pf[0], r);
+            pf[0] = pf[1]; pf[1] = pf[2]; pf[2] = pf[3]; pf[3] = ldraw(r + 4);
+            // vertical erosion over 5 rows -> row r - 2, horizontal erosion; nothing outside the image
+            u64 ve = v & e5[0] & e5[1] & e5[2] & e5[3];
+            e5[3] = e5[2]; e5[2] = e5[1]; e5[1] = e5[0]; e5[0] = v;
+            u64 er = 0;
+            if (r >= -1) {                               // (uniform: the eroded rows the tile's output rows reach)
+                const int ye = y0 + r - 2;
+                er = hwin<5, true>(ve, hasl, hasr);
+                er = (act && ye >= 0 && ye < H) ? (er & vm) : 0ull;
+            }
+            // vertical dilation over 5 rows -> row r - 4, horizontal dilation
+            const u64 vd = er | d5[0] | d5[1] | d5[2] | d5[3];
+            d5[3] = d5[2]; d5[2] = d5[1]; d5[1] = d5[0]; d5[0] = er;
+            const int rho = r - 4;                       // the opened row this step completes (relative to y0)
+            if (rho < -1) continue;                      // (uniform)
+            u64 o0 = hwin<5, false>(vd, hasl, hasr);
+            {
+                const int y = y0 + rho;
+                o0 = (act && y >= 0 && y < H) ? (o0 & vm) : 0ull;               // :195  morphologyEx(MORPH_OPEN, 5x5)
+            }
+            u32 l0 = dpp_shr1((u32)(o0 >> 63)), r0 = dpp_shl1((u32)o0 & 1u);
+            if (!hasl) l0 = 0;
+            if (!hasr) r0 = 0;
+            const int c = rho - 1;                       // the row to label now: its neighbours above and below are known
+            bool live = false;
+#pragma unroll
+            for (int k = 0; k < SG_KO; ++k) live |= pm[k] != 0ull;
+            // ---- Euler number by bit quads (8-connected foreground): E = (Q1 - Q3 - 2 QD) / 4 over all 2x2 windows of the
+            //      zero-padded image; a word counts the windows whose top row is its row (image row 0 also the padding row)
+            if (c >= 0) {
+                const bool top = (y0 + c) == 0;
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq) {
+                    if (qq == 1 && !top) continue;
+                    const u64 a = qq ? 0ull : o1, bq = qq ? o1 : o0;
+                    const u32 an = qq ? 0u : r1, bn = qq ? r1 : r0;
+                    if (a | bq | an | bn) {
+                        const u64 a1 = (a >> 1) | ((u64)an << 63), b1 = (bq >> 1) | ((u64)bn << 63);
+                        const u64 x2 = (a ^ a1) ^ (bq ^ b1);
+                        const u64 pairs = (a & a1) | (a & bq) | (a & b1) | (a1 & bq) | (a1 & b1) | (bq & b1);
+                        const u64 qd = (a & b1 & ~a1 & ~bq) | (a1 & bq & ~a & ~b1);
+                        e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
+                        if (j == 0) e4 += (int)((a ^ bq) & 1ull);           // window x = -1: only (0,y), (0,y+1)
+                    }
+                }
+            }
+            if (c >= 0 && __any(o1 != 0ull || live || row_asked(c))) {
+                const u64 B = o1;
+                if (c == 0) firstB = B;
+                // ---- segments ---------------------------------------------------------------------------------------------
+                const u64 rB = brev64(B);
+                u64 Rn[SG_KO];
+                const u64 claimed = seg_update<SG_KO, true, true>(B, rB, pm, sid, Rn, Q);
+#pragma unroll
+                for (int k = 0; k < SG_KO; ++k) pm[k] = Rn[k];
+                u64 N = B & ~claimed;
+                while (N) {
+                    const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                    N &= t2;
+                    bool done = false;
+#pragma unroll
+                    for (int k = 0; k < SG_KO; ++k) {
+                        if (!done && pm[k] == 0ull) {
+                            if (mo[k][0]) emit_mom(sid[k], mo[k]);
+                            if (nseg < SG_SEGMAX) {
+                                sid[k] = sbase + nseg;
+                                segpos[sbase + nseg] = (u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
+                            } else why = SLOW_SLOTS;
+                            ++nseg;
+                            pm[k] = gg;
+                            done = true;
+                        }
+                    }
+                    if (!done) why = SLOW_SLOTS;
+                }
+                if (__any(((B >> 63) | B) & 1ull)) seg_hlinks<SG_KO, true>(pm, sid, hasr, p63, prs0, la, lb, Q);
+                else { p63 = NONE16; prs0 = NONE16; }    // (no pixel at a word edge in this row: nothing for the next row to meet)
+                // ---- probes: the segment that holds a pixel of this row ---------------------------------------------------
+                if (row_asked(c)) {
+#pragma unroll
+                    for (u32 qq = 0; qq < ST_MB_CAP; ++qq) {
+                        const u32 rq = req[qq];
+                        if (qq >= nreq || ((rq >> 12) & 127u) != (u32)c) continue;
+                        const u32 q0 = (rq >> 10) & 3u;
+                        for (u32 d = 0; d <= ((rq >> 25) & 1u); ++d) {
+                            const u32 kb = ((rq >> 19) & 63u) + d;
+                            u32 s = NONE16;
+#pragma unroll
+                            for (int k = 0; k < SG_KO; ++k)
+                                if ((pm[k] >> kb) & 1ull) s = sid[k];
+                            pr[(rq & 1023u) * 4 + q0 + d] = (unsigned short)s;
+                        }
+                    }
+                }
+                // ---- contour vertices -------------------------------------------------------------------------------------
+                if (__any(B != 0ull)) {
+                    const u64 D0 = (B >> 1) | ((u64)r1 << 63), D4 = (B << 1) | (u64)l1;
+                    const u64 D2 = o2, D1 = (o2 >> 1) | ((u64)r2 << 63), D3 = (o2 << 1) | (u64)l2;
+                    const u64 D6 = o0, D7 = (o0 >> 1) | ((u64)r0 << 63), D5 = (o0 << 1) | (u64)l0;
+#define KEPT_EVEN(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ((Dp1) | (Dp2) | ~(Dp3)))
+#define KEPT_ODD(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ~(Dp1) & ((Dp2) | ~(Dp3)))
+                    const u64 k0 = KEPT_EVEN(D0, D7, D1, D2, D3), k1 = KEPT_ODD(D1, D0, D2, D3, D4);
+                    const u64 k2 = KEPT_EVEN(D2, D1, D3, D4, D5), k3 = KEPT_ODD(D3, D2, D4, D5, D6);
+                    const u64 k4 = KEPT_EVEN(D4, D3, D5, D6, D7), k5 = KEPT_ODD(D5, D4, D6, D7, D0);
+                    const u64 k6 = KEPT_EVEN(D6, D5, D7, D0, D1), k7 = KEPT_ODD(D7, D6, D0, D1, D2);
+#undef KEPT_EVEN
+#undef KEPT_ODD
+                    const u64 iso = ~(D0 | D1 | D2 | D3 | D4 | D5 | D6 | D7);    // an isolated pixel is written once
+                    u64 V1 = k0, V2 = 0, V3 = 0;
+#define ADDP(Kp) { V3 |= V2 & (Kp); V2 |= V1 & (Kp); V1 |= (Kp); }
+                    ADDP(k1) ADDP(k2) ADDP(k3) ADDP(k4) ADDP(k5) ADDP(k6) ADDP(k7) ADDP(iso)
+#undef ADDP
+                    V1 &= B; V2 &= B; V3 &= B;
+                    if (V3) why = SLOW_VERTEX;            // multiplicity > 2: impossible after a 5x5 opening; general path
+                    const int tc = c - tch, tc2 = __mul24(tc, tc), tc3 = __mul24(tc2, tc), tc4 = tc2 * tc2;
+#pragma unroll
+                    for (int k = 0; k < SG_KO; ++k) {
+                        u64 vg = V1 & pm[k];
+                        if (!__any(vg != 0ull)) continue;
+                        if (vg) {
+                            int s0 = 0, s1 = 0, s2 = 0, s3 = 0, s4 = 0;
+                            auto half = [&](u32 bits, int base) {
+                                while (bits) {
+                                    const int dx = __ffs((int)bits) - 1 + base;
+                                    bits &= bits - 1u;
+                                    const int x2 = __mul24(dx, dx);
+                                    s0 += 1; s1 += dx; s2 += x2; s3 += __mul24(x2, dx); s4 += __mul24(x2, x2);
+                                }
+                            };
+                            half((u32)vg, -32);
+                            half((u32)(vg >> 32), 0);
+                            const u64 v2 = vg & V2;
+                            if (v2) { half((u32)v2, -32); half((u32)(v2 >> 32), 0); }
+                            int (&m)[NMOM] = mo[k];
+                            if (m[0] > mthr) emit_mom(sid[k], m);
+                            m[0] += s0;                    m[1] += s1;                    m[2] += __mul24(s0, tc);
+                            m[3] += s2;                    m[4] += __mul24(s1, tc);       m[5] += __mul24(s0, tc2);
+                            m[6] += s3;                    m[7] += __mul24(s2, tc);       m[8] += __mul24(s1, tc2);
+                            m[9] += __mul24(s0, tc3);      m[10] += s4;                   m[11] += s3 * tc;
+                            m[12] += __mul24(s2, tc2);     m[13] += __mul24(s1, tc3);     m[14] += s0 * tc4;
+                        }
+                    }
+                }
+            } else if (c >= 0) {
+                p63 = NONE16; prs0 = NONE16;             // an empty row: nothing to link the next one with
+            }
+            o2 = o1; o1 = o0; l2 = l1; l1 = l0; r2 = r1; r1 = r0;
+        }
+#pragma unroll
+        for (int k = 0; k < SG_KO; ++k) {
+            if (mo[k][0]) emit_mom(sid[k], mo[k]);
+            if (act) { botm[(size_t)k * FT + bj] = pm[k]; bots[(size_t)k * FT + bj] = (unsigned short)sid[k]; }
+        }
+        nsegG[FT + ftid] = (unsigned char)min(nseg, (u32)SG_SEGMAX);
+        firstG[FT + ftid] = firstB;
+        if (e4) atomicAdd(&misc[0], e4);
+        if (why) misc[6] = (int)why;
+        __syncthreads();
+        if (tid == 0) {
+            if (misc[5] > LT_PQ) misc[6] = SLOW_SLOTS;
+            hdr[LH_NMREC + wg] = (u32)min(misc[7], LT_MREC);
+            hdr[LH_NPQO + wg] = (u32)min(misc[5], LT_PQ);
+            if (misc[0]) atomicAdd(&hdr[LH_EULER], (u32)misc[0]);
+            if (misc[6]) atomicMax(&hdr[LH_WHY], (u32)misc[6]);
+        }
+    }
+    if (!arrive(LH_ARRIVE2)) return;
+    // ---- the frame's opened components, by this workgroup alone --------------------------------------------------------
+    {
+        const u32 whyw = __atomic_load_n(&hdr[LH_WHY], __ATOMIC_RELAXED);
+        if (whyw) { hand_on(16u + whyw); return; }
+    }
+    const u32 nband = ncomp_all[n * 2 + 0];
+    const u32 ncomp = lat_resolve<SG_KO, true>(geo, P, nsegL, nsegG + FT, firstG + FT, botm, bots, pqg, hdr + LH_NPQO, nullptr, nullptr,
+                                               nullptr, segpos, comp_pos, cidmap, tmp, min((u32)maxm, (u32)CCL_OPEN_COMPS));
+    if (ncomp == NONE32) { hand_on(16u + SLOW_NCOMP); return; }
+    if ((int)ncomp - (int)__atomic_load_n(&hdr[LH_EULER], __ATOMIC_RELAXED) / 4 != 0) {      // holes: RETR_EXTERNAL needs the fill passes of the general path
+        hand_on(16u + SLOW_HOLES);
+        return;
+    }
+    // ---- the component's first pixel (the moments' origin) -------------------------------------------------------------
+    u32* anchor = reinterpret_cast<u32*>(accb);                                          // [CCL_OPEN_COMPS]  (y << 16) | x
+    u64* acc = reinterpret_cast<u64*>(accb + 4 * CCL_OPEN_COMPS);                         // [mom_comps][NMOM]
+    {
+        u32* first = area_first + (int64_t)n * maxm;
+        for (u32 c = tid; c < ncomp; c += LT_NT) {
+            const u32 pos = comp_pos[c], cid = cidmap[c], py = pos / (u32)W;
+            anchor[cid] = (py << 16) | (pos - py * (u32)W);
+            first[cid] = pos;
+        }
+    }
+    // ---- segment moments -> component moments about its first pixel, `mom_comps` components per pass -----------------------------
+    i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
+    for (u32 c0 = 0; c0 < ncomp; c0 += geo.mom_comps) {
+        const u32 nc = min(geo.mom_comps, ncomp - c0);
+        for (u32 c = tid; c < nc * NMOM; c += LT_NT) acc[c] = 0;
+        __syncthreads();
+        for (int w = 0; w < C; ++w) {
+            const u32 nm = hdr[LH_NMREC + w];
+            for (u32 r = tid; r < nm; r += LT_NT) {
+                const uint4* src = reinterpret_cast<const uint4*>(mrec + ((size_t)w * LT_MREC + r) * 16);
+                const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+                const u32 s = w0.x, cid = (u32)cidmap[P[s] & 0x7FFFu] - c0;
+                if (cid >= nc) continue;                 // another pass's component
+                const u32 ot = s / SG_SEGMAX, ol = ot & 63u, og = ol / (u32)WW;         // the thread that wrote it: its tile
+                const int ox = 64 * (int)(ol - og * (u32)WW) + 32, oy = (int)((ot >> 6) * (u32)G + og) * R + (R >> 1);
+                const u32 fp = anchor[cid + c0];
+                const i64 m[NMOM] = {(int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w, (int)w2.x,
+                                     (int)w2.y, (int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y, (int)w3.z, (int)w3.w};
+                i64 o[NMOM];
+                shift_moments_i64(m, (i64)(ox - (int)(fp & 0xFFFFu)), (i64)(oy - (int)(fp >> 16)), o);
+                u64* a = acc + cid * NMOM;
+#pragma unroll
+                for (int q = 0; q < NMOM; ++q)
+                    if (o[q]) atomicAdd(&a[q], (u64)o[q]);
+            }
+        }
+        __syncthreads();
+        for (u32 c = tid; c < nc * NMOM; c += LT_NT) as[(c0 + c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
+        __syncthreads();
+    }
+    // ---- probes: segment -> component ----------------------------------------------------------------------------------
+    for (u32 e = tid; e < nband * 4; e += LT_NT) {
+        const u32 v = pr[e];
+        if (v != NONE16) pr[e] = cidmap[P[v] & 0x7FFFu];
+    }
+    if (tid == 0) { ncomp_all[n * 2 + 1] = ncomp; fstat[n * 8 + 6] = ncomp; fstat[n * 8 + 4] = 0; }
+}
+
+// ---- host side ----------------------------------------------------------------------------------------------------
+// false = geometry outside this path
+static bool lat_geom(const vbs_handle* h, LatGeom* g, size_t* lds_bytes) {
+    if (h->W > 4096 || h->H > 2048 || h->maxm > 1024) return false;
+    const int G = 64 / h->WW;                            // (WW <= 64: vbs_create)
+    const int NW = (h->H + LT_ROWS * G - 1) / (LT_ROWS * G);
+    int C = (NW + 3) / 4;
+    if (C > LT_CMAX) C = LT_CMAX;
+    if (C < 1) C = 1;
+    const int NB = 4 * C * G, R = (h->H + NB - 1) / NB;
+    if (R > 128 || R < 1) return false;
+    g->H = h->H; g->W = h->W; g->WW = h->WW; g->G = G; g->NB = NB; g->R = R; g->C = C; g->FT = LT_NT * C; g->maxm = h->maxm;
+    g->mom_comps = (u32)CCL_MOM_COMPS;
+    const size_t FT = (size_t)g->FT;
+    auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
+    size_t o = 0;
+    auto take = [&](size_t bytes) { const size_t at = o; o += up16(bytes); return (u32)at; };
+    g->o_nseg = take(2 * FT);
+    g->o_first = take(2 * FT * 8);
+    g->o_botm = take(4 * FT * 8);
+    g->o_bots = take(4 * FT * 2);
+    g->o_rsid = take((size_t)C * LT_REC * 2);
+    g->o_rpos = take((size_t)C * LT_REC * 4);
+    g->o_rcnt = take((size_t)C * LT_REC * 4);
+    g->o_rsx = take((size_t)C * LT_REC * 4);
+    g->o_rsy = take((size_t)C * LT_REC * 4);
+    g->o_pq = take((size_t)C * LT_PQ * 4);
+    g->o_segpos = take(8 * FT * 4);
+    g->o_mbcnt = take(FT * 4);
+    g->o_mbreq = take(FT * ST_MB_CAP * 4);
+    g->o_mrec = take((size_t)C * LT_MREC * 64);
+    g->stride = (u32)((o + 255) / 256 * 256);
+    // LDS of the resolving workgroup
+    const size_t par = up16(8 * FT * 2);
+    const size_t acc_band = up16((size_t)(8 * ((h->maxm + 1) / 2)) + 16 * (size_t)h->maxm);
+    const size_t acc_open = up16((size_t)4 * CCL_OPEN_COMPS + (size_t)g->mom_comps * NMOM * 8);
+    g->l_nseg = (u32)par;
+    g->l_comp = (u32)(par + up16(FT));
+    g->l_acc = g->l_comp + 4096 + 2048;
+    g->l_tmp = (u32)(g->l_acc + (acc_band > acc_open ? acc_band : acc_open));
+    *lds_bytes = g->l_tmp + 64;
+    return *lds_bytes <= 160 * 1024;
+}
+
+// bytes of per-frame scratch this geometry needs (vbs_create allocates VBS_LAT_MAXN of them); 0 = outside the path
+size_t stage_lat_scratch(const vbs_handle* h) {
+    LatGeom g;
+    size_t lds;
+    return lat_geom(h, &g, &lds) ? (size_t)g.stride : 0;
+}
+
+template <int NS>
+static bool stage_lat_launch_t(vbs_handle* h, int nb, const LatGeom& g, size_t lds, hipStream_t s) {
+    if (lds > h->lat_lds_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage_lat<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds) != hipSuccess) {
+            (void)hipGetLastError();
+            return false;
+        }
+        h->lat_lds_set = lds;
+    }
+    VBS_LAUNCH(h, s, "k_stage_lat", (k_stage_lat<NS>), dim3(g.C, nb), dim3(LT_NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
+               h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, h->slow_total, h->lat_hdr,
+               h->lat_scratch, g);
+    return true;
+}
+
+// The few-frames form of launch_stage.  The caller has cleared the frames' headers (h->lat_hdr) on `s`.
+// false: not for this pass (more than VBS_LAT_MAXN frames, geometry outside the path, no scratch)
+bool launch_stage_lat(vbs_handle* h, int nb, hipStream_t s) {
+    LatGeom g;
+    size_t lds = 0;
+    if (nb > VBS_LAT_MAXN || !h->lat_scratch || !lat_geom(h, &g, &lds)) return false;
+    return h->bp.ns == 14 ? stage_lat_launch_t<14>(h, nb, g, lds, s) : stage_lat_launch_t<8>(h, nb, g, lds, s);
+}
