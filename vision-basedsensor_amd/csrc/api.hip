@@ -805,3 +805,14 @@ extern "C" int vbs_assign_ids(vbs_handle* h, const double* det, const int32_t* c
     launch_assign_ids(h, det, count, num_layers, id_mode, ids, ref_xy, cap, m_out, (hipStream_t)stream);
     return check_launch(h);
 }
+
+#ifdef VBS_DEBUG_KNOBS
+// tools/ builds only: k_stage_lat's per-frame header words of the last pass (phase stamps in words 80..), synchronising
+extern "C" int vbs_debug_lat_hdr(vbs_handle* h, uint32_t* out, int frames) {
+    if (!h || !out || frames < 1 || frames > VBS_LAT_MAXN) return VBS_EINVAL;
+    vbs_handle* w = last_ws(h);
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemcpy(out, w->lat_hdr, (size_t)frames * VBS_LAT_HDR * sizeof(u32), hipMemcpyDeviceToHost));
+    return VBS_OK;
+}
+#endif

@@ -3,16 +3,21 @@
 //
 // k_stage labels a frame on ONE compute unit - the right shape for a batch (one frame per CU, 256 CUs), 190 us for a
 // single frame.  Here a thread's tile is 64 px x ~8 rows instead of x 29, a frame has 256 C threads (C = 11 at
-// 1280x1024) and every wave has a SIMD to itself; what the workgroups of a frame share lives in global memory:
+// 1280x1024) and every wave has a SIMD to itself; what the workgroups of a frame share goes through global memory - and
+// a workgroup on another XCD sees it only through memory, at 1 - 3 us per dependent access, so everything shared is a flat
+// list that is read with many independent loads in flight, never a table that is chased:
 //   walk      as k_stage (same helpers, stage_common.h): rows through register delay lines, segments in slots, what
-//             crosses a tile only NOTED.  Records, pairs and moment records go to the workgroup's own region of the
-//             frame's scratch (index from an LDS counter: no global atomic on the walk), last-row slots, first rows and
-//             segment counts to per-thread cells.
+//             crosses a tile only NOTED as a pair.  The link between a tile and the tile BELOW it is made by the upper tile's
+//             thread, which computes the first row of the tile below itself (one more row step; the opened walk has that
+//             row anyway) and knows that tile's segment ids - its first row's runs are its segments 0, 1, .. in order.
+//             Records, pairs, segment first pixels and moment records go to the workgroup's own region of the frame's
+//             scratch (index from an LDS counter: no global atomic on the walk).
 //   resolve   the LAST workgroup of a frame to finish a walk (an arrival counter, nobody waits for a workgroup that has
-//             not started) does what k_stage does after it, alone: parents in its LDS, tile links + queued pairs,
-//             flatten, number the roots, first pixel, rank, sums.  After the band walk the other workgroups of the frame
-//             wait for it (the probe requests of the opened walk come out of the band centroids); after the opened walk
-//             they simply leave.  A wait that expires reports VBS_EINTERNAL in the frame's status, never a wrong table.
+//             not started) does what k_stage does after it, alone: parents in its LDS, the queued pairs, flatten, number
+//             the roots, first pixel, rank, sums.  After the band walk the other workgroups of the frame wait for it (the
+//             probe requests of the opened walk come out of the band centroids: a list every wave filters for its own
+//             lanes); after the opened walk they simply leave.  A wait that expires reports VBS_EINTERNAL in the frame's
+//             status, never a wrong table.
 // Results are bit-identical to k_stage's (tests/test_gpu_parity.py::test_latency_stage_equals_the_batch_stage), frames
 // it cannot take are handed on with the same slow flags.
 #include "stage_common.h"
@@ -20,8 +25,11 @@
 #define LT_NT 256                  // threads per workgroup: four waves, one per SIMD
 #define LT_CMAX 16                 // workgroups per frame, at most: segment ids 8 x 256 x 16 = 2^15 (bit 15 marks a root)
 #define LT_REC 512                 // band segment records per workgroup
-#define LT_PQ 1024                 // queued pairs per workgroup and walk
+#define LT_PQ 1024                 // queued pairs per workgroup and walk (LDS)
+#define LT_XPQ 512                 // of them, pairs that reach into another workgroup's segments (global)
 #define LT_MREC 512                // moment records per workgroup
+#define LT_SEG (LT_NT * SG_SEGMAX) // opened segments per workgroup (every one of them)
+#define LT_REQ 4096                // probe requests per frame (4 per band component)
 #define LT_ROWS 8                  // rows per thread aimed at
 // header words of a frame (VBS_LAT_HDR each, cleared by launch_labelling's fill together with the slow flags)
 #define LH_ARRIVE1 0
@@ -29,17 +37,28 @@
 #define LH_FLAG 2                  // 1: band components are out, go on; 2: the frame was handed on, leave
 #define LH_WHY 3
 #define LH_EULER 4
-#define LH_NREC 16                 // [C] band records / pairs of the band walk / moment records / pairs of the opened walk
+#define LH_NREQ 5                  // probe requests in the list
+#define LH_NREC 16                 // [C] band records / pairs of the band walk / moment records / pairs of the opened walk / opened segments
 #define LH_NPQB 32
 #define LH_NMREC 48
 #define LH_NPQO 64
+#define LH_NSEG 80
+
+// tools/ builds: wall-clock stamps (100 MHz) of the phases in header words 96.., read with vbs_debug_lat_hdr (tools/gpu_lat_trace.py)
+#ifdef VBS_DEBUG_KNOBS
+#define LT_STAMP(slot) do { if (tid == 0) atomicMax(&hdr[96 + (slot)], (u32)wall_clock64()); } while (0)
+#define LT_STAMP_MIN(slot) do { if (tid == 0) atomicMax(&hdr[96 + (slot)], ~(u32)wall_clock64()); } while (0)
+#else
+#define LT_STAMP(slot)
+#define LT_STAMP_MIN(slot)
+#endif
 
 struct LatGeom {
     int H, W, WW, G, NB, R, C, FT, maxm;                  // FT = 256 C threads per frame, NB = 4 C G row blocks of R rows
     u32 mom_comps;
     u32 stride;                                           // bytes of scratch per frame
-    u32 o_nseg, o_first, o_botm, o_bots, o_rsid, o_rpos, o_rcnt, o_rsx, o_rsy, o_pq, o_segpos, o_mbcnt, o_mbreq, o_mrec;
-    u32 l_nseg, l_comp, l_acc, l_tmp;                     // byte offsets into the dynamic LDS (parents at 0)
+    u32 o_nseg, o_rsid, o_rpos, o_rcnt, o_rsx, o_rsy, o_pq, o_lroot, o_seg, o_req, o_mrec;       // byte offsets into it
+    u32 l_nseg, l_comp, l_acc, l_mbc, l_tmp;              // byte offsets into the dynamic LDS (parents at 0)
 };
 
 // exclusive prefix sum over the LT_NT threads; tmp holds >= 8 words
@@ -62,7 +81,7 @@ __device__ __forceinline__ u32 lt_scan(u32 v, u32* tmp, u32* total) {
 }
 
 // the tile of frame-thread ft
-struct LatTile { int g, j, blk, bj; bool act, hasl, hasr, hasu; };
+struct LatTile { int g, j, blk; bool act, hasl, hasr; u32 below; };   // below: frame-thread of the tile under this one
 __device__ __forceinline__ LatTile lat_tile(u32 ft, int WW, int G) {
     LatTile t;
     const int lane = (int)(ft & 63u);
@@ -70,97 +89,157 @@ __device__ __forceinline__ LatTile lat_tile(u32 ft, int WW, int G) {
     t.act = t.g < G;
     t.blk = (int)(ft >> 6) * G + t.g;
     t.hasl = t.j > 0; t.hasr = t.act && t.j + 1 < WW;
-    t.hasu = t.act && t.blk > 0;
-    t.bj = t.act ? t.blk * WW + t.j : 0;
+    t.below = t.g + 1 < G ? ft + (u32)WW : (((ft >> 6) + 1u) << 6) + (u32)t.j;
     return t;
 }
 
-// After a walk, by ONE workgroup: the components of the frame's segments.  P (LDS) = parents over 8 FT segment ids; the
-// unions are the first row of every tile against the last-row slots of the tile above (C8: with the diagonal neighbours
-// across the word edges) and the pairs the walks queued.  Then as k_stage's seg_resolve: flatten, number the roots (an
-// entry becomes its root's number, bit 15 marks the root), comp_pos[c] = first pixel of component c (band: minimum over
-// its records' first pixels; opened: over its segments'), cidmap[c] = rank of that pixel = the component's id.
-// Workgroup-uniform return: components, or NONE32 when there are more than `limit`.
-template <int K, bool C8>
-__device__ __forceinline__ u32 lat_resolve(const LatGeom& geo, unsigned short* P, unsigned char* nsegL,
-                                           const unsigned char* nsegG, const u64* firstG, const u64* botm,
-                                           const unsigned short* bots, const u32* pq, const u32* npq,
-                                           const unsigned short* rsid, const u32* rpos, const u32* nrec, const u32* segpos,
-                                           u32* comp_pos, unsigned short* cidmap, u32* tmp, u32 limit) {
-    const int tid = threadIdx.x;
-    const u32 FT = (u32)geo.FT, NS = 8u * FT;
-    const int WW = geo.WW;
-    for (u32 s = tid; s < NS; s += LT_NT) P[s] = (unsigned short)s;
-    for (u32 ft = tid; ft < FT; ft += LT_NT) nsegL[ft] = nsegG[ft];
-    __syncthreads();
-    for (u32 ft = tid; ft < FT; ft += LT_NT) {
-        const LatTile t = lat_tile(ft, WW, geo.G);
-        if (!t.hasu) continue;
-        u64 N = firstG[ft];
-        u32 i = 0;
-        const int up = t.bj - WW;
-        while (N) {                                      // the runs of the tile's first row are its segments 0, 1, .. in order
-            const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
-            N &= t2;
-            const u64 ga = C8 ? (gg | (gg << 1) | (gg >> 1)) : gg;
+// The items of C per-workgroup regions (cnt[w] of them in region w, `cap` slots apart) as one flat list over the workgroup's
+// threads, U items per thread in flight: every load of a round is issued before the first item is used (a region
+// written on another XCD answers from memory).  pre (LDS, C + 1 words) = exclusive prefix of the counts.
+template <int U, class LD, class USE>
+__device__ __forceinline__ void lat_flat(const u32* pre, int C, u32 cap, LD ld, USE use) {
+    const u32 total = pre[C];
+    for (u32 i0 = threadIdx.x; i0 < total; i0 += LT_NT * U) {
+        decltype(ld((size_t)0)) v[U];
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                if (ga & botm[(size_t)k * FT + up]) ccl_union(P, 8u * ft + i, bots[(size_t)k * FT + up]);
-                if (C8) {
-                    if ((gg & 1ull) && t.hasl && (botm[(size_t)k * FT + up - 1] >> 63)) ccl_union(P, 8u * ft + i, bots[(size_t)k * FT + up - 1]);
-                    if ((gg >> 63) && t.hasr && (botm[(size_t)k * FT + up + 1] & 1ull)) ccl_union(P, 8u * ft + i, bots[(size_t)k * FT + up + 1]);
-                }
+        for (int u = 0; u < U; ++u) {
+            const u32 i = i0 + (u32)u * LT_NT;
+            if (i < total) {
+                u32 w = 0;
+                for (int c = 1; c < C; ++c) w += i >= pre[c];
+                v[u] = ld((size_t)w * cap + (i - pre[w]));
             }
-            ++i;
         }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (i0 + (u32)u * LT_NT < total) use(v[u]);
     }
-    for (int w = 0; w < geo.C; ++w) {
-        const u32 np = min(npq[w], (u32)LT_PQ);
-        for (u32 i = tid; i < np; i += LT_NT) { const u32 pr = pq[(size_t)w * LT_PQ + i]; ccl_union(P, pr >> 16, pr & 0xFFFFu); }
+}
+// pre[0 .. C] <- exclusive prefix of cnt[0 .. C) (global), every count clipped to cap
+__device__ __forceinline__ void lat_prefix(const u32* cnt, int C, u32 cap, u32* pre) {
+    __syncthreads();
+    if (threadIdx.x < (unsigned)C) pre[threadIdx.x + 1] = min(cnt[threadIdx.x], cap);
+    __syncthreads();
+    if (threadIdx.x == 0) { pre[0] = 0; for (int c = 1; c <= C; ++c) pre[c] += pre[c - 1]; }
+    __syncthreads();
+}
+
+// End of a walk, every workgroup for itself: the queued pairs between two of ITS OWN segments are united here, in its
+// LDS, by all workgroups at once (a pair costs a chain of dependent LDS accesses; 2 600 of them per frame are ten per thread
+// of one workgroup and one per thread when every workgroup takes its own); what goes out is every segment's root within
+// the workgroup (lroot, a global id) and the few pairs that reach into another workgroup - the links of its last row
+// block with the first of the next.
+__device__ __forceinline__ void lat_local(unsigned short* Pl, const u32* lpq, int npairs, u32 base, u32 nseg, u32* xpq, int* nx,
+                                          unsigned short* lroot_out) {
+    const int tid = threadIdx.x;
+    {
+        const u32 b = 8u * (u32)tid;
+        reinterpret_cast<uint4*>(Pl)[tid] = make_uint4(b | ((b + 1u) << 16), (b + 2u) | ((b + 3u) << 16), (b + 4u) | ((b + 5u) << 16),
+                                                       (b + 6u) | ((b + 7u) << 16));
     }
     __syncthreads();
-    auto valid = [&](u32 s) -> bool { return (s & 7u) < (u32)nsegL[s >> 3]; };
-    for (u32 s = tid; s < NS; s += LT_NT) {              // flatten (no halving: a late store must be a root)
-        if (!valid(s)) continue;
-        u32 x = s, p;
-        while ((p = ((volatile unsigned short*)P)[x]) != x) x = p;
-        if (x != s) P[s] = (unsigned short)x;
+    for (int i = tid; i < npairs; i += LT_NT) {
+        const u32 pr = lpq[i], a = (pr >> 16) - base, b = (pr & 0xFFFFu) - base;
+        if (a < (u32)LT_SEG && b < (u32)LT_SEG) ccl_union(Pl, a, b);
+        else { const int k = atomicAdd(nx, 1); if (k < LT_XPQ) xpq[k] = pr; }
     }
     __syncthreads();
-    const u32 per = NS / LT_NT, s0 = (u32)tid * per;     // a contiguous run of ids per thread: the roots are numbered in id order
+    u32 r[SG_SEGMAX];
+#pragma unroll
+    for (u32 i = 0; i < SG_SEGMAX; ++i) {                // (read only: nobody writes until every root is found)
+        u32 x = 8u * (u32)tid + i;
+        if (i < nseg) { u32 p; while ((p = Pl[x]) != x) x = p; }
+        r[i] = base + x;
+    }
+    reinterpret_cast<uint4*>(lroot_out)[tid] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+}
+
+// After a walk, by ONE workgroup: the components of the frame's segments.  P (LDS) = parents over 8 FT segment ids, starting
+// from every segment's root within its workgroup (lroot); the unions are the pairs between workgroups.  Then as
+// k_stage's seg_resolve - roots numbered (an entry becomes its root's number, bit 15 marks the root) - but a tile's
+// eight entries at a time: one wide read, eight independent chains (one workgroup's four waves cannot hide the latency of
+// 2 000 chains taken one after the other).  The caller fills comp_pos[c] = first pixel of component c; lat_rank turns it into
+// cidmap[c] = rank of that pixel = the component's id.  Workgroup-uniform return: components, or NONE32 when there are
+// more than `limit`.
+__device__ __forceinline__ u32 lat_resolve(const LatGeom& geo, unsigned short* P, unsigned char* nsegL, const unsigned char* nsegG,
+                                           const unsigned short* lroot, const u32* xpq, const u32* nxpq, u32* comp_pos, u32* pre,
+                                           u32* tmp, u32 limit, u32* hdr, int st0) {
+    const int tid = threadIdx.x;
+    const u32 FT = (u32)geo.FT;
+    uint4* P128 = reinterpret_cast<uint4*>(P);
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(lroot);
+#pragma unroll
+        for (int k = 0; k < LT_CMAX; ++k)                // (unrolled: the loads are issued together)
+            if ((u32)k * LT_NT + tid < FT) P128[(u32)k * LT_NT + tid] = src[(u32)k * LT_NT + tid];
+        const u32* ns = reinterpret_cast<const u32*>(nsegG);
+        u32* dst = reinterpret_cast<u32*>(nsegL);
+        for (u32 i = tid; i < FT / 4; i += LT_NT) dst[i] = ns[i];
+    }
+    lat_prefix(nxpq, geo.C, LT_XPQ, pre);
+    LT_STAMP(st0);
+    lat_flat<4>(pre, geo.C, LT_XPQ, [&](size_t o) { return xpq[o]; },
+                [&](u32 pr) { ccl_union(P, pr >> 16, pr & 0xFFFFu); });
+    __syncthreads();
+    LT_STAMP(st0 + 1);
+    // every segment's root, tile by tile (tile k LT_NT + tid).  A tile's roots are stored while other threads still follow
+    // chains: what they meet is the old parent or the root, both ancestors (no halving: a late store must be a root)
     u32 nroot = 0;
-    for (u32 s = s0; s < s0 + per; ++s) nroot += valid(s) && P[s] == s;
-    u32 ncomp;
-    u32 c0 = lt_scan(nroot, tmp, &ncomp);
-    if (ncomp > limit) return NONE32;
-    for (u32 s = s0; s < s0 + per; ++s)
-        if (valid(s) && P[s] == s) { comp_pos[c0] = NONE32; P[s] = (unsigned short)(0x8000u | c0++); }
-    __syncthreads();
-    for (u32 s = tid; s < NS; s += LT_NT) {
-        if (!valid(s)) continue;
-        const u32 v = P[s];
-        if (!(v & 0x8000u)) P[s] = (unsigned short)(P[v] & 0x7FFFu);
-    }
-    __syncthreads();
-    if (segpos) {
-        for (u32 s = tid; s < NS; s += LT_NT)
-            if (valid(s)) atomicMin(&comp_pos[P[s] & 0x7FFFu], segpos[s]);
-    } else {
-        for (int w = 0; w < geo.C; ++w) {
-            const u32 nr = min(nrec[w], (u32)LT_REC);
-            for (u32 r = tid; r < nr; r += LT_NT)
-                atomicMin(&comp_pos[P[rsid[(size_t)w * LT_REC + r]] & 0x7FFFu], rpos[(size_t)w * LT_REC + r]);
+#pragma unroll
+    for (int k = 0; k < LT_CMAX; ++k) {
+        const u32 ft = (u32)k * LT_NT + tid;
+        const u32 ns = ft < FT ? (u32)nsegL[ft] : 0u;
+        const uint4 w = ft < FT ? P128[ft] : make_uint4(0, 0, 0, 0);
+        u32 r[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+#pragma unroll
+        for (u32 i = 0; i < 8; ++i) {
+            if (i < ns) {
+                u32 x = r[i], p;
+                while ((p = P[x]) != x) x = p;
+                r[i] = x;
+                nroot += x == 8u * ft + i;
+            }
         }
+        if (ns) P128[ft] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+    }
+    LT_STAMP(st0 + 2);
+    u32 ncomp;
+    u32 c0 = lt_scan(nroot, tmp, &ncomp);                 // (its barriers: every root is found before the first number is written)
+    if (ncomp > limit) return NONE32;
+#pragma unroll
+    for (int k = 0; k < LT_CMAX; ++k) {
+        const u32 ft = (u32)k * LT_NT + tid;
+        const u32 ns = ft < FT ? (u32)nsegL[ft] : 0u;
+        const uint4 w = ns ? P128[ft] : make_uint4(0, 0, 0, 0);
+        const u32 r[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+#pragma unroll
+        for (u32 i = 0; i < 8; ++i)
+            if (i < ns && r[i] == 8u * ft + i) { comp_pos[c0] = NONE32; P[8u * ft + i] = (unsigned short)(0x8000u | c0++); }
     }
     __syncthreads();
-    for (u32 c = tid; c < ncomp; c += LT_NT) {           // rank by first pixel (positions are distinct)
+#pragma unroll
+    for (int k = 0; k < LT_CMAX; ++k) {
+        const u32 ft = (u32)k * LT_NT + tid;
+        const u32 ns = ft < FT ? (u32)nsegL[ft] : 0u;
+        const uint4 w = ns ? P128[ft] : make_uint4(0, 0, 0, 0);
+        u32 r[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
+#pragma unroll
+        for (u32 i = 0; i < 8; ++i)
+            if (i < ns && !(r[i] & 0x8000u)) r[i] = P[r[i]] & 0x7FFFu;       // (a root already holds its number and its mark)
+        if (ns) P128[ft] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+    }
+    __syncthreads();
+    return ncomp;
+}
+__device__ __forceinline__ void lat_rank(const u32* comp_pos, unsigned short* cidmap, u32 ncomp) {
+    __syncthreads();
+    for (u32 c = threadIdx.x; c < ncomp; c += LT_NT) {   // rank by first pixel (positions are distinct)
         const u32 p = comp_pos[c];
         u32 rank = 0;
         for (u32 q = 0; q < ncomp; ++q) rank += comp_pos[q] < p;
         cidmap[c] = (unsigned short)rank;
     }
     __syncthreads();
-    return ncomp;
 }
 
 template <int NS>
@@ -173,43 +252,47 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                                                         LatGeom geo) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int misc[16];         // [0] Euler sum, [4] records, [5] queued pairs, [6] why the frame is handed on, [7] moment records,
-                                     // [8] this workgroup is the last of its frame, [9] the flag the others waited for
+                                     // [8] this workgroup is the last of its frame, [9] the flag the others waited for, [10] opened segments
+    __shared__ u32 lmb_cnt[LT_NT], lmb[LT_NT * ST_MB_CAP];       // this workgroup's probe requests, by owner thread
+    __shared__ u32 lpq[LT_PQ];                                   // the pairs this workgroup's walk queues
+    __shared__ __align__(16) unsigned short Pl[LT_SEG];          // parents over its own segments (lat_local)
     unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [8 FT] segment parents (resolving workgroup)
     unsigned char* nsegL = smem + geo.l_nseg;                                            // [FT]
     u32* comp_pos = reinterpret_cast<u32*>(smem + geo.l_comp);                            // [1024] first pixel of a component
     unsigned short* cidmap = reinterpret_cast<unsigned short*>(smem + geo.l_comp + 4096); // [1024] its rank = component id
     unsigned char* accb = smem + geo.l_acc;                                              // band sums | anchors + moments
-    u32* tmp = reinterpret_cast<u32*>(smem + geo.l_tmp);                                  // [8]
+    u32* mbc = reinterpret_cast<u32*>(smem + geo.l_mbc);                                  // [FT] probe requests per owner (counted only)
+    u32* tmp = reinterpret_cast<u32*>(smem + geo.l_tmp);                                  // [8], then [24]: prefix of a region list
+    u32* pre = tmp + 8;
     const int wg = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int H = geo.H, W = geo.W, WW = geo.WW, G = geo.G, R = geo.R, maxm = geo.maxm, C = geo.C;
     const u32 FT = (u32)geo.FT, ftid = (u32)wg * LT_NT + (u32)tid;
     const LatTile T = lat_tile(ftid, WW, G);
-    const int j = T.j, bj = T.bj, y0 = T.blk * R;
+    const int j = T.j, y0 = T.blk * R;
     const bool act = T.act, hasl = T.hasl, hasr = T.hasr;
+    const u32 sbelow = T.below * SG_SEGMAX;              // segment ids of the tile below: its first row's runs are its segments 0, 1, ..
     const u64 vm = act ? valid_mask(j, W) : 0ull;
     const u32 sbase = ftid * SG_SEGMAX;
     // the frame's scratch
     u32* hdr = hdr_all + (size_t)n * VBS_LAT_HDR;
     unsigned char* sc = scratch_all + (size_t)n * geo.stride;
     unsigned char* nsegG = sc + geo.o_nseg;                                              // [2][FT]   band | opened
-    u64* firstG = reinterpret_cast<u64*>(sc + geo.o_first);                               // [2][FT]
-    u64* botm = reinterpret_cast<u64*>(sc + geo.o_botm);                                  // [4][FT] last-row slots of every tile
-    unsigned short* bots = reinterpret_cast<unsigned short*>(sc + geo.o_bots);            // [4][FT]
     unsigned short* rsid = reinterpret_cast<unsigned short*>(sc + geo.o_rsid);            // [C][LT_REC] band records
     u32* rpos = reinterpret_cast<u32*>(sc + geo.o_rpos);
     u32* rcnt = reinterpret_cast<u32*>(sc + geo.o_rcnt);
     u32* rsx = reinterpret_cast<u32*>(sc + geo.o_rsx);
     u32* rsy = reinterpret_cast<u32*>(sc + geo.o_rsy);
-    u32* pqg = reinterpret_cast<u32*>(sc + geo.o_pq);                                     // [C][LT_PQ]
-    u32* segpos = reinterpret_cast<u32*>(sc + geo.o_segpos);                              // [8 FT] opened mask: first pixel by segment id
-    u32* mbcnt = reinterpret_cast<u32*>(sc + geo.o_mbcnt);                                // [FT] probe requests
-    u32* mbreq = reinterpret_cast<u32*>(sc + geo.o_mbreq);                                // [FT][ST_MB_CAP]
+    u32* xpqg = reinterpret_cast<u32*>(sc + geo.o_pq);                                    // [C][LT_XPQ] pairs between workgroups
+    unsigned short* lroot = reinterpret_cast<unsigned short*>(sc + geo.o_lroot);          // [8 FT] a segment's root within its workgroup
+    u64* segl = reinterpret_cast<u64*>(sc + geo.o_seg);                                   // [C][LT_SEG] opened mask: segment id << 32 | first pixel
+    u64* reql = reinterpret_cast<u64*>(sc + geo.o_req);                                   // [LT_REQ] probe requests: owner thread << 32 | request
     u32* mrec = reinterpret_cast<u32*>(sc + geo.o_mrec);                                  // [C][LT_MREC][16]  segment id, 15 moments
     PairQ Q;
-    Q.q = pqg + (size_t)wg * LT_PQ;
+    Q.q = lpq;
     Q.cap = LT_PQ;
     Q.n = &misc[5];
     if (tid < 16) misc[tid] = 0;
+    lmb_cnt[tid] = 0;
     const int64_t fo = (int64_t)n * H * WW;
     auto hand_on = [&](u32 why) {                        // (the resolving workgroup, uniformly)
         if (tid == 0) { slow_flag[n] = why; atomicAdd(slow_total, 1u); }
@@ -225,6 +308,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         return last;
     };
     __syncthreads();
+    LT_STAMP_MIN(0); LT_STAMP(1);
 
     // ================================ band plane ====================================================================
     {
@@ -252,7 +336,6 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         for (int k = 0; k < SG_KB; ++k) { pm[k] = 0; sid[k] = 0; cnt[k] = 0; sy[k] = 0; sk[k] = 0; pos[k] = 0; }
         u32 nseg = 0, la = NONE16, lb = NONE16, p63 = NONE16, prs0 = NONE16;
         bool fail = false;
-        u64 firstB = 0;
         auto emit = [&](u32 sid_, u32 pos_, u32 cnt_, u32 sk_, u32 sy_) {
             const int r = atomicAdd(&misc[4], 1);
             if (r < LT_REC) {
@@ -262,7 +345,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             } else fail = true;
         };
 #pragma unroll 1
-        for (int q = 0; q < R + NS - 1; ++q) {
+        for (int q = 0; q < R + NS; ++q) {               // (one step past the tile: the first row of the tile below)
             const int r = q - NA;                        // source row of this step
             const u64 v = rowval(pf[0], r);
             pf[0] = pf[1]; pf[1] = pf[2]; pf[2] = pf[3]; pf[3] = ldraw(r + 4);
@@ -285,7 +368,19 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             if (t < 0) continue;                         // (uniform)
             const u64 eh = hwin<NS, true>(e, hasl, hasr);
             const u64 B = (act && y0 + t < H) ? (cr[NBL] & ~eh & vm) : 0ull;      // :171-174  maxima = mask & (window holds a 0)
-            if (t == 0) firstB = B;
+            if (t == R) {                                // (uniform) this tile's last row against the segments of the tile below
+                u64 N = B;
+                u32 i = 0;
+                while (N) {
+                    const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                    N &= t2;
+#pragma unroll
+                    for (int k = 0; k < SG_KB; ++k)
+                        if (gg & pm[k]) pq_push(Q, sbelow + i, sid[k]);
+                    ++i;
+                }
+                break;
+            }
             bool live = false;
 #pragma unroll
             for (int k = 0; k < SG_KB; ++k) live |= pm[k] != 0ull;
@@ -326,56 +421,58 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             if (__any(((B >> 63) | B) & 1ull)) seg_hlinks<SG_KB, false>(pm, sid, hasr, p63, prs0, la, lb, Q);    // (wave-uniform)
         }
 #pragma unroll
-        for (int k = 0; k < SG_KB; ++k) {
+        for (int k = 0; k < SG_KB; ++k)
             if (cnt[k]) emit(sid[k], pos[k], cnt[k], sk[k], sy[k]);
-            if (act) { botm[(size_t)k * FT + bj] = pm[k]; bots[(size_t)k * FT + bj] = (unsigned short)sid[k]; }
-        }
         nsegG[ftid] = (unsigned char)min(nseg, (u32)SG_SEGMAX);
-        firstG[ftid] = firstB;
         if (fail) misc[6] = SLOW_SLOTS;
         __syncthreads();
+        LT_STAMP(2); LT_STAMP_MIN(12);
+        lat_local(Pl, lpq, min(misc[5], LT_PQ), (u32)wg * LT_SEG, min(nseg, (u32)SG_SEGMAX), xpqg + (size_t)wg * LT_XPQ, &misc[12],
+                  lroot + (size_t)wg * LT_SEG);
+        __syncthreads();
         if (tid == 0) {
-            if (misc[5] > LT_PQ) misc[6] = SLOW_SLOTS;
+            if (misc[5] > LT_PQ || misc[12] > LT_XPQ) misc[6] = SLOW_SLOTS;
             hdr[LH_NREC + wg] = (u32)min(misc[4], LT_REC);
-            hdr[LH_NPQB + wg] = (u32)min(misc[5], LT_PQ);
+            hdr[LH_NPQB + wg] = (u32)min(misc[12], LT_XPQ);
             if (misc[6]) atomicMax(&hdr[LH_WHY], (u32)misc[6]);
         }
         const bool last = arrive(LH_ARRIVE1);
         if (last) {
             // ---- the frame's band components, by this workgroup alone ------------------------------------------------------
+            LT_STAMP(3);
             u32 go = 1;
             const u32 whyw = __atomic_load_n(&hdr[LH_WHY], __ATOMIC_RELAXED);
             u32 ncomp = 0;
             if (whyw) { hand_on(whyw); go = 2; }
             else {
-                for (u32 ft = tid; ft < FT; ft += LT_NT) mbcnt[ft] = 0;
-                ncomp = lat_resolve<SG_KB, false>(geo, P, nsegL, nsegG, firstG, botm, bots, pqg, hdr + LH_NPQB, rsid, rpos,
-                                                  hdr + LH_NREC, nullptr, comp_pos, cidmap, tmp, min((u32)maxm, 1024u));
+                for (u32 ft = tid; ft < FT; ft += LT_NT) mbc[ft] = 0;
+                ncomp = lat_resolve(geo, P, nsegL, nsegG, lroot, xpqg, hdr + LH_NPQB, comp_pos, pre, tmp, min((u32)maxm, 1024u), hdr, 14);
                 if (ncomp == NONE32) { hand_on(SLOW_NCOMP); go = 2; }
             }
+            LT_STAMP(4);
             if (go == 1) {
-                // ---- component sums (center_of_mass :181) ------------------------------------------------------------------
+                // ---- first pixels, rank, component sums (center_of_mass :181): the records once, all of a thread's in flight ----
                 u32* acnt = reinterpret_cast<u32*>(accb);                                // [maxm]
                 u64* asx = reinterpret_cast<u64*>(accb + 8 * ((maxm + 1) / 2));           // [maxm]
                 u64* asy = asx + maxm;                                                   // [maxm]
                 for (u32 c = tid; c < ncomp; c += LT_NT) { acnt[c] = 0; asx[c] = 0; asy[c] = 0; }
-                __threadfence();                         // (the cleared request counters, before anybody adds to them)
-                __syncthreads();
-                for (int w = 0; w < C; ++w) {
-                    const u32 nr = hdr[LH_NREC + w];
-                    for (u32 r = tid; r < nr; r += LT_NT) {
-                        const size_t o = (size_t)w * LT_REC + r;
-                        const u32 cid = cidmap[P[rsid[o]] & 0x7FFFu];
-                        atomicAdd(&acnt[cid], rcnt[o]); atomicAdd(&asx[cid], (u64)rsx[o]); atomicAdd(&asy[cid], (u64)rsy[o]);
-                    }
-                }
-                __syncthreads();
+                lat_prefix(hdr + LH_NREC, C, LT_REC, pre);
+                struct RecV { u32 sid, pos, cnt, sx, sy; };
+                lat_flat<4>(pre, C, LT_REC,
+                            [&](size_t o) { return RecV{rsid[o], rpos[o], rcnt[o], rsx[o], rsy[o]}; },
+                            [&](const RecV& v) {
+                                const u32 c = P[v.sid] & 0x7FFFu;               // (numbered, not yet ranked: the sums move below)
+                                atomicMin(&comp_pos[c], v.pos);
+                                atomicAdd(&acnt[c], v.cnt); atomicAdd(&asx[c], (u64)v.sx); atomicAdd(&asy[c], (u64)v.sy);
+                            });
+                lat_rank(comp_pos, cidmap, ncomp);
                 // the sums go out; the probe requests (2x2 pixel cell around every centroid) go to the threads that own the pixels
                 u64* bs = band_sums + (int64_t)n * maxm * 4;
                 unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
-                for (u32 c = tid; c < ncomp; c += LT_NT) {
-                    const u32 cn_ = acnt[c];
-                    const u64 sx = asx[c], sy_ = asy[c];
+                for (u32 cu = tid; cu < ncomp; cu += LT_NT) {
+                    const u32 c = cidmap[cu];                // (the sums were gathered by component NUMBER: the id is its rank)
+                    const u32 cn_ = acnt[cu];
+                    const u64 sx = asx[cu], sy_ = asy[cu];
                     bs[c * 4 + 0] = cn_; bs[c * 4 + 1] = sx; bs[c * 4 + 2] = sy_;
                     const double cn = (double)cn_;
                     const float xf = (float)((double)sx / cn), yf = (float)((double)sy_ / cn);
@@ -389,16 +486,18 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                         if ((q & 1) && px > 0 && (px & 63) != 0) continue;                   // rode along with (ix, py)
                         const int ob = py / R, oi = py - ob * R, ow = ob / G, og = ob - ow * G;
                         const int owner = ow * 64 + og * WW + (px >> 6);
-                        const u32 slot = atomicAdd(&mbcnt[owner], 1u);
-                        if (slot < ST_MB_CAP)
-                            mbreq[owner * ST_MB_CAP + slot] = c | ((u32)q << 10) | ((u32)oi << 12) | ((u32)(px & 63) << 19) | ((u32)pair << 25);
+                        const u32 slot = atomicAdd(&mbc[owner], 1u);
+                        const int li = atomicAdd(&misc[11], 1);
+                        if (slot < ST_MB_CAP && li < LT_REQ)
+                            reql[li] = ((u64)(u32)owner << 32) | (c | ((u32)q << 10) | ((u32)oi << 12) | ((u32)(px & 63) << 19) | ((u32)pair << 25));
                         else misc[6] = SLOW_MAILBOX;
                     }
                 }
-                if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; }
                 __syncthreads();
+                if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; hdr[LH_NREQ] = (u32)min(misc[11], LT_REQ); }
                 if (misc[6]) { hand_on(SLOW_MAILBOX); go = 2; }      // a crowded mailbox
             }
+            LT_STAMP(5);
             __threadfence();
             __syncthreads();
             if (tid == 0) { atomicExch(&hdr[LH_FLAG], go); misc[9] = (int)go; }
@@ -423,12 +522,23 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             return;
         }
         if (tid < 16 && tid != 9) misc[tid] = 0;
+        // this wave's lanes' probe requests out of the frame's list (a wave only fills its own lanes' boxes)
+        {
+            const u32 nreq = __atomic_load_n(&hdr[LH_NREQ], __ATOMIC_RELAXED), fw = ftid >> 6;
+            for (u32 i = lane; i < nreq; i += 64) {
+                const u64 rq = reql[i];
+                const u32 owner = (u32)(rq >> 32);
+                if ((owner >> 6) != fw) continue;
+                const u32 ot = owner - (u32)wg * LT_NT, slot = atomicAdd(&lmb_cnt[ot], 1u);
+                if (slot < ST_MB_CAP) lmb[ot * ST_MB_CAP + slot] = (u32)rq;
+            }
+        }
         __syncthreads();
+        LT_STAMP(6);
     }
 
     // ================================ opened area plane =============================================================
     unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
-    Q.q = pqg + (size_t)wg * LT_PQ;
     {
         const u64* A = area_all + fo;
         auto ldraw = [&](int r) -> u64 {
@@ -447,11 +557,11 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         u32 l1 = 0, l2 = 0, r1 = 0, r2 = 0;              // bit 63 of the word to the left / bit 0 of the word to the right in those rows
         // this thread's probe requests (in registers: a request read from memory where its row comes by would stall the wave)
         u64 rowm[2] = {0, 0};                            // (R <= 128)
-        const u32 nreq = min(mbcnt[ftid], (u32)ST_MB_CAP);
+        const u32 nreq = min(lmb_cnt[tid], (u32)ST_MB_CAP);
         u32 req[ST_MB_CAP];
 #pragma unroll
         for (u32 q = 0; q < ST_MB_CAP; ++q) {
-            req[q] = q < nreq ? mbreq[ftid * ST_MB_CAP + q] : 0u;
+            req[q] = q < nreq ? lmb[tid * ST_MB_CAP + q] : 0u;
             if (q < nreq) {
                 const u32 rr = (req[q] >> 12) & 127u;
                 if (rr < 64) rowm[0] |= 1ull << rr; else rowm[1] |= 1ull << (rr - 64);
@@ -469,7 +579,6 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         }
         u32 nseg = 0, la = NONE16, lb = NONE16, p63 = NONE16, prs0 = NONE16;
         u32 why = 0;
-        u64 firstB = 0;
         int e4 = 0;
         const int tch = R >> 1;
         const int mthr = R <= 64 ? 900 : 56;             // vertices (with multiplicity) an entry may hold: its sums stay below 2^31
@@ -537,7 +646,6 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             }
             if (c >= 0 && __any(o1 != 0ull || live || row_asked(c))) {
                 const u64 B = o1;
-                if (c == 0) firstB = B;
                 // ---- segments ---------------------------------------------------------------------------------------------
                 const u64 rB = brev64(B);
                 u64 Rn[SG_KO];
@@ -555,7 +663,9 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                             if (mo[k][0]) emit_mom(sid[k], mo[k]);
                             if (nseg < SG_SEGMAX) {
                                 sid[k] = sbase + nseg;
-                                segpos[sbase + nseg] = (u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
+                                const int si = atomicAdd(&misc[10], 1);     // (< LT_SEG: eight per thread)
+                                segl[(size_t)wg * LT_SEG + si] = ((u64)(sbase + nseg) << 32) |
+                                    ((u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1));
                             } else why = SLOW_SLOTS;
                             ++nseg;
                             pm[k] = gg;
@@ -638,33 +748,63 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             o2 = o1; o1 = o0; l2 = l1; l1 = l0; r2 = r1; r1 = r0;
         }
 #pragma unroll
-        for (int k = 0; k < SG_KO; ++k) {
+        for (int k = 0; k < SG_KO; ++k)
             if (mo[k][0]) emit_mom(sid[k], mo[k]);
-            if (act) { botm[(size_t)k * FT + bj] = pm[k]; bots[(size_t)k * FT + bj] = (unsigned short)sid[k]; }
+        // this tile's last row against the segments of the tile below: o1 is that tile's first row by now (l1 / r1: bit 63 of
+        // the word to its left / bit 0 of the word to its right); 8-connectivity: also the tiles below-left and below-right
+        {
+            const u64 Bn = o1;
+            const u32 nrun = (u32)__popcll(Bn & ~(Bn << 1));
+            u32 nrl = dpp_shr1(nrun);                    // runs in the first row of the tile below-left (every lane executes this)
+            u64 N = Bn;
+            u32 i = 0;
+            while (N) {
+                const u64 lowbit = N & (~N + 1ull), t2 = N + lowbit, gg = N & ~t2;
+                N &= t2;
+                const u64 ga = gg | (gg << 1) | (gg >> 1);
+#pragma unroll
+                for (int k = 0; k < SG_KO; ++k)
+                    if (ga & pm[k]) pq_push(Q, sbelow + i, sid[k]);
+                ++i;
+            }
+#pragma unroll
+            for (int k = 0; k < SG_KO; ++k) {
+                if ((pm[k] >> 63) && r1) pq_push(Q, sbelow + SG_SEGMAX, sid[k]);                  // its run at bit 0 is its segment 0
+                if ((pm[k] & 1ull) && l1) pq_push(Q, sbelow - SG_SEGMAX + nrl - 1u, sid[k]);      // its run at bit 63 is its last
+            }
         }
         nsegG[FT + ftid] = (unsigned char)min(nseg, (u32)SG_SEGMAX);
-        firstG[FT + ftid] = firstB;
         if (e4) atomicAdd(&misc[0], e4);
         if (why) misc[6] = (int)why;
         __syncthreads();
+        LT_STAMP(7); LT_STAMP_MIN(13);
+        lat_local(Pl, lpq, min(misc[5], LT_PQ), (u32)wg * LT_SEG, min(nseg, (u32)SG_SEGMAX), xpqg + (size_t)wg * LT_XPQ, &misc[12],
+                  lroot + (size_t)wg * LT_SEG);
+        __syncthreads();
         if (tid == 0) {
-            if (misc[5] > LT_PQ) misc[6] = SLOW_SLOTS;
+            if (misc[5] > LT_PQ || misc[12] > LT_XPQ) misc[6] = SLOW_SLOTS;
             hdr[LH_NMREC + wg] = (u32)min(misc[7], LT_MREC);
-            hdr[LH_NPQO + wg] = (u32)min(misc[5], LT_PQ);
+            hdr[LH_NPQO + wg] = (u32)min(misc[12], LT_XPQ);
+            hdr[LH_NSEG + wg] = (u32)misc[10];
             if (misc[0]) atomicAdd(&hdr[LH_EULER], (u32)misc[0]);
             if (misc[6]) atomicMax(&hdr[LH_WHY], (u32)misc[6]);
         }
     }
     if (!arrive(LH_ARRIVE2)) return;
+    LT_STAMP(8);
     // ---- the frame's opened components, by this workgroup alone --------------------------------------------------------
     {
         const u32 whyw = __atomic_load_n(&hdr[LH_WHY], __ATOMIC_RELAXED);
         if (whyw) { hand_on(16u + whyw); return; }
     }
     const u32 nband = ncomp_all[n * 2 + 0];
-    const u32 ncomp = lat_resolve<SG_KO, true>(geo, P, nsegL, nsegG + FT, firstG + FT, botm, bots, pqg, hdr + LH_NPQO, nullptr, nullptr,
-                                               nullptr, segpos, comp_pos, cidmap, tmp, min((u32)maxm, (u32)CCL_OPEN_COMPS));
+    const u32 ncomp = lat_resolve(geo, P, nsegL, nsegG + FT, lroot, xpqg, hdr + LH_NPQO, comp_pos, pre, tmp, min((u32)maxm, (u32)CCL_OPEN_COMPS), hdr, 17);
     if (ncomp == NONE32) { hand_on(16u + SLOW_NCOMP); return; }
+    lat_prefix(hdr + LH_NSEG, C, LT_SEG, pre);
+    lat_flat<4>(pre, C, LT_SEG, [&](size_t o) { return segl[o]; },
+                [&](u64 v) { atomicMin(&comp_pos[P[(u32)(v >> 32)] & 0x7FFFu], (u32)v); });
+    lat_rank(comp_pos, cidmap, ncomp);
+    LT_STAMP(9);
     if ((int)ncomp - (int)__atomic_load_n(&hdr[LH_EULER], __ATOMIC_RELAXED) / 4 != 0) {      // holes: RETR_EXTERNAL needs the fill passes of the general path
         hand_on(16u + SLOW_HOLES);
         return;
@@ -682,17 +822,18 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     }
     // ---- segment moments -> component moments about its first pixel, `mom_comps` components per pass -----------------------------
     i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
+    lat_prefix(hdr + LH_NMREC, C, LT_MREC, pre);
     for (u32 c0 = 0; c0 < ncomp; c0 += geo.mom_comps) {
         const u32 nc = min(geo.mom_comps, ncomp - c0);
         for (u32 c = tid; c < nc * NMOM; c += LT_NT) acc[c] = 0;
         __syncthreads();
-        for (int w = 0; w < C; ++w) {
-            const u32 nm = hdr[LH_NMREC + w];
-            for (u32 r = tid; r < nm; r += LT_NT) {
-                const uint4* src = reinterpret_cast<const uint4*>(mrec + ((size_t)w * LT_MREC + r) * 16);
-                const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+        struct MomV { uint4 w0, w1, w2, w3; };
+        lat_flat<2>(pre, C, LT_MREC,
+                    [&](size_t o) { const uint4* src = reinterpret_cast<const uint4*>(mrec + o * 16); return MomV{src[0], src[1], src[2], src[3]}; },
+                    [&](const MomV& v) {
+                const uint4 w0 = v.w0, w1 = v.w1, w2 = v.w2, w3 = v.w3;
                 const u32 s = w0.x, cid = (u32)cidmap[P[s] & 0x7FFFu] - c0;
-                if (cid >= nc) continue;                 // another pass's component
+                if (cid >= nc) return;                   // another pass's component
                 const u32 ot = s / SG_SEGMAX, ol = ot & 63u, og = ol / (u32)WW;         // the thread that wrote it: its tile
                 const int ox = 64 * (int)(ol - og * (u32)WW) + 32, oy = (int)((ot >> 6) * (u32)G + og) * R + (R >> 1);
                 const u32 fp = anchor[cid + c0];
@@ -704,18 +845,19 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
 #pragma unroll
                 for (int q = 0; q < NMOM; ++q)
                     if (o[q]) atomicAdd(&a[q], (u64)o[q]);
-            }
-        }
+            });
         __syncthreads();
         for (u32 c = tid; c < nc * NMOM; c += LT_NT) as[(c0 + c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
         __syncthreads();
     }
+    LT_STAMP(10);
     // ---- probes: segment -> component ----------------------------------------------------------------------------------
     for (u32 e = tid; e < nband * 4; e += LT_NT) {
         const u32 v = pr[e];
         if (v != NONE16) pr[e] = cidmap[P[v] & 0x7FFFu];
     }
     if (tid == 0) { ncomp_all[n * 2 + 1] = ncomp; fstat[n * 8 + 6] = ncomp; fstat[n * 8 + 4] = 0; }
+    LT_STAMP(11);
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
@@ -736,18 +878,15 @@ static bool lat_geom(const vbs_handle* h, LatGeom* g, size_t* lds_bytes) {
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += up16(bytes); return (u32)at; };
     g->o_nseg = take(2 * FT);
-    g->o_first = take(2 * FT * 8);
-    g->o_botm = take(4 * FT * 8);
-    g->o_bots = take(4 * FT * 2);
     g->o_rsid = take((size_t)C * LT_REC * 2);
     g->o_rpos = take((size_t)C * LT_REC * 4);
     g->o_rcnt = take((size_t)C * LT_REC * 4);
     g->o_rsx = take((size_t)C * LT_REC * 4);
     g->o_rsy = take((size_t)C * LT_REC * 4);
-    g->o_pq = take((size_t)C * LT_PQ * 4);
-    g->o_segpos = take(8 * FT * 4);
-    g->o_mbcnt = take(FT * 4);
-    g->o_mbreq = take(FT * ST_MB_CAP * 4);
+    g->o_pq = take((size_t)C * LT_XPQ * 4);
+    g->o_lroot = take(8 * FT * 2);
+    g->o_seg = take((size_t)C * LT_SEG * 8);
+    g->o_req = take((size_t)LT_REQ * 8);
     g->o_mrec = take((size_t)C * LT_MREC * 64);
     g->stride = (u32)((o + 255) / 256 * 256);
     // LDS of the resolving workgroup
@@ -757,8 +896,9 @@ static bool lat_geom(const vbs_handle* h, LatGeom* g, size_t* lds_bytes) {
     g->l_nseg = (u32)par;
     g->l_comp = (u32)(par + up16(FT));
     g->l_acc = g->l_comp + 4096 + 2048;
-    g->l_tmp = (u32)(g->l_acc + (acc_band > acc_open ? acc_band : acc_open));
-    *lds_bytes = g->l_tmp + 64;
+    g->l_mbc = (u32)(g->l_acc + (acc_band > acc_open ? acc_band : acc_open));
+    g->l_tmp = (u32)(g->l_mbc + up16(FT * 4));
+    *lds_bytes = g->l_tmp + 128;
     return *lds_bytes <= 160 * 1024;
 }
 
