@@ -28,7 +28,9 @@
 #define LT_PQ 1024                 // queued pairs per workgroup and walk (LDS)
 #define LT_XPQ 512                 // of them, pairs that reach into another workgroup's segments (global)
 #define LT_MREC 512                // moment records per workgroup
-#define LT_SEG (LT_NT * SG_SEGMAX) // opened segments per workgroup (every one of them)
+#define LT_SEG (LT_NT * SG_SEGMAX) // segment ids per workgroup
+#define LT_NODE 256                // components WITHIN a workgroup's tiles ("nodes") it can hand to the frame's resolve
+#define LT_NODES 1024              // nodes per frame the resolving workgroup stages in its LDS
 #define LT_REQ 4096                // probe requests per frame (4 per band component)
 #define LT_ROWS 8                  // rows per thread aimed at
 // header words of a frame (VBS_LAT_HDR each, cleared by launch_labelling's fill together with the slow flags)
@@ -38,7 +40,7 @@
 #define LH_WHY 3
 #define LH_EULER 4
 #define LH_NREQ 5                  // probe requests in the list
-#define LH_NREC 16                 // [C] band records / pairs of the band walk / moment records / pairs of the opened walk / opened segments
+#define LH_NREC 16                 // [C] band nodes / pairs out of the band walk / moment records / pairs out of the opened walk / opened nodes
 #define LH_NPQB 32
 #define LH_NMREC 48
 #define LH_NPQO 64
@@ -57,8 +59,8 @@ struct LatGeom {
     int H, W, WW, G, NB, R, C, FT, maxm;                  // FT = 256 C threads per frame, NB = 4 C G row blocks of R rows
     u32 mom_comps;
     u32 stride;                                           // bytes of scratch per frame
-    u32 o_nseg, o_rsid, o_rpos, o_rcnt, o_rsx, o_rsy, o_pq, o_lroot, o_seg, o_req, o_mrec;       // byte offsets into it
-    u32 l_nseg, l_comp, l_acc, l_mbc, l_tmp;              // byte offsets into the dynamic LDS (parents at 0)
+    u32 o_node, o_pq, o_lroot, o_req, o_mrec;             // byte offsets into it
+    u32 l_node, l_comp, l_acc, l_mbc, l_tmp;              // byte offsets into the dynamic LDS of the resolving workgroup (parents at 0)
 };
 
 // exclusive prefix sum over the LT_NT threads; tmp holds >= 8 words
@@ -112,7 +114,7 @@ __device__ __forceinline__ void lat_flat(const u32* pre, int C, u32 cap, LD ld, 
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (i0 + (u32)u * LT_NT < total) use(v[u]);
+            if (i0 + (u32)u * LT_NT < total) use(v[u], i0 + (u32)u * LT_NT);
     }
 }
 // pre[0 .. C] <- exclusive prefix of cnt[0 .. C) (global), every count clipped to cap
@@ -124,13 +126,16 @@ __device__ __forceinline__ void lat_prefix(const u32* cnt, int C, u32 cap, u32* 
     __syncthreads();
 }
 
-// End of a walk, every workgroup for itself: the queued pairs between two of ITS OWN segments are united here, in its
-// LDS, by all workgroups at once (a pair costs a chain of dependent LDS accesses; 2 600 of them per frame are ten per thread
-// of one workgroup and one per thread when every workgroup takes its own); what goes out is every segment's root within
-// the workgroup (lroot, a global id) and the few pairs that reach into another workgroup - the links of its last row
-// block with the first of the next.
-__device__ __forceinline__ void lat_local(unsigned short* Pl, const u32* lpq, int npairs, u32 base, u32 nseg, u32* xpq, int* nx,
-                                          unsigned short* lroot_out) {
+// End of a walk, every workgroup for itself, all workgroups at once: the queued pairs between two of ITS OWN segments are
+// united in its LDS (a pair costs a chain of dependent LDS accesses: 2 600 of them per frame are ten per thread of one
+// workgroup and one per thread when every workgroup takes its own), its segments' sums are gathered per root within the
+// workgroup, and what goes out to the frame's resolve is one NODE per such root (~ 25 per workgroup instead of 210
+// records), every segment's node (lroot, global ids: the few lookups the resolve needs) and the few pairs that reach
+// into another workgroup - the links of its last row block with the first of the next - with its own side already a node.
+//   here: Pl[s] <- root of local segment s, r[i] = that of the thread's own segment i (local numbering); pairs with a
+//   foreign side -> xl.  Three barriers; the caller clears its accumulators BEFORE the call (first barrier).
+__device__ __forceinline__ void lat_local_roots(unsigned short* Pl, const u32* lpq, int npairs, u32 base, u32 nseg, u32* xl, int* nx,
+                                                u32 (&r)[SG_SEGMAX]) {
     const int tid = threadIdx.x;
     {
         const u32 b = 8u * (u32)tid;
@@ -141,93 +146,78 @@ __device__ __forceinline__ void lat_local(unsigned short* Pl, const u32* lpq, in
     for (int i = tid; i < npairs; i += LT_NT) {
         const u32 pr = lpq[i], a = (pr >> 16) - base, b = (pr & 0xFFFFu) - base;
         if (a < (u32)LT_SEG && b < (u32)LT_SEG) ccl_union(Pl, a, b);
-        else { const int k = atomicAdd(nx, 1); if (k < LT_XPQ) xpq[k] = pr; }
+        else { const int k = atomicAdd(nx, 1); if (k < LT_XPQ) xl[k] = pr; }
     }
     __syncthreads();
-    u32 r[SG_SEGMAX];
 #pragma unroll
-    for (u32 i = 0; i < SG_SEGMAX; ++i) {                // (read only: nobody writes until every root is found)
+    for (u32 i = 0; i < SG_SEGMAX; ++i) {
         u32 x = 8u * (u32)tid + i;
         if (i < nseg) { u32 p; while ((p = Pl[x]) != x) x = p; }
-        r[i] = base + x;
+        r[i] = x;
     }
-    reinterpret_cast<uint4*>(lroot_out)[tid] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+    // (stored while other threads still follow chains: what they meet is the old parent or the root, both ancestors)
+    reinterpret_cast<uint4*>(Pl)[tid] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+    __syncthreads();
+}
+// ... and out: the pairs between workgroups with this workgroup's side replaced by its node, every own segment's node
+__device__ __forceinline__ void lat_local_out(const unsigned short* Pl, u32 base, const u32* xl, int nx, const u32 (&r)[SG_SEGMAX],
+                                              u32* xpq, unsigned short* lroot_out) {
+    const int tid = threadIdx.x;
+    for (int k = tid; k < nx; k += LT_NT) {
+        const u32 pr = xl[k];
+        u32 a = pr >> 16, b = pr & 0xFFFFu;
+        if (a - base < (u32)LT_SEG) a = base + Pl[a - base];
+        if (b - base < (u32)LT_SEG) b = base + Pl[b - base];
+        xpq[k] = (a << 16) | b;
+    }
+    reinterpret_cast<uint4*>(lroot_out)[tid] = make_uint4((base + r[0]) | ((base + r[1]) << 16), (base + r[2]) | ((base + r[3]) << 16),
+                                                          (base + r[4]) | ((base + r[5]) << 16), (base + r[6]) | ((base + r[7]) << 16));
 }
 
-// After a walk, by ONE workgroup: the components of the frame's segments.  P (LDS) = parents over 8 FT segment ids, starting
-// from every segment's root within its workgroup (lroot); the unions are the pairs between workgroups.  Then as
-// k_stage's seg_resolve - roots numbered (an entry becomes its root's number, bit 15 marks the root) - but a tile's
-// eight entries at a time: one wide read, eight independent chains (one workgroup's four waves cannot hide the latency of
-// 2 000 chains taken one after the other).  The caller fills comp_pos[c] = first pixel of component c; lat_rank turns it into
-// cidmap[c] = rank of that pixel = the component's id.  Workgroup-uniform return: components, or NONE32 when there are
-// more than `limit`.
-__device__ __forceinline__ u32 lat_resolve(const LatGeom& geo, unsigned short* P, unsigned char* nsegL, const unsigned char* nsegG,
+// The resolving workgroup's LDS copy of the frame's nodes
+struct LatNodes { unsigned short* id; unsigned short* root; u32* pos; u32* cnt; u64* sx; u64* sy; };
+
+// After a walk, by ONE workgroup: the components of the frame's nodes.  The nodes are staged in LDS (BAND: with their sums),
+// P (LDS, indexed by segment id, only the nodes' entries are ever touched) starts as the identity on them, the unions are
+// the pairs between workgroups (a foreign side looked up in lroot), then every node's root, the roots numbered (P[root] =
+// bit 15 | number, comp_pos cleared).  Workgroup-uniform return: components; NONE32: more than `limit`; NONE32 - 1: more
+// nodes than LT_NODES.  *nnodes = nodes.
+template <bool BAND>
+__device__ __forceinline__ u32 lat_resolve(const LatGeom& geo, unsigned short* P, const LatNodes& N, const uint4* nodes, const u32* nnode,
                                            const unsigned short* lroot, const u32* xpq, const u32* nxpq, u32* comp_pos, u32* pre,
-                                           u32* tmp, u32 limit, u32* hdr, int st0) {
+                                           u32* tmp, u32 limit, u32* nnodes, u32* hdr, int st0) {
     const int tid = threadIdx.x;
-    const u32 FT = (u32)geo.FT;
-    uint4* P128 = reinterpret_cast<uint4*>(P);
-    {
-        const uint4* src = reinterpret_cast<const uint4*>(lroot);
-#pragma unroll
-        for (int k = 0; k < LT_CMAX; ++k)                // (unrolled: the loads are issued together)
-            if ((u32)k * LT_NT + tid < FT) P128[(u32)k * LT_NT + tid] = src[(u32)k * LT_NT + tid];
-        const u32* ns = reinterpret_cast<const u32*>(nsegG);
-        u32* dst = reinterpret_cast<u32*>(nsegL);
-        for (u32 i = tid; i < FT / 4; i += LT_NT) dst[i] = ns[i];
-    }
-    lat_prefix(nxpq, geo.C, LT_XPQ, pre);
+    lat_prefix(nnode, geo.C, LT_NODE, pre);
+    const u32 T = pre[geo.C];
+    *nnodes = T;
+    if (T > (u32)LT_NODES) return NONE32 - 1u;
+    struct NodeV { uint4 a, b; };
+    lat_flat<4>(pre, geo.C, LT_NODE,
+                [&](size_t o) { NodeV v; v.a = nodes[2 * o]; if (BAND) v.b = nodes[2 * o + 1]; return v; },
+                [&](const NodeV& v, u32 i) {
+                    N.id[i] = (unsigned short)v.a.x; N.pos[i] = v.a.y; P[v.a.x] = (unsigned short)v.a.x;
+                    if (BAND) { N.cnt[i] = v.a.z; N.sx[i] = mk64(v.b.x, v.b.y); N.sy[i] = mk64(v.b.z, v.b.w); }
+                });
+    lat_prefix(nxpq, geo.C, LT_XPQ, pre);                 // (its barriers: every node's entry is in place)
     LT_STAMP(st0);
-    lat_flat<4>(pre, geo.C, LT_XPQ, [&](size_t o) { return xpq[o]; },
-                [&](u32 pr) { ccl_union(P, pr >> 16, pr & 0xFFFFu); });
+    lat_flat<4>(pre, geo.C, LT_XPQ,
+                [&](size_t o) { const u32 pr = xpq[o]; return make_uint2(lroot[pr >> 16], lroot[pr & 0xFFFFu]); },
+                [&](const uint2& v, u32) { ccl_union(P, v.x, v.y); });
     __syncthreads();
     LT_STAMP(st0 + 1);
-    // every segment's root, tile by tile (tile k LT_NT + tid).  A tile's roots are stored while other threads still follow
-    // chains: what they meet is the old parent or the root, both ancestors (no halving: a late store must be a root)
     u32 nroot = 0;
-#pragma unroll
-    for (int k = 0; k < LT_CMAX; ++k) {
-        const u32 ft = (u32)k * LT_NT + tid;
-        const u32 ns = ft < FT ? (u32)nsegL[ft] : 0u;
-        const uint4 w = ft < FT ? P128[ft] : make_uint4(0, 0, 0, 0);
-        u32 r[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
-#pragma unroll
-        for (u32 i = 0; i < 8; ++i) {
-            if (i < ns) {
-                u32 x = r[i], p;
-                while ((p = P[x]) != x) x = p;
-                r[i] = x;
-                nroot += x == 8u * ft + i;
-            }
-        }
-        if (ns) P128[ft] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
+    for (u32 t = tid; t < T; t += LT_NT) {               // (read only)
+        u32 x = N.id[t], p;
+        while ((p = P[x]) != x) x = p;
+        N.root[t] = (unsigned short)x;
+        nroot += x == N.id[t];
     }
     LT_STAMP(st0 + 2);
     u32 ncomp;
     u32 c0 = lt_scan(nroot, tmp, &ncomp);                 // (its barriers: every root is found before the first number is written)
     if (ncomp > limit) return NONE32;
-#pragma unroll
-    for (int k = 0; k < LT_CMAX; ++k) {
-        const u32 ft = (u32)k * LT_NT + tid;
-        const u32 ns = ft < FT ? (u32)nsegL[ft] : 0u;
-        const uint4 w = ns ? P128[ft] : make_uint4(0, 0, 0, 0);
-        const u32 r[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
-#pragma unroll
-        for (u32 i = 0; i < 8; ++i)
-            if (i < ns && r[i] == 8u * ft + i) { comp_pos[c0] = NONE32; P[8u * ft + i] = (unsigned short)(0x8000u | c0++); }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < LT_CMAX; ++k) {
-        const u32 ft = (u32)k * LT_NT + tid;
-        const u32 ns = ft < FT ? (u32)nsegL[ft] : 0u;
-        const uint4 w = ns ? P128[ft] : make_uint4(0, 0, 0, 0);
-        u32 r[8] = {w.x & 0xFFFFu, w.x >> 16, w.y & 0xFFFFu, w.y >> 16, w.z & 0xFFFFu, w.z >> 16, w.w & 0xFFFFu, w.w >> 16};
-#pragma unroll
-        for (u32 i = 0; i < 8; ++i)
-            if (i < ns && !(r[i] & 0x8000u)) r[i] = P[r[i]] & 0x7FFFu;       // (a root already holds its number and its mark)
-        if (ns) P128[ft] = make_uint4(r[0] | (r[1] << 16), r[2] | (r[3] << 16), r[4] | (r[5] << 16), r[6] | (r[7] << 16));
-    }
+    for (u32 t = tid; t < T; t += LT_NT)
+        if (N.root[t] == N.id[t]) { comp_pos[c0] = NONE32; P[N.id[t]] = (unsigned short)(0x8000u | c0++); }
     __syncthreads();
     return ncomp;
 }
@@ -255,13 +245,34 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                                      // [8] this workgroup is the last of its frame, [9] the flag the others waited for, [10] opened segments
     __shared__ u32 lmb_cnt[LT_NT], lmb[LT_NT * ST_MB_CAP];       // this workgroup's probe requests, by owner thread
     __shared__ u32 lpq[LT_PQ];                                   // the pairs this workgroup's walk queues
+    __shared__ u32 xl[LT_XPQ];                                   // of them, the pairs with a side in another workgroup
     __shared__ __align__(16) unsigned short Pl[LT_SEG];          // parents over its own segments (lat_local)
-    unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [8 FT] segment parents (resolving workgroup)
-    unsigned char* nsegL = smem + geo.l_nseg;                                            // [FT]
+    unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [8 FT] parents, by segment id (resolving workgroup)
+    LatNodes ND;                                                                         // the frame's nodes (resolving workgroup)
+    ND.id = reinterpret_cast<unsigned short*>(smem + geo.l_node);
+    ND.root = ND.id + LT_NODES;
+    ND.pos = reinterpret_cast<u32*>(ND.root + LT_NODES);
+    ND.cnt = ND.pos + LT_NODES;
+    ND.sx = reinterpret_cast<u64*>(ND.cnt + LT_NODES);
+    ND.sy = ND.sx + LT_NODES;
+    // the dynamic LDS while a workgroup WALKS: band: its records [LT_REC] and sums per own segment id [LT_SEG]; opened: its moment
+    // records [LT_MREC][16], first pixel per own segment and per node
+    unsigned short* w_rsid = reinterpret_cast<unsigned short*>(smem);
+    u32* w_rpos = reinterpret_cast<u32*>(smem + 2 * LT_REC);
+    u32* w_rcnt = w_rpos + LT_REC;
+    u32* w_rsx = w_rcnt + LT_REC;
+    u32* w_rsy = w_rsx + LT_REC;
+    u32* w_apos = w_rsy + LT_REC;                                                         // [LT_SEG]
+    u32* w_acnt = w_apos + LT_SEG;
+    u64* w_asx = reinterpret_cast<u64*>(w_acnt + LT_SEG);
+    u64* w_asy = w_asx + LT_SEG;
+    u32* w_mrec = reinterpret_cast<u32*>(smem);                                           // [LT_MREC][16]
+    u32* w_spos = w_mrec + LT_MREC * 16;                                                  // [LT_SEG]
+    u32* w_opos = w_spos + LT_SEG;                                                        // [LT_SEG]
     u32* comp_pos = reinterpret_cast<u32*>(smem + geo.l_comp);                            // [1024] first pixel of a component
     unsigned short* cidmap = reinterpret_cast<unsigned short*>(smem + geo.l_comp + 4096); // [1024] its rank = component id
     unsigned char* accb = smem + geo.l_acc;                                              // band sums | anchors + moments
-    u32* mbc = reinterpret_cast<u32*>(smem + geo.l_mbc);                                  // [FT] probe requests per owner (counted only)
+    u32* mbc = reinterpret_cast<u32*>(smem + geo.l_mbc);                                  // [FT] bytes: probe requests per owner (counted only)
     u32* tmp = reinterpret_cast<u32*>(smem + geo.l_tmp);                                  // [8], then [24]: prefix of a region list
     u32* pre = tmp + 8;
     const int wg = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
@@ -276,17 +287,12 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     // the frame's scratch
     u32* hdr = hdr_all + (size_t)n * VBS_LAT_HDR;
     unsigned char* sc = scratch_all + (size_t)n * geo.stride;
-    unsigned char* nsegG = sc + geo.o_nseg;                                              // [2][FT]   band | opened
-    unsigned short* rsid = reinterpret_cast<unsigned short*>(sc + geo.o_rsid);            // [C][LT_REC] band records
-    u32* rpos = reinterpret_cast<u32*>(sc + geo.o_rpos);
-    u32* rcnt = reinterpret_cast<u32*>(sc + geo.o_rcnt);
-    u32* rsx = reinterpret_cast<u32*>(sc + geo.o_rsx);
-    u32* rsy = reinterpret_cast<u32*>(sc + geo.o_rsy);
+    uint4* nodes = reinterpret_cast<uint4*>(sc + geo.o_node);                             // [C][LT_NODE][2] id, first pixel, count, - | sum x, sum y
     u32* xpqg = reinterpret_cast<u32*>(sc + geo.o_pq);                                    // [C][LT_XPQ] pairs between workgroups
-    unsigned short* lroot = reinterpret_cast<unsigned short*>(sc + geo.o_lroot);          // [8 FT] a segment's root within its workgroup
-    u64* segl = reinterpret_cast<u64*>(sc + geo.o_seg);                                   // [C][LT_SEG] opened mask: segment id << 32 | first pixel
+    unsigned short* lroot = reinterpret_cast<unsigned short*>(sc + geo.o_lroot);          // [8 FT] a segment's node (its root within its workgroup)
     u64* reql = reinterpret_cast<u64*>(sc + geo.o_req);                                   // [LT_REQ] probe requests: owner thread << 32 | request
-    u32* mrec = reinterpret_cast<u32*>(sc + geo.o_mrec);                                  // [C][LT_MREC][16]  segment id, 15 moments
+    u32* mrec = reinterpret_cast<u32*>(sc + geo.o_mrec);                                  // [C][LT_MREC][16]  segment id | node << 16, 15 moments
+    const u32 base = (u32)wg * LT_SEG;                                                    // this workgroup's first segment id
     PairQ Q;
     Q.q = lpq;
     Q.cap = LT_PQ;
@@ -339,9 +345,8 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         auto emit = [&](u32 sid_, u32 pos_, u32 cnt_, u32 sk_, u32 sy_) {
             const int r = atomicAdd(&misc[4], 1);
             if (r < LT_REC) {
-                const size_t o = (size_t)wg * LT_REC + r;
-                rsid[o] = (unsigned short)sid_; rpos[o] = pos_; rcnt[o] = cnt_;
-                rsx[o] = 64u * (u32)j * cnt_ + sk_; rsy[o] = sy_;
+                w_rsid[r] = (unsigned short)sid_; w_rpos[r] = pos_; w_rcnt[r] = cnt_;
+                w_rsx[r] = 64u * (u32)j * cnt_ + sk_; w_rsy[r] = sy_;
             } else fail = true;
         };
 #pragma unroll 1
@@ -423,16 +428,43 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
 #pragma unroll
         for (int k = 0; k < SG_KB; ++k)
             if (cnt[k]) emit(sid[k], pos[k], cnt[k], sk[k], sy[k]);
-        nsegG[ftid] = (unsigned char)min(nseg, (u32)SG_SEGMAX);
         if (fail) misc[6] = SLOW_SLOTS;
-        __syncthreads();
         LT_STAMP(2); LT_STAMP_MIN(12);
-        lat_local(Pl, lpq, min(misc[5], LT_PQ), (u32)wg * LT_SEG, min(nseg, (u32)SG_SEGMAX), xpqg + (size_t)wg * LT_XPQ, &misc[12],
-                  lroot + (size_t)wg * LT_SEG);
+        // ---- this workgroup's own part of the resolve: its pairs, its segments' sums per node -----------------------------
+        {
+            const uint4 z = make_uint4(0, 0, 0, 0), o = make_uint4(NONE32, NONE32, NONE32, NONE32);
+            reinterpret_cast<uint4*>(w_apos)[2 * tid] = o; reinterpret_cast<uint4*>(w_apos)[2 * tid + 1] = o;
+            reinterpret_cast<uint4*>(w_acnt)[2 * tid] = z; reinterpret_cast<uint4*>(w_acnt)[2 * tid + 1] = z;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { reinterpret_cast<uint4*>(w_asx)[4 * tid + q] = z; reinterpret_cast<uint4*>(w_asy)[4 * tid + q] = z; }
+            u32 r[SG_SEGMAX];
+            __syncthreads();                             // (every wave's walk is over: the counts stand)
+            lat_local_roots(Pl, lpq, min(misc[5], LT_PQ), base, min(nseg, (u32)SG_SEGMAX), xl, &misc[12], r);
+            const int nrec = min(misc[4], LT_REC);
+            for (int i = tid; i < nrec; i += LT_NT) {
+                const u32 nd = Pl[w_rsid[i] - base];
+                atomicMin(&w_apos[nd], w_rpos[i]); atomicAdd(&w_acnt[nd], w_rcnt[i]);
+                atomicAdd(&w_asx[nd], (u64)w_rsx[i]); atomicAdd(&w_asy[nd], (u64)w_rsy[i]);
+            }
+            lat_local_out(Pl, base, xl, min(misc[12], LT_XPQ), r, xpqg + (size_t)wg * LT_XPQ, lroot + base);
+            __syncthreads();
+#pragma unroll
+            for (u32 i = 0; i < SG_SEGMAX; ++i) {
+                const u32 sl = 8u * (u32)tid + i;
+                if (i < nseg && r[i] == sl) {            // a node: its sums go out
+                    const int k = atomicAdd(&misc[13], 1);
+                    if (k < LT_NODE) {
+                        const u64 sx = w_asx[sl], sy_ = w_asy[sl];
+                        nodes[2 * ((size_t)wg * LT_NODE + k)] = make_uint4(base + sl, w_apos[sl], w_acnt[sl], 0u);
+                        nodes[2 * ((size_t)wg * LT_NODE + k) + 1] = make_uint4((u32)sx, (u32)(sx >> 32), (u32)sy_, (u32)(sy_ >> 32));
+                    }
+                }
+            }
+        }
         __syncthreads();
         if (tid == 0) {
-            if (misc[5] > LT_PQ || misc[12] > LT_XPQ) misc[6] = SLOW_SLOTS;
-            hdr[LH_NREC + wg] = (u32)min(misc[4], LT_REC);
+            if (misc[5] > LT_PQ || misc[12] > LT_XPQ || misc[13] > LT_NODE) misc[6] = SLOW_SLOTS;
+            hdr[LH_NREC + wg] = (u32)min(misc[13], LT_NODE);
             hdr[LH_NPQB + wg] = (u32)min(misc[12], LT_XPQ);
             if (misc[6]) atomicMax(&hdr[LH_WHY], (u32)misc[6]);
         }
@@ -442,29 +474,29 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             LT_STAMP(3);
             u32 go = 1;
             const u32 whyw = __atomic_load_n(&hdr[LH_WHY], __ATOMIC_RELAXED);
-            u32 ncomp = 0;
+            u32 ncomp = 0, nnodes = 0;
             if (whyw) { hand_on(whyw); go = 2; }
             else {
-                for (u32 ft = tid; ft < FT; ft += LT_NT) mbc[ft] = 0;
-                ncomp = lat_resolve(geo, P, nsegL, nsegG, lroot, xpqg, hdr + LH_NPQB, comp_pos, pre, tmp, min((u32)maxm, 1024u), hdr, 14);
-                if (ncomp == NONE32) { hand_on(SLOW_NCOMP); go = 2; }
+                for (u32 i = tid; i < FT / 4; i += LT_NT) mbc[i] = 0;
+                u32 T = 0;
+                ncomp = lat_resolve<true>(geo, P, ND, nodes, hdr + LH_NREC, lroot, xpqg, hdr + LH_NPQB, comp_pos, pre, tmp,
+                                          min((u32)maxm, 1024u), &T, hdr, 14);
+                if (ncomp >= NONE32 - 1u) { hand_on(ncomp == NONE32 ? SLOW_NCOMP : SLOW_SLOTS); go = 2; }
+                nnodes = T;
             }
             LT_STAMP(4);
             if (go == 1) {
-                // ---- first pixels, rank, component sums (center_of_mass :181): the records once, all of a thread's in flight ----
+                // ---- first pixels, rank, component sums (center_of_mass :181) out of the nodes ---------------------------------
                 u32* acnt = reinterpret_cast<u32*>(accb);                                // [maxm]
                 u64* asx = reinterpret_cast<u64*>(accb + 8 * ((maxm + 1) / 2));           // [maxm]
                 u64* asy = asx + maxm;                                                   // [maxm]
                 for (u32 c = tid; c < ncomp; c += LT_NT) { acnt[c] = 0; asx[c] = 0; asy[c] = 0; }
-                lat_prefix(hdr + LH_NREC, C, LT_REC, pre);
-                struct RecV { u32 sid, pos, cnt, sx, sy; };
-                lat_flat<4>(pre, C, LT_REC,
-                            [&](size_t o) { return RecV{rsid[o], rpos[o], rcnt[o], rsx[o], rsy[o]}; },
-                            [&](const RecV& v) {
-                                const u32 c = P[v.sid] & 0x7FFFu;               // (numbered, not yet ranked: the sums move below)
-                                atomicMin(&comp_pos[c], v.pos);
-                                atomicAdd(&acnt[c], v.cnt); atomicAdd(&asx[c], (u64)v.sx); atomicAdd(&asy[c], (u64)v.sy);
-                            });
+                __syncthreads();
+                for (u32 t = tid; t < nnodes; t += LT_NT) {
+                    const u32 c = P[ND.root[t]] & 0x7FFFu;       // (numbered, not yet ranked: the sums move below)
+                    atomicMin(&comp_pos[c], ND.pos[t]);
+                    atomicAdd(&acnt[c], ND.cnt[t]); atomicAdd(&asx[c], ND.sx[t]); atomicAdd(&asy[c], ND.sy[t]);
+                }
                 lat_rank(comp_pos, cidmap, ncomp);
                 // the sums go out; the probe requests (2x2 pixel cell around every centroid) go to the threads that own the pixels
                 u64* bs = band_sums + (int64_t)n * maxm * 4;
@@ -486,7 +518,8 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                         if ((q & 1) && px > 0 && (px & 63) != 0) continue;                   // rode along with (ix, py)
                         const int ob = py / R, oi = py - ob * R, ow = ob / G, og = ob - ow * G;
                         const int owner = ow * 64 + og * WW + (px >> 6);
-                        const u32 slot = atomicAdd(&mbc[owner], 1u);
+                        const u32 sh = 8u * ((u32)owner & 3u);
+                        const u32 slot = (atomicAdd(&mbc[owner >> 2], 1u << sh) >> sh) & 0xFFu;   // (byte counters: a carry can only over-count)
                         const int li = atomicAdd(&misc[11], 1);
                         if (slot < ST_MB_CAP && li < LT_REQ)
                             reql[li] = ((u64)(u32)owner << 32) | (c | ((u32)q << 10) | ((u32)oi << 12) | ((u32)(px & 63) << 19) | ((u32)pair << 25));
@@ -585,7 +618,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         auto emit_mom = [&](u32 sid_, int (&m)[NMOM]) {
             const int r = atomicAdd(&misc[7], 1);
             if (r < LT_MREC) {
-                uint4* dst = reinterpret_cast<uint4*>(mrec + ((size_t)wg * LT_MREC + r) * 16);
+                uint4* dst = reinterpret_cast<uint4*>(w_mrec + (size_t)r * 16);
                 dst[0] = make_uint4(sid_, (u32)m[0], (u32)m[1], (u32)m[2]);
                 dst[1] = make_uint4((u32)m[3], (u32)m[4], (u32)m[5], (u32)m[6]);
                 dst[2] = make_uint4((u32)m[7], (u32)m[8], (u32)m[9], (u32)m[10]);
@@ -663,9 +696,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                             if (mo[k][0]) emit_mom(sid[k], mo[k]);
                             if (nseg < SG_SEGMAX) {
                                 sid[k] = sbase + nseg;
-                                const int si = atomicAdd(&misc[10], 1);     // (< LT_SEG: eight per thread)
-                                segl[(size_t)wg * LT_SEG + si] = ((u64)(sbase + nseg) << 32) |
-                                    ((u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1));
+                                w_spos[sbase + nseg - base] = (u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
                             } else why = SLOW_SLOTS;
                             ++nseg;
                             pm[k] = gg;
@@ -773,19 +804,44 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                 if ((pm[k] & 1ull) && l1) pq_push(Q, sbelow - SG_SEGMAX + nrl - 1u, sid[k]);      // its run at bit 63 is its last
             }
         }
-        nsegG[FT + ftid] = (unsigned char)min(nseg, (u32)SG_SEGMAX);
         if (e4) atomicAdd(&misc[0], e4);
         if (why) misc[6] = (int)why;
-        __syncthreads();
         LT_STAMP(7); LT_STAMP_MIN(13);
-        lat_local(Pl, lpq, min(misc[5], LT_PQ), (u32)wg * LT_SEG, min(nseg, (u32)SG_SEGMAX), xpqg + (size_t)wg * LT_XPQ, &misc[12],
-                  lroot + (size_t)wg * LT_SEG);
+        // ---- this workgroup's own part of the resolve: its pairs, its segments' first pixels per node, its moment records out ----
+        {
+            const uint4 o = make_uint4(NONE32, NONE32, NONE32, NONE32);
+            reinterpret_cast<uint4*>(w_opos)[2 * tid] = o; reinterpret_cast<uint4*>(w_opos)[2 * tid + 1] = o;
+            u32 r[SG_SEGMAX];
+            __syncthreads();                             // (every wave's walk is over: the counts stand)
+            lat_local_roots(Pl, lpq, min(misc[5], LT_PQ), base, min(nseg, (u32)SG_SEGMAX), xl, &misc[12], r);
+#pragma unroll
+            for (u32 i = 0; i < SG_SEGMAX; ++i)
+                if (i < nseg) atomicMin(&w_opos[r[i]], w_spos[8u * (u32)tid + i]);
+            lat_local_out(Pl, base, xl, min(misc[12], LT_XPQ), r, xpqg + (size_t)wg * LT_XPQ, lroot + base);
+            const int nm = min(misc[7], LT_MREC);
+            for (int q = tid; q < nm; q += LT_NT) {      // the moment records, each with its segment's node beside the segment id
+                const uint4* src = reinterpret_cast<const uint4*>(w_mrec + (size_t)q * 16);
+                uint4* dst = reinterpret_cast<uint4*>(mrec + ((size_t)wg * LT_MREC + q) * 16);
+                uint4 w0 = src[0];
+                w0.x |= (base + Pl[w0.x - base]) << 16;
+                dst[0] = w0; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
+            }
+            __syncthreads();
+#pragma unroll
+            for (u32 i = 0; i < SG_SEGMAX; ++i) {
+                const u32 sl = 8u * (u32)tid + i;
+                if (i < nseg && r[i] == sl) {
+                    const int k = atomicAdd(&misc[13], 1);
+                    if (k < LT_NODE) nodes[2 * ((size_t)wg * LT_NODE + k)] = make_uint4(base + sl, w_opos[sl], 0u, 0u);
+                }
+            }
+        }
         __syncthreads();
         if (tid == 0) {
-            if (misc[5] > LT_PQ || misc[12] > LT_XPQ) misc[6] = SLOW_SLOTS;
+            if (misc[5] > LT_PQ || misc[12] > LT_XPQ || misc[13] > LT_NODE) misc[6] = SLOW_SLOTS;
             hdr[LH_NMREC + wg] = (u32)min(misc[7], LT_MREC);
             hdr[LH_NPQO + wg] = (u32)min(misc[12], LT_XPQ);
-            hdr[LH_NSEG + wg] = (u32)misc[10];
+            hdr[LH_NSEG + wg] = (u32)min(misc[13], LT_NODE);
             if (misc[0]) atomicAdd(&hdr[LH_EULER], (u32)misc[0]);
             if (misc[6]) atomicMax(&hdr[LH_WHY], (u32)misc[6]);
         }
@@ -798,11 +854,15 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         if (whyw) { hand_on(16u + whyw); return; }
     }
     const u32 nband = ncomp_all[n * 2 + 0];
-    const u32 ncomp = lat_resolve(geo, P, nsegL, nsegG + FT, lroot, xpqg, hdr + LH_NPQO, comp_pos, pre, tmp, min((u32)maxm, (u32)CCL_OPEN_COMPS), hdr, 17);
-    if (ncomp == NONE32) { hand_on(16u + SLOW_NCOMP); return; }
-    lat_prefix(hdr + LH_NSEG, C, LT_SEG, pre);
-    lat_flat<4>(pre, C, LT_SEG, [&](size_t o) { return segl[o]; },
-                [&](u64 v) { atomicMin(&comp_pos[P[(u32)(v >> 32)] & 0x7FFFu], (u32)v); });
+    u32 nnodes = 0;
+    const u32 ncomp = lat_resolve<false>(geo, P, ND, nodes, hdr + LH_NSEG, lroot, xpqg, hdr + LH_NPQO, comp_pos, pre, tmp,
+                                         min((u32)maxm, (u32)CCL_OPEN_COMPS), &nnodes, hdr, 17);
+    if (ncomp >= NONE32 - 1u) { hand_on(16u + (ncomp == NONE32 ? SLOW_NCOMP : SLOW_SLOTS)); return; }
+    for (u32 t = tid; t < nnodes; t += LT_NT) {
+        const u32 c = P[ND.root[t]] & 0x7FFFu;
+        atomicMin(&comp_pos[c], ND.pos[t]);
+        if (ND.root[t] != ND.id[t]) P[ND.id[t]] = (unsigned short)c;      // (every node's entry: its component's number)
+    }
     lat_rank(comp_pos, cidmap, ncomp);
     LT_STAMP(9);
     if ((int)ncomp - (int)__atomic_load_n(&hdr[LH_EULER], __ATOMIC_RELAXED) / 4 != 0) {      // holes: RETR_EXTERNAL needs the fill passes of the general path
@@ -830,9 +890,9 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         struct MomV { uint4 w0, w1, w2, w3; };
         lat_flat<2>(pre, C, LT_MREC,
                     [&](size_t o) { const uint4* src = reinterpret_cast<const uint4*>(mrec + o * 16); return MomV{src[0], src[1], src[2], src[3]}; },
-                    [&](const MomV& v) {
+                    [&](const MomV& v, u32) {
                 const uint4 w0 = v.w0, w1 = v.w1, w2 = v.w2, w3 = v.w3;
-                const u32 s = w0.x, cid = (u32)cidmap[P[s] & 0x7FFFu] - c0;
+                const u32 s = w0.x & 0xFFFFu, cid = (u32)cidmap[P[w0.x >> 16] & 0x7FFFu] - c0;
                 if (cid >= nc) return;                   // another pass's component
                 const u32 ot = s / SG_SEGMAX, ol = ot & 63u, og = ol / (u32)WW;         // the thread that wrote it: its tile
                 const int ox = 64 * (int)(ol - og * (u32)WW) + 32, oy = (int)((ot >> 6) * (u32)G + og) * R + (R >> 1);
@@ -852,9 +912,15 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     }
     LT_STAMP(10);
     // ---- probes: segment -> component ----------------------------------------------------------------------------------
-    for (u32 e = tid; e < nband * 4; e += LT_NT) {
-        const u32 v = pr[e];
-        if (v != NONE16) pr[e] = cidmap[P[v] & 0x7FFFu];
+    for (u32 e0 = tid; e0 < nband * 4; e0 += LT_NT * 4) {    // (a segment's node out of lroot: four lookups in flight)
+        u32 v[4], nd[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const u32 e = e0 + (u32)u * LT_NT; v[u] = e < nband * 4 ? (u32)pr[e] : NONE16; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) nd[u] = v[u] != NONE16 ? (u32)lroot[v[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (v[u] != NONE16) pr[e0 + (u32)u * LT_NT] = cidmap[P[nd[u]] & 0x7FFFu];
     }
     if (tid == 0) { ncomp_all[n * 2 + 1] = ncomp; fstat[n * 8 + 6] = ncomp; fstat[n * 8 + 4] = 0; }
     LT_STAMP(11);
@@ -877,28 +943,24 @@ static bool lat_geom(const vbs_handle* h, LatGeom* g, size_t* lds_bytes) {
     auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += up16(bytes); return (u32)at; };
-    g->o_nseg = take(2 * FT);
-    g->o_rsid = take((size_t)C * LT_REC * 2);
-    g->o_rpos = take((size_t)C * LT_REC * 4);
-    g->o_rcnt = take((size_t)C * LT_REC * 4);
-    g->o_rsx = take((size_t)C * LT_REC * 4);
-    g->o_rsy = take((size_t)C * LT_REC * 4);
+    g->o_node = take((size_t)C * LT_NODE * 32);
     g->o_pq = take((size_t)C * LT_XPQ * 4);
     g->o_lroot = take(8 * FT * 2);
-    g->o_seg = take((size_t)C * LT_SEG * 8);
     g->o_req = take((size_t)LT_REQ * 8);
     g->o_mrec = take((size_t)C * LT_MREC * 64);
     g->stride = (u32)((o + 255) / 256 * 256);
-    // LDS of the resolving workgroup
+    // LDS of the resolving workgroup | of a walking one (the kernel's prologue has the layouts)
     const size_t par = up16(8 * FT * 2);
     const size_t acc_band = up16((size_t)(8 * ((h->maxm + 1) / 2)) + 16 * (size_t)h->maxm);
     const size_t acc_open = up16((size_t)4 * CCL_OPEN_COMPS + (size_t)g->mom_comps * NMOM * 8);
-    g->l_nseg = (u32)par;
-    g->l_comp = (u32)(par + up16(FT));
+    g->l_node = (u32)par;
+    g->l_comp = (u32)(par + (size_t)LT_NODES * 28);
     g->l_acc = g->l_comp + 4096 + 2048;
     g->l_mbc = (u32)(g->l_acc + (acc_band > acc_open ? acc_band : acc_open));
-    g->l_tmp = (u32)(g->l_mbc + up16(FT * 4));
-    *lds_bytes = g->l_tmp + 128;
+    g->l_tmp = (u32)(g->l_mbc + up16(FT));
+    const size_t res = g->l_tmp + 128;
+    const size_t walk_band = (size_t)LT_REC * 18 + (size_t)LT_SEG * 24, walk_open = (size_t)LT_MREC * 64 + (size_t)LT_SEG * 8;
+    *lds_bytes = std::max(res, std::max(walk_band, walk_open));
     return *lds_bytes <= 160 * 1024;
 }
 
