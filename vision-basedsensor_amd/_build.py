@@ -25,7 +25,7 @@ def _stale(target, deps):
 def build(force: bool = False, verbose: bool = False, extra_flags=(), suffix: str = "") -> str:
     """`extra_flags` / `suffix`: a second library next to the product one, e.g. tools/ build `libvbs_dbg.so` with
     -DVBS_DEBUG_KNOBS (phase-timing early exits read from the environment); the product library never has them."""
-    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ccl_common.h"), os.path.join(CSRC, "stage_common.h"), os.path.join(CSRC, "..", "..", "include", "vbs.h")]
+    hdrs = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "ccl_common.h"), os.path.join(CSRC, "stage_common.h"), os.path.join(CSRC, "track_common.h"), os.path.join(CSRC, "..", "..", "include", "vbs.h")]
     lib = LIB.replace(".so", suffix + ".so")
     objs, jobs = [], []
     for src in SOURCES:

@@ -161,7 +161,6 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(area_bits, B * HW); ALLOC(mask_bits, B * HW); ALLOC(band_bits, B * HW);
     ALLOC(open_bits, B * HW);
     ALLOC(ncc_rx, (size_t)width); ALLOC(ncc_ry, (size_t)height);
-    ALLOC(fstat, B * 8 + 8);                           // + one spare word (displacement's first-frame cell)
     ALLOC(wbase, B * 2 * HW);
     ALLOC(node_pos, B * 2 * VBS_RUN_CAP); ALLOC(node_comp, B * 2 * VBS_RUN_CAP);
     ALLOC(ncomp, B * 2);
@@ -169,9 +168,12 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(area_first, B * max_markers); ALLOC(area_sums, B * max_markers * VBS_AREA_SUMS);
     ALLOC(ell, B * max_markers * 8); ALLOC(det64, B * max_markers * 6);
     ALLOC(cnt, B);
-    ALLOC(probe, B * max_markers * 4); ALLOC(lat_hdr, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + B + 4); ALLOC(ncc_tot, 4);
+    ALLOC(probe, B * max_markers * 4); ALLOC(ncc_tot, 4);
+    // one allocation, one fill per pass: k_stage_lat's headers | slow counter | slow flags | frame statistics
+    ALLOC(lat_hdr, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + 4 + B + B * 8 + 8);     // (+ one spare word: displacement's first-frame cell)
     h->slow_total = h->lat_hdr + (size_t)VBS_LAT_MAXN * VBS_LAT_HDR;
-    h->slow_flag = h->slow_total + 4;                    // (one fill clears both - and the headers in front when k_stage_lat runs)
+    h->slow_flag = h->slow_total + 4;
+    h->fstat = h->slow_flag + B;
     if (const size_t per = stage_lat_scratch(h)) ALLOC(lat_scratch, per * (size_t)std::min<size_t>(B, VBS_LAT_MAXN));
     ALLOC(lut, 256);
     ALLOC(blur_frags, frags.size() / 4);
@@ -259,13 +261,25 @@ static int need_gray(vbs_handle* h, int planes, hipStream_t s) {
     return VBS_OK;
 }
 
+// The per-frame statistics of a pass <- 0; for a pass of a few frames also what launch_labelling would clear (k_stage_lat's
+// headers, the slow counter and flags lie in front of fstat in one allocation): one launch instead of two
+static void clear_pass(vbs_handle* h, int nb, hipStream_t s) {
+    if (nb <= h->lat_frames && h->stage_impl == 0 && h->lat_scratch) {
+        launch_fill(h->lat_hdr, 0u, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + 4 + (size_t)h->maxb + (size_t)nb * 8, s);
+        h->pass_cleared = true;
+    } else {
+        launch_fill(h->fstat, 0u, (size_t)nb * 8, s);
+        h->pass_cleared = false;
+    }
+}
+
 // One internal pass of the detection stage.  `pre` = gray plane already converted for this pass (vbs_detect_loop's
 // side-stream pipeline), else the conversion runs here on `s`.
 static int detect_pass(vbs_handle* h, const u8* frames, int nb, int channels, int64_t stride_n,
                        int64_t stride_row, u8* mask_u8, u8* area_u8, double* ncc_out, hipStream_t s, const u8* pre = nullptr) {
     if (!pre && (h->undist || channels != 1)) { int rc = need_gray(h, 1, s); if (rc != VBS_OK) return rc; }
     h->last_ws = h; h->last_nb = nb;                     // (vbs_track_to_3d names the workspace of ITS last pass afterwards)
-    launch_fill(h->fstat, 0u, (size_t)nb * 8, s);
+    clear_pass(h, nb, s);
     if (pre) {
         launch_blur(h, pre, (int64_t)h->H * h->P, h->P, nb, area_u8, s);
     } else if (h->undist) {                             // marker_detection.py:88-89: undistort, then cvtColor
@@ -404,7 +418,7 @@ extern "C" int vbs_normxcorr2(vbs_handle* h, const uint8_t* area_mask, int n, do
     const size_t hw = (size_t)h->H * h->W;
     for (int off = 0; off < n; off += h->maxb) {
         int nb = std::min(h->maxb, n - off);
-        launch_fill(h->fstat, 0u, (size_t)nb * 8, s);
+        clear_pass(h, nb, s);
         launch_threshold(h, area_mask + off * hw, area_mask + off * hw, nb, s);
         launch_popcount(h, nb, s);
         launch_ncc(h, nb, mask ? mask + off * hw : nullptr, ncc ? ncc + off * hw : nullptr, s);
@@ -603,7 +617,7 @@ extern "C" int vbs_marker_center(vbs_handle* h, const uint8_t* mask, const uint8
     const size_t hw = (size_t)h->H * h->W;
     for (int off = 0; off < n; off += h->maxb) {
         int nb = std::min(h->maxb, n - off);
-        launch_fill(h->fstat, 0u, (size_t)nb * 8, s);
+        clear_pass(h, nb, s);
         h->last_ws = h; h->last_nb = nb;
         launch_threshold(h, mask + off * hw, area_mask + off * hw, nb, s);
         launch_labelling(h, nb, s);
@@ -724,11 +738,16 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
         h->last_ws = hh; h->last_nb = nb;                // (what vbs_frame_stats / vbs_stage_tables read)
         if ((rc = gp.release(k)) != VBS_OK) return join(gp.fail(rc));
         launch_labelling(hh, nb, ss);
-        launch_finalize(hh, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr,
-                        counts ? counts + off : nullptr, ss);
-        if (table)
-            launch_track_fused(hh, nb, ref_xy, m_ref, min_dist, table + (size_t)off * m_ref * VBS_TABLE_COLS, cam,
-                               min_marker_size_px, ss);
+        if (table && nb <= hh->lat_frames)               // a few frames: detections and tracking rows in one launch
+            launch_finalize_track(hh, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr, counts ? counts + off : nullptr,
+                                  ref_xy, m_ref, min_dist, table + (size_t)off * m_ref * VBS_TABLE_COLS, cam, min_marker_size_px, ss);
+        else {
+            launch_finalize(hh, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr,
+                            counts ? counts + off : nullptr, ss);
+            if (table)
+                launch_track_fused(hh, nb, ref_xy, m_ref, min_dist, table + (size_t)off * m_ref * VBS_TABLE_COLS, cam,
+                                   min_marker_size_px, ss);
+        }
         rc = check_launch(hh);
         if (rc != VBS_OK) { if (hh != h) h->err = hh->err; return join(gp.fail(rc)); }
     }

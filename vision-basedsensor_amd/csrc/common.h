@@ -101,6 +101,7 @@ struct vbs_handle {
     unsigned char* lat_scratch = nullptr;   // [VBS_LAT_MAXN][stage_lat_scratch()] what the workgroups of a frame share; null = path not available
     int lat_frames = 4;             // vbs_set_option(VBS_OPT_LATENCY_FRAMES): passes of <= this many frames take k_stage_lat (0: never)
     size_t lat_lds_set = 0;
+    bool pass_cleared = false;      // detect_pass cleared the labelling headers / flags of this pass together with fstat
     u32* slow_total;   // [1]  frames of this pass the fused kernel handed on (lets the general kernels leave at once)
     u32* slow_flag;    // [maxb]  non-zero = the fast labelling path handed the frame on (the value says why)
     size_t stage_lds_set = 0, ccl_lds_set[2] = {0, 0};   // dynamic LDS declared for k_stage / k_ccl<0|1> through this handle
@@ -171,6 +172,9 @@ void blur16_fragments(const std::vector<int>& taps_s, const std::vector<int>& ta
                       std::vector<u32>* vfrag);
 void launch_track_fused(vbs_handle* h, int nb, const double* ref_xy, int m_ref, double min_dist,
                         float* table, const vbs_camera* cam, double min_size, hipStream_t s);
+// launch_finalize + launch_track_fused as one launch (k_finalize_track: passes of a few frames)
+void launch_finalize_track(vbs_handle* h, int nb, double* det, int32_t* counts, const double* ref_xy, int m_ref, double min_dist,
+                           float* table, const vbs_camera* cam, double min_size, hipStream_t s);
 void launch_popcount(vbs_handle* h, int nb, hipStream_t s);
 size_t stage_lat_scratch(const vbs_handle* h);          // bytes of scratch per frame k_stage_lat needs for this geometry (0: not taken)
 // n 32-bit words <- value, as a KERNEL on `s`: the per-pass clears of the hot path.  (Not hipMemsetAsync: captured into a HIP

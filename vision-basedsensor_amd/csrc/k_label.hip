@@ -103,18 +103,13 @@ __device__ __forceinline__ u64 hmorph(u64 wl, u64 wc, u64 wr, int lo, int hi) {
 // registers (the ns-row AND by doubling: 2, 4, 8, ns rows).  No LDS, no barrier; a strip re-reads only the ns - 1 rows
 // above / below it.  (The first version staged 32-row tiles in LDS behind four barriers: 0.31 us per 1280x1024 frame.)
 // Outside the image erosion sees 1s (pixels ignored), dilation sees 0s - scipy 'reflect' / cv2's default border.
+// one wave: the G strips `wv` G .. of frame n
 template <int NS14>                                      // ns = 14 (large frames) or 8 (small)
-__global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits, const u64* __restrict__ abits,
-                                               u64* __restrict__ band, u64* __restrict__ opn, const u32* __restrict__ only,
-                                               const u32* __restrict__ nslow,
-                                               int nb, int H, int W, int WW, int G, int strips, int rows_per_strip,
-                                               int waves_per_frame) {
-    if (nslow && *nslow == 0) return;                    // the fused kernel handed no frame on
+__device__ __forceinline__ void morph_wave(const u64* __restrict__ mbits, const u64* __restrict__ abits,
+                                           u64* __restrict__ band, u64* __restrict__ opn, int H, int W, int WW, int G, int strips,
+                                           int rows_per_strip, int n, int wv) {
     const int lane = threadIdx.x & 63;
-    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int n = gw / waves_per_frame;
-    if (n >= nb || (only && !only[n])) return;           // wave-uniform (`only`: just the frames the fused path handed on)
-    const int sidx = (gw - n * waves_per_frame) * G + lane / WW, j = lane % WW;
+    const int sidx = wv * G + lane / WW, j = lane % WW;
     const bool act = lane < G * WW && sidx < strips;
     const int ra = min(sidx * rows_per_strip, H), rb = min(ra + rows_per_strip, H);
     const int64_t fo = (int64_t)n * H * WW;
@@ -186,6 +181,19 @@ __global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits, co
             if (act && yo >= ra && yo < rb) opn[fo + (int64_t)yo * WW + j] = o & vm;
         }
     }
+}
+
+template <int NS14>
+__global__ __launch_bounds__(256) void k_morph(const u64* __restrict__ mbits, const u64* __restrict__ abits,
+                                               u64* __restrict__ band, u64* __restrict__ opn, const u32* __restrict__ only,
+                                               const u32* __restrict__ nslow,
+                                               int nb, int H, int W, int WW, int G, int strips, int rows_per_strip,
+                                               int waves_per_frame) {
+    if (nslow && *nslow == 0) return;                    // the fused kernel handed no frame on
+    const int gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int n = gw / waves_per_frame;
+    if (n >= nb || (only && !only[n])) return;           // wave-uniform (`only`: just the frames the fused path handed on)
+    morph_wave<NS14>(mbits, abits, band, opn, H, W, WW, G, strips, rows_per_strip, n, gw - n * waves_per_frame);
 }
 
 static void launch_morph(vbs_handle* h, int nb, const u32* only, hipStream_t s) {
@@ -481,6 +489,9 @@ __device__ __forceinline__ u32 comp_at(const u64* __restrict__ bits, const u32* 
 //         contours, "inside the contour" and RETR_EXTERNAL's nesting rule are invariant under hole filling, and after
 //         it every border is an outer border, which is what the per-pixel vertex table assumes.
 // mode 2: relabel the (now hole-free) opened mask of those frames.
+// MORPH = 14 | 8 (the few-frames path): the workgroup first makes the frame's band / opened planes itself (k_morph's waves,
+// its sixteen in turn) - one launch less on a path where a launch costs as much as a kernel; 0: the planes are there
+template <int MORPH>
 __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bits,
                                                 u64* __restrict__ open_bits,
                                                 u32* __restrict__ wbase_all, u32* __restrict__ node_pos_all,
@@ -490,7 +501,8 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
                                                 u32* __restrict__ fstat, const u8* __restrict__ lut_g,
                                                 const u32* __restrict__ slow_flag, const u32* __restrict__ nslow,
                                                 unsigned short* __restrict__ probe_all, int nb, int all, int H, int W, int WW,
-                                                int maxm, int stop) {
+                                                int maxm, int stop, const u64* __restrict__ mbits, const u64* __restrict__ abits,
+                                                int mG, int mstrips, int mrps, int mwpf) {
     __shared__ u32 parent[VBS_RUN_CAP];                // union-find parents; later [m=1] the moment accumulators
     __shared__ u64 bnd_w[16][64];                      // last row of every strip: words,
     __shared__ u32 bnd_base[16][64], bnd_cin[16][64];  //   first-node indices, entering nodes
@@ -507,6 +519,10 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     if (nslow && *nslow == 0) return;                    // the fused kernel handed no frame on
     for (int n = blockIdx.x; n < nb; n += gridDim.x) {
     if (!all && !slow_flag[n]) continue;
+    if (MORPH) {                                        // (the stage loop's first fence + barrier publish the planes)
+        for (int wv = (int)(threadIdx.x >> 6); wv < mwpf; wv += 16)
+            morph_wave<(MORPH ? MORPH : 14)>(mbits, abits, const_cast<u64*>(band_bits), open_bits, H, W, WW, mG, mstrips, mrps, n, wv);
+    }
     for (int stage = 0; stage < 4; ++stage) {
     __threadfence();                                    // the previous stage's global writes (holes, filled bits, tables)
     __syncthreads();                                    // are visible; its readers of the LDS tables are done
@@ -874,20 +890,34 @@ bool launch_stage_lat(vbs_handle* h, int nb, hipStream_t s);   // k_stage_lat.hi
 void launch_labelling(vbs_handle* h, int nb, hipStream_t s) {
     // a pass of a few frames (MarkerTracker.process: ONE) spreads each frame over several workgroups: k_stage_lat.hip
     const bool lat = h->stage_impl == 0 && nb <= h->lat_frames && h->lat_scratch != nullptr;
-    if (lat) launch_fill(h->lat_hdr, 0u, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + nb + 4, s);     // its headers, the counter and the flags
+    if (h->pass_cleared) h->pass_cleared = false;        // (detect_pass cleared them with the frame statistics: one launch less)
+    else if (lat) launch_fill(h->lat_hdr, 0u, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + nb + 4, s);     // its headers, the counter and the flags
     else launch_fill(h->slow_total, 0u, (size_t)nb + 4, s);                       // the counter and the flags
     int all = 0;
     const u32* nslow = nullptr;
-    if (h->stage_impl == 0 && ((lat && launch_stage_lat(h, nb, s)) || launch_stage(h, nb, s))) {
+    if (lat && launch_stage_lat(h, nb, s)) {
+        // what it hands on: planes and labels by ONE more kernel (k_label<ns> makes the planes itself); no frame on marker frames
+        const int G = 64 / h->WW, wpf = std::max(1, std::min(64, h->H / (2 * h->bp.ns) / G));
+        const int strips = wpf * G, rps = (h->H + strips - 1) / strips;
+#define LABEL_M(NS_)                                                                                                              \
+        VBS_LAUNCH(h, s, "k_label", k_label<NS_>, dim3(nb), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase, h->node_pos,    \
+                   h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first, h->area_sums, h->fstat, h->lut, h->slow_flag, \
+                   h->slow_total, h->probe, nb, 0, h->H, h->W, h->WW, h->maxm, 0, h->mask_bits, h->area_bits, G, strips, rps, wpf)
+        if (h->bp.ns == 14) LABEL_M(14); else LABEL_M(8);
+#undef LABEL_M
+        return;
+    }
+    if (h->stage_impl == 0 && launch_stage(h, nb, s)) {
         launch_morph(h, nb, h->slow_flag, s);
         nslow = h->slow_total;
     } else {
         launch_morph(h, nb, nullptr, s);
         all = launch_ccl(h, nb, s) ? 0 : 1;
     }
-    VBS_LAUNCH(h, s, "k_label", k_label, dim3(nb < 64 ? nb : 64), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
+    VBS_LAUNCH(h, s, "k_label", k_label<0>, dim3(nb < 64 ? nb : 64), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
                h->node_pos, h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first, h->area_sums, h->fstat,
-               h->lut, h->slow_flag, nslow, h->probe, nb, all, h->H, h->W, h->WW, h->maxm, VBS_KNOB("VBS_LABEL_STOP"));
+               h->lut, h->slow_flag, nslow, h->probe, nb, all, h->H, h->W, h->WW, h->maxm, VBS_KNOB("VBS_LABEL_STOP"),
+               (const u64*)nullptr, (const u64*)nullptr, 0, 0, 0, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1053,22 +1083,23 @@ __device__ bool inside_polygon(const unsigned short* __restrict__ pr, double px,
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_all,
-                                                  const u64* __restrict__ band_sums,
-                                                  const u32* __restrict__ area_first,
-                                                  const i64* __restrict__ area_sums,
-                                                  const unsigned short* __restrict__ probe_all,
-                                                  const u32* __restrict__ fstat, double* __restrict__ ell_all,
-                                                  double* __restrict__ det64, int32_t* __restrict__ cnt64,
-                                                  double* __restrict__ det32, int32_t* __restrict__ cnt32,
-                                                  int H, int W, int WW, int maxm, int stop, int force_seq) {
+// frame n, by one workgroup of 256 threads
+__device__ __forceinline__ void finalize_frame(int n, const u32* __restrict__ ncomp_all,
+                                               const u64* __restrict__ band_sums,
+                                               const u32* __restrict__ area_first,
+                                               const i64* __restrict__ area_sums,
+                                               const unsigned short* __restrict__ probe_all,
+                                               const u32* __restrict__ fstat, double* __restrict__ ell_all,
+                                               double* __restrict__ det64, int32_t* __restrict__ cnt64,
+                                               double* __restrict__ det32, int32_t* __restrict__ cnt32,
+                                               int H, int W, int WW, int maxm, int stop, int force_seq) {
     __shared__ double bx[1024], by[1024];
     __shared__ u8 unmatched[1024];
     __shared__ int best_of[1024], claim[1024], wsum[4];
     __shared__ double thr_s[1024];
     __shared__ u64 best_d[1024];
     __shared__ int dup_s;
-    const int n = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     int status = (int)fstat[n * 8 + 2];
     if (status != 0) {
         if (tid == 0) { cnt64[n] = status; if (cnt32) cnt32[n] = status; }
@@ -1225,9 +1256,49 @@ __global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_
     if (tid == 0) { cnt64[n] = count; if (cnt32) cnt32[n] = count; }
 }
 
+__global__ __launch_bounds__(256) void k_finalize(const u32* __restrict__ ncomp_all, const u64* __restrict__ band_sums,
+                                                  const u32* __restrict__ area_first, const i64* __restrict__ area_sums,
+                                                  const unsigned short* __restrict__ probe_all,
+                                                  const u32* __restrict__ fstat, double* __restrict__ ell_all,
+                                                  double* __restrict__ det64, int32_t* __restrict__ cnt64,
+                                                  double* __restrict__ det32, int32_t* __restrict__ cnt32,
+                                                  int H, int W, int WW, int maxm, int stop, int force_seq) {
+    finalize_frame(blockIdx.x, ncomp_all, band_sums, area_first, area_sums, probe_all, fstat, ell_all, det64, cnt64, det32, cnt32,
+                   H, W, WW, maxm, stop, force_seq);
+}
+
 void launch_finalize(vbs_handle* h, int nb, double* det, int32_t* counts, hipStream_t s) {
     VBS_LAUNCH(h, s, "k_finalize", k_finalize, dim3(nb), dim3(256), 0, s, h->ncomp, h->band_sums, h->area_first,
                        h->area_sums, h->probe, h->fstat, h->ell, h->det64,
                        h->cnt, det, counts, h->H, h->W, h->WW, h->maxm, VBS_KNOB("VBS_FINAL_STOP"),
                        h->force_seq_match ? 1 : 0);                 // (vbs_set_option: exercises the sequential replay)
+}
+
+// The few-frames path: a13 and a15 (+ a19 / a20) of a frame in ONE launch - the same workgroup fits and matches the
+// frame's detections, then tracks them against the reference IDs (a launch on a dependent stream costs ~ 5 us, as much as
+// either kernel works on one frame).  Same code, same results as k_finalize followed by k_track.
+#include "track_common.h"
+__global__ __launch_bounds__(256) void k_finalize_track(const u32* __restrict__ ncomp_all, const u64* __restrict__ band_sums,
+                                                        const u32* __restrict__ area_first, const i64* __restrict__ area_sums,
+                                                        const unsigned short* __restrict__ probe_all,
+                                                        const u32* __restrict__ fstat, double* __restrict__ ell_all,
+                                                        double* __restrict__ det64, int32_t* __restrict__ cnt64,
+                                                        double* __restrict__ det32, int32_t* __restrict__ cnt32,
+                                                        int H, int W, int WW, int maxm, int force_seq,
+                                                        const double* __restrict__ ref_xy, int m_ref, double min_dist,
+                                                        float* __restrict__ table, int do3d, CamD cam, double min_size) {
+    finalize_frame(blockIdx.x, ncomp_all, band_sums, area_first, area_sums, probe_all, fstat, ell_all, det64, cnt64, det32, cnt32,
+                   H, W, WW, maxm, 0, force_seq);
+    __threadfence();                                     // (the frame's detections and count, written by this workgroup)
+    __syncthreads();
+    track_frame(blockIdx.x, det64, cnt64, maxm, ref_xy, m_ref, min_dist, table, do3d, cam, min_size);
+}
+
+void launch_finalize_track(vbs_handle* h, int nb, double* det, int32_t* counts, const double* ref_xy, int m_ref, double min_dist,
+                           float* table, const vbs_camera* cam, double min_size, hipStream_t s) {
+    CamD c{};
+    if (cam) c = make_cam(*cam);
+    VBS_LAUNCH(h, s, "k_finalize_track", k_finalize_track, dim3(nb), dim3(256), 0, s, h->ncomp, h->band_sums, h->area_first,
+               h->area_sums, h->probe, h->fstat, h->ell, h->det64, h->cnt, det, counts, h->H, h->W, h->WW, h->maxm,
+               h->force_seq_match ? 1 : 0, ref_xy, m_ref, min_dist, table, cam ? 1 : 0, c, min_size);
 }
