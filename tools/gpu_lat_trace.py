@@ -13,11 +13,11 @@ spec = S.config2()
 eng = Engine(spec.height, spec.width, max_markers=512, max_batch=n)
 eng.set_option(L.OPT_LATENCY_FRAMES, 8)
 ft = S.make_frames_torch(spec, range(8), seed=0, device="cuda")
-names = ["first start", "last start", "band walk done (last)", "band resolve begins", "  components known", "  sums + requests out",
-         "others go on (last)", "opened walk done (last)", "opened resolve begins", "  components known", "  moments shifted", "end",
+names = ["first start", "last start", "band walk done (last)", "band resolve begins", "  components known", "  sums out, flag set",
+         "others go on (last)", "opened walk done (last)", "opened resolve begins", "  components known", "  moments shifted", "end (probes answered)",
          "band walk done (first)", "opened walk done (first)", "  parents set, counts read", "  pairs united", "  flattened",
          "  parents set, counts read", "  pairs united", "  flattened", "pairs (band walk)", "pairs (opened walk)", "band records", "moment records"]
-order = [0, 1, 12, 2, 3, 14, 15, 16, 4, 5, 6, 13, 7, 8, 17, 18, 19, 9, 10, 11]
+order = [0, 1, 12, 2, 3, 14, 15, 16, 4, 5, 13, 7, 8, 17, 18, 19, 9, 10, 11]
 NS = 20
 acc = np.zeros(NS)
 cnts = np.zeros(4)

@@ -31,15 +31,14 @@
 #define LT_SEG (LT_NT * SG_SEGMAX) // segment ids per workgroup
 #define LT_NODE 256                // components WITHIN a workgroup's tiles ("nodes") it can hand to the frame's resolve
 #define LT_NODES 1024              // nodes per frame the resolving workgroup stages in its LDS
-#define LT_REQ 4096                // probe requests per frame (4 per band component)
 #define LT_ROWS 8                  // rows per thread aimed at
 // header words of a frame (VBS_LAT_HDR each, cleared by launch_labelling's fill together with the slow flags)
 #define LH_ARRIVE1 0
 #define LH_ARRIVE2 1
-#define LH_FLAG 2                  // 1: band components are out, go on; 2: the frame was handed on, leave
+#define LH_FLAG 2                  // 1: the band components and sums are out; 2: the band plane handed the frame on
 #define LH_WHY 3
 #define LH_EULER 4
-#define LH_NREQ 5                  // probe requests in the list
+#define LH_WHYO 5                  // LH_WHY of the opened plane's walk
 #define LH_NREC 16                 // [C] band nodes / pairs out of the band walk / moment records / pairs out of the opened walk / opened nodes
 #define LH_NPQB 32
 #define LH_NMREC 48
@@ -59,8 +58,8 @@ struct LatGeom {
     int H, W, WW, G, NB, R, C, FT, maxm;                  // FT = 256 C threads per frame, NB = 4 C G row blocks of R rows
     u32 mom_comps;
     u32 stride;                                           // bytes of scratch per frame
-    u32 o_node, o_pq, o_lroot, o_req, o_mrec;             // byte offsets into it
-    u32 l_node, l_comp, l_acc, l_mbc, l_tmp;              // byte offsets into the dynamic LDS of the resolving workgroup (parents at 0)
+    u32 o_node, o_pq, o_lroot, o_rst, o_mrec;             // byte offsets into it
+    u32 l_node, l_comp, l_acc, l_tmp;                     // byte offsets into the dynamic LDS of the resolving workgroup (parents at 0)
 };
 
 // exclusive prefix sum over the LT_NT threads; tmp holds >= 8 words
@@ -243,7 +242,6 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int misc[16];         // [0] Euler sum, [4] records, [5] queued pairs, [6] why the frame is handed on, [7] moment records,
                                      // [8] this workgroup is the last of its frame, [9] the flag the others waited for, [10] opened segments
-    __shared__ u32 lmb_cnt[LT_NT], lmb[LT_NT * ST_MB_CAP];       // this workgroup's probe requests, by owner thread
     __shared__ u32 lpq[LT_PQ];                                   // the pairs this workgroup's walk queues
     __shared__ u32 xl[LT_XPQ];                                   // of them, the pairs with a side in another workgroup
     __shared__ __align__(16) unsigned short Pl[LT_SEG];          // parents over its own segments (lat_local)
@@ -272,11 +270,11 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     u32* comp_pos = reinterpret_cast<u32*>(smem + geo.l_comp);                            // [1024] first pixel of a component
     unsigned short* cidmap = reinterpret_cast<unsigned short*>(smem + geo.l_comp + 4096); // [1024] its rank = component id
     unsigned char* accb = smem + geo.l_acc;                                              // band sums | anchors + moments
-    u32* mbc = reinterpret_cast<u32*>(smem + geo.l_mbc);                                  // [FT] bytes: probe requests per owner (counted only)
     u32* tmp = reinterpret_cast<u32*>(smem + geo.l_tmp);                                  // [8], then [24]: prefix of a region list
     u32* pre = tmp + 8;
-    const int wg = blockIdx.x, n = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const int H = geo.H, W = geo.W, WW = geo.WW, G = geo.G, R = geo.R, maxm = geo.maxm, C = geo.C;
+    // workgroups 0 .. C - 1 of a frame take its band plane, C .. 2 C - 1 its opened plane, at the same time
+    const int role = (int)blockIdx.x >= C, wg = (int)blockIdx.x - role * C, n = blockIdx.y, tid = threadIdx.x;
     const u32 FT = (u32)geo.FT, ftid = (u32)wg * LT_NT + (u32)tid;
     const LatTile T = lat_tile(ftid, WW, G);
     const int j = T.j, y0 = T.blk * R;
@@ -287,10 +285,10 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     // the frame's scratch
     u32* hdr = hdr_all + (size_t)n * VBS_LAT_HDR;
     unsigned char* sc = scratch_all + (size_t)n * geo.stride;
-    uint4* nodes = reinterpret_cast<uint4*>(sc + geo.o_node);                             // [C][LT_NODE][2] id, first pixel, count, - | sum x, sum y
-    u32* xpqg = reinterpret_cast<u32*>(sc + geo.o_pq);                                    // [C][LT_XPQ] pairs between workgroups
-    unsigned short* lroot = reinterpret_cast<unsigned short*>(sc + geo.o_lroot);          // [8 FT] a segment's node (its root within its workgroup)
-    u64* reql = reinterpret_cast<u64*>(sc + geo.o_req);                                   // [LT_REQ] probe requests: owner thread << 32 | request
+    uint4* nodes = reinterpret_cast<uint4*>(sc + geo.o_node) + (size_t)role * C * LT_NODE * 2;   // [2][C][LT_NODE][2] id, first pixel, count, - | sum x, sum y
+    u32* xpqg = reinterpret_cast<u32*>(sc + geo.o_pq) + (size_t)role * C * LT_XPQ;        // [2][C][LT_XPQ] pairs between workgroups
+    unsigned short* lroot = reinterpret_cast<unsigned short*>(sc + geo.o_lroot) + (size_t)role * 8 * FT;   // [2][8 FT] a segment's node
+    u64* rst = reinterpret_cast<u64*>(sc + geo.o_rst);   // [R][FT][4] opened walk: the slots' pixels in every row of every tile, their segments
     u32* mrec = reinterpret_cast<u32*>(sc + geo.o_mrec);                                  // [C][LT_MREC][16]  segment id | node << 16, 15 moments
     const u32 base = (u32)wg * LT_SEG;                                                    // this workgroup's first segment id
     PairQ Q;
@@ -298,10 +296,9 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     Q.cap = LT_PQ;
     Q.n = &misc[5];
     if (tid < 16) misc[tid] = 0;
-    lmb_cnt[tid] = 0;
     const int64_t fo = (int64_t)n * H * WW;
-    auto hand_on = [&](u32 why) {                        // (the resolving workgroup, uniformly)
-        if (tid == 0) { slow_flag[n] = why; atomicAdd(slow_total, 1u); }
+    auto hand_on = [&](u32 why) {                        // (a resolving workgroup, uniformly; both may: the frame counts once)
+        if (tid == 0 && atomicCAS(&slow_flag[n], 0u, why) == 0u) atomicAdd(slow_total, 1u);
     };
     // every store of this workgroup out, then one arrival; true in the workgroup that arrived last
     auto arrive = [&](int which) -> bool {
@@ -317,7 +314,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     LT_STAMP_MIN(0); LT_STAMP(1);
 
     // ================================ band plane ====================================================================
-    {
+    if (role == 0) {
         constexpr int NA = NS / 2, NBL = NS / 2 - 1;     // rows of the window above / below its row
         const u64* M = mask_all + fo;
         auto ldraw = [&](int r) -> u64 {
@@ -468,8 +465,8 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             hdr[LH_NPQB + wg] = (u32)min(misc[12], LT_XPQ);
             if (misc[6]) atomicMax(&hdr[LH_WHY], (u32)misc[6]);
         }
-        const bool last = arrive(LH_ARRIVE1);
-        if (last) {
+        if (!arrive(LH_ARRIVE1)) return;
+        {
             // ---- the frame's band components, by this workgroup alone ------------------------------------------------------
             LT_STAMP(3);
             u32 go = 1;
@@ -477,7 +474,6 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             u32 ncomp = 0, nnodes = 0;
             if (whyw) { hand_on(whyw); go = 2; }
             else {
-                for (u32 i = tid; i < FT / 4; i += LT_NT) mbc[i] = 0;
                 u32 T = 0;
                 ncomp = lat_resolve<true>(geo, P, ND, nodes, hdr + LH_NREC, lroot, xpqg, hdr + LH_NPQB, comp_pos, pre, tmp,
                                           min((u32)maxm, 1024u), &T, hdr, 14);
@@ -500,74 +496,19 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                 lat_rank(comp_pos, cidmap, ncomp);
                 // the sums go out; the probe requests (2x2 pixel cell around every centroid) go to the threads that own the pixels
                 u64* bs = band_sums + (int64_t)n * maxm * 4;
-                unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
                 for (u32 cu = tid; cu < ncomp; cu += LT_NT) {
                     const u32 c = cidmap[cu];                // (the sums were gathered by component NUMBER: the id is its rank)
-                    const u32 cn_ = acnt[cu];
-                    const u64 sx = asx[cu], sy_ = asy[cu];
-                    bs[c * 4 + 0] = cn_; bs[c * 4 + 1] = sx; bs[c * 4 + 2] = sy_;
-                    const double cn = (double)cn_;
-                    const float xf = (float)((double)sx / cn), yf = (float)((double)sy_ / cn);
-                    const int ix = (int)floorf(xf), iy = (int)floorf(yf);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int px = ix + (q & 1), py = iy + (q >> 1);
-                        if (px < 0 || py < 0 || px >= W || py >= H) { pr[c * 4 + q] = (unsigned short)NONE16; continue; }
-                        // one request per row and word: the pixel (ix + 1, py) rides along when it lies in the same word
-                        const bool pair = (q & 1) == 0 && px + 1 < W && (px & 63) != 63;
-                        if ((q & 1) && px > 0 && (px & 63) != 0) continue;                   // rode along with (ix, py)
-                        const int ob = py / R, oi = py - ob * R, ow = ob / G, og = ob - ow * G;
-                        const int owner = ow * 64 + og * WW + (px >> 6);
-                        const u32 sh = 8u * ((u32)owner & 3u);
-                        const u32 slot = (atomicAdd(&mbc[owner >> 2], 1u << sh) >> sh) & 0xFFu;   // (byte counters: a carry can only over-count)
-                        const int li = atomicAdd(&misc[11], 1);
-                        if (slot < ST_MB_CAP && li < LT_REQ)
-                            reql[li] = ((u64)(u32)owner << 32) | (c | ((u32)q << 10) | ((u32)oi << 12) | ((u32)(px & 63) << 19) | ((u32)pair << 25));
-                        else misc[6] = SLOW_MAILBOX;
-                    }
+                    bs[c * 4 + 0] = acnt[cu]; bs[c * 4 + 1] = asx[cu]; bs[c * 4 + 2] = asy[cu];
                 }
-                __syncthreads();
-                if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; hdr[LH_NREQ] = (u32)min(misc[11], LT_REQ); }
-                if (misc[6]) { hand_on(SLOW_MAILBOX); go = 2; }      // a crowded mailbox
+                if (tid == 0) { ncomp_all[n * 2 + 0] = ncomp; fstat[n * 8 + 5] = ncomp; }
             }
             LT_STAMP(5);
+            // the band sums are out (or the frame is handed on): the opened plane's resolve reads the centroids for its probes
             __threadfence();
             __syncthreads();
-            if (tid == 0) { atomicExch(&hdr[LH_FLAG], go); misc[9] = (int)go; }
-            __syncthreads();
-        } else {
-            if (tid == 0) {
-                u32 f = 0;
-                for (int it = 0; it < (1 << 19); ++it) {
-                    f = __atomic_load_n(&hdr[LH_FLAG], __ATOMIC_RELAXED);
-                    if (f) break;
-                    __builtin_amdgcn_s_sleep(8);
-                }
-                misc[9] = (int)f;
-            }
-            __syncthreads();
-            __threadfence();
+            if (tid == 0) atomicExch(&hdr[LH_FLAG], go);
         }
-        const int f = misc[9];
-        if (f != 1) {
-            // 2: the frame was handed on.  0: the wait ran out (a workgroup of the frame never arrived): say so, never go on
-            if (f == 0 && tid == 0) atomicMin((int*)&fstat[n * 8 + 2], VBS_EINTERNAL);
-            return;
-        }
-        if (tid < 16 && tid != 9) misc[tid] = 0;
-        // this wave's lanes' probe requests out of the frame's list (a wave only fills its own lanes' boxes)
-        {
-            const u32 nreq = __atomic_load_n(&hdr[LH_NREQ], __ATOMIC_RELAXED), fw = ftid >> 6;
-            for (u32 i = lane; i < nreq; i += 64) {
-                const u64 rq = reql[i];
-                const u32 owner = (u32)(rq >> 32);
-                if ((owner >> 6) != fw) continue;
-                const u32 ot = owner - (u32)wg * LT_NT, slot = atomicAdd(&lmb_cnt[ot], 1u);
-                if (slot < ST_MB_CAP) lmb[ot * ST_MB_CAP + slot] = (u32)rq;
-            }
-        }
-        __syncthreads();
-        LT_STAMP(6);
+        return;
     }
 
     // ================================ opened area plane =============================================================
@@ -588,19 +529,6 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         u64 e5[4] = {~0ull, ~0ull, ~0ull, ~0ull}, d5[4] = {0, 0, 0, 0};
         u64 o1 = 0, o2 = 0;                              // the opened rows before the newest one
         u32 l1 = 0, l2 = 0, r1 = 0, r2 = 0;              // bit 63 of the word to the left / bit 0 of the word to the right in those rows
-        // this thread's probe requests (in registers: a request read from memory where its row comes by would stall the wave)
-        u64 rowm[2] = {0, 0};                            // (R <= 128)
-        const u32 nreq = min(lmb_cnt[tid], (u32)ST_MB_CAP);
-        u32 req[ST_MB_CAP];
-#pragma unroll
-        for (u32 q = 0; q < ST_MB_CAP; ++q) {
-            req[q] = q < nreq ? lmb[tid * ST_MB_CAP + q] : 0u;
-            if (q < nreq) {
-                const u32 rr = (req[q] >> 12) & 127u;
-                if (rr < 64) rowm[0] |= 1ull << rr; else rowm[1] |= 1ull << (rr - 64);
-            }
-        }
-        auto row_asked = [&](int c) -> bool { return ((c < 64 ? rowm[0] >> c : rowm[1] >> (c - 64)) & 1ull) != 0; };
         u64 pm[SG_KO];
         u32 sid[SG_KO];
         int mo[SG_KO][NMOM];                             // vertex moments about the tile's centre
@@ -677,7 +605,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                     }
                 }
             }
-            if (c >= 0 && __any(o1 != 0ull || live || row_asked(c))) {
+            if (c >= 0 && __any(o1 != 0ull || live)) {
                 const u64 B = o1;
                 // ---- segments ---------------------------------------------------------------------------------------------
                 const u64 rB = brev64(B);
@@ -707,23 +635,6 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                 }
                 if (__any(((B >> 63) | B) & 1ull)) seg_hlinks<SG_KO, true>(pm, sid, hasr, p63, prs0, la, lb, Q);
                 else { p63 = NONE16; prs0 = NONE16; }    // (no pixel at a word edge in this row: nothing for the next row to meet)
-                // ---- probes: the segment that holds a pixel of this row ---------------------------------------------------
-                if (row_asked(c)) {
-#pragma unroll
-                    for (u32 qq = 0; qq < ST_MB_CAP; ++qq) {
-                        const u32 rq = req[qq];
-                        if (qq >= nreq || ((rq >> 12) & 127u) != (u32)c) continue;
-                        const u32 q0 = (rq >> 10) & 3u;
-                        for (u32 d = 0; d <= ((rq >> 25) & 1u); ++d) {
-                            const u32 kb = ((rq >> 19) & 63u) + d;
-                            u32 s = NONE16;
-#pragma unroll
-                            for (int k = 0; k < SG_KO; ++k)
-                                if ((pm[k] >> kb) & 1ull) s = sid[k];
-                            pr[(rq & 1023u) * 4 + q0 + d] = (unsigned short)s;
-                        }
-                    }
-                }
                 // ---- contour vertices -------------------------------------------------------------------------------------
                 if (__any(B != 0ull)) {
                     const u64 D0 = (B >> 1) | ((u64)r1 << 63), D4 = (B << 1) | (u64)l1;
@@ -775,6 +686,13 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                 }
             } else if (c >= 0) {
                 p63 = NONE16; prs0 = NONE16;             // an empty row: nothing to link the next one with
+            }
+            // the slots' pixels in row c and their segments: what a probe (the component at a pixel next to a band centroid,
+            // asked once the band plane is resolved - by then this walk is over) is answered from
+            if (c >= 0) {
+                uint4* dst = reinterpret_cast<uint4*>(rst + ((size_t)c * FT + ftid) * 4);
+                dst[0] = make_uint4((u32)pm[0], (u32)(pm[0] >> 32), (u32)pm[1], (u32)(pm[1] >> 32));
+                dst[1] = make_uint4((u32)pm[2], (u32)(pm[2] >> 32), sid[0] | (sid[1] << 16), sid[2]);
             }
             o2 = o1; o1 = o0; l2 = l1; l1 = l0; r2 = r1; r1 = r0;
         }
@@ -843,17 +761,16 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             hdr[LH_NPQO + wg] = (u32)min(misc[12], LT_XPQ);
             hdr[LH_NSEG + wg] = (u32)min(misc[13], LT_NODE);
             if (misc[0]) atomicAdd(&hdr[LH_EULER], (u32)misc[0]);
-            if (misc[6]) atomicMax(&hdr[LH_WHY], (u32)misc[6]);
+            if (misc[6]) atomicMax(&hdr[LH_WHYO], (u32)misc[6]);
         }
     }
     if (!arrive(LH_ARRIVE2)) return;
     LT_STAMP(8);
     // ---- the frame's opened components, by this workgroup alone --------------------------------------------------------
     {
-        const u32 whyw = __atomic_load_n(&hdr[LH_WHY], __ATOMIC_RELAXED);
+        const u32 whyw = __atomic_load_n(&hdr[LH_WHYO], __ATOMIC_RELAXED);
         if (whyw) { hand_on(16u + whyw); return; }
     }
-    const u32 nband = ncomp_all[n * 2 + 0];
     u32 nnodes = 0;
     const u32 ncomp = lat_resolve<false>(geo, P, ND, nodes, hdr + LH_NSEG, lroot, xpqg, hdr + LH_NPQO, comp_pos, pre, tmp,
                                          min((u32)maxm, (u32)CCL_OPEN_COMPS), &nnodes, hdr, 17);
@@ -911,16 +828,64 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         __syncthreads();
     }
     LT_STAMP(10);
-    // ---- probes: segment -> component ----------------------------------------------------------------------------------
-    for (u32 e0 = tid; e0 < nband * 4; e0 += LT_NT * 4) {    // (a segment's node out of lroot: four lookups in flight)
-        u32 v[4], nd[4];
+    // ---- probes: the opened component at the four pixels around every band centroid -------------------------------------
+    // the band plane's resolve runs beside this one and is shorter; its flag says the centroids are out
+    if (tid == 0) {
+        u32 f = 0;
+        for (int it = 0; it < (1 << 19); ++it) {
+            f = __atomic_load_n(&hdr[LH_FLAG], __ATOMIC_RELAXED);
+            if (f) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        misc[9] = (int)f;
+    }
+    __syncthreads();
+    __threadfence();
+    {
+        const int f = misc[9];
+        if (f != 1) {
+            // 2: the band plane handed the frame on.  0: the wait ran out (a workgroup of the frame never arrived): say so
+            if (f == 0 && tid == 0) atomicMin((int*)&fstat[n * 8 + 2], VBS_EINTERNAL);
+            return;
+        }
+    }
+    const u32 nband = ncomp_all[n * 2 + 0];
+    const u64* bs = band_sums + (int64_t)n * maxm * 4;
+    for (u32 e0 = tid; e0 < nband * 4; e0 += LT_NT * 2) {   // (two probes per thread in flight: centroid -> row slots -> node)
+        u32 sg[2];
+        uint4 t0[2], t1[2];
+        int kb[2];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { const u32 e = e0 + (u32)u * LT_NT; v[u] = e < nband * 4 ? (u32)pr[e] : NONE16; }
+        for (int u = 0; u < 2; ++u) {
+            const u32 e = e0 + (u32)u * LT_NT;
+            kb[u] = -1;
+            if (e >= nband * 4) continue;
+            const u32 c = e >> 2, q = e & 3u;
+            const double cn = (double)(u32)bs[c * 4 + 0];
+            const float xf = (float)((double)bs[c * 4 + 1] / cn), yf = (float)((double)bs[c * 4 + 2] / cn);
+            const int px = (int)floorf(xf) + (int)(q & 1u), py = (int)floorf(yf) + (int)(q >> 1);
+            if (px < 0 || py < 0 || px >= W || py >= H) continue;
+            const int ob = py / R, oi = py - ob * R, ow = ob / G, og = ob - ow * G;
+            const u32 owner = (u32)(ow * 64 + og * WW + (px >> 6));
+            const uint4* src = reinterpret_cast<const uint4*>(rst + ((size_t)oi * FT + owner) * 4);
+            t0[u] = src[0]; t1[u] = src[1];
+            kb[u] = px & 63;
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u) nd[u] = v[u] != NONE16 ? (u32)lroot[v[u]] : 0u;
+        for (int u = 0; u < 2; ++u) {
+            sg[u] = NONE16;
+            if (kb[u] < 0) continue;
+            const u64 m0 = mk64(t0[u].x, t0[u].y), m1 = mk64(t0[u].z, t0[u].w), m2 = mk64(t1[u].x, t1[u].y);
+            if ((m0 >> kb[u]) & 1ull) sg[u] = t1[u].z & 0xFFFFu;
+            if ((m1 >> kb[u]) & 1ull) sg[u] = t1[u].z >> 16;
+            if ((m2 >> kb[u]) & 1ull) sg[u] = t1[u].w & 0xFFFFu;
+            if (sg[u] != NONE16) sg[u] = lroot[sg[u]];   // its node
+        }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (v[u] != NONE16) pr[e0 + (u32)u * LT_NT] = cidmap[P[nd[u]] & 0x7FFFu];
+        for (int u = 0; u < 2; ++u) {
+            const u32 e = e0 + (u32)u * LT_NT;
+            if (e < nband * 4) pr[e] = sg[u] != NONE16 ? cidmap[P[sg[u]] & 0x7FFFu] : (unsigned short)NONE16;
+        }
     }
     if (tid == 0) { ncomp_all[n * 2 + 1] = ncomp; fstat[n * 8 + 6] = ncomp; fstat[n * 8 + 4] = 0; }
     LT_STAMP(11);
@@ -943,10 +908,10 @@ static bool lat_geom(const vbs_handle* h, LatGeom* g, size_t* lds_bytes) {
     auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += up16(bytes); return (u32)at; };
-    g->o_node = take((size_t)C * LT_NODE * 32);
-    g->o_pq = take((size_t)C * LT_XPQ * 4);
-    g->o_lroot = take(8 * FT * 2);
-    g->o_req = take((size_t)LT_REQ * 8);
+    g->o_node = take((size_t)2 * C * LT_NODE * 32);
+    g->o_pq = take((size_t)2 * C * LT_XPQ * 4);
+    g->o_lroot = take(2 * 8 * FT * 2);
+    g->o_rst = take((size_t)R * FT * 32);
     g->o_mrec = take((size_t)C * LT_MREC * 64);
     g->stride = (u32)((o + 255) / 256 * 256);
     // LDS of the resolving workgroup | of a walking one (the kernel's prologue has the layouts)
@@ -956,8 +921,7 @@ static bool lat_geom(const vbs_handle* h, LatGeom* g, size_t* lds_bytes) {
     g->l_node = (u32)par;
     g->l_comp = (u32)(par + (size_t)LT_NODES * 28);
     g->l_acc = g->l_comp + 4096 + 2048;
-    g->l_mbc = (u32)(g->l_acc + (acc_band > acc_open ? acc_band : acc_open));
-    g->l_tmp = (u32)(g->l_mbc + up16(FT));
+    g->l_tmp = (u32)(g->l_acc + (acc_band > acc_open ? acc_band : acc_open));
     const size_t res = g->l_tmp + 128;
     const size_t walk_band = (size_t)LT_REC * 18 + (size_t)LT_SEG * 24, walk_open = (size_t)LT_MREC * 64 + (size_t)LT_SEG * 8;
     *lds_bytes = std::max(res, std::max(walk_band, walk_open));
@@ -981,7 +945,7 @@ static bool stage_lat_launch_t(vbs_handle* h, int nb, const LatGeom& g, size_t l
         }
         h->lat_lds_set = lds;
     }
-    VBS_LAUNCH(h, s, "k_stage_lat", (k_stage_lat<NS>), dim3(g.C, nb), dim3(LT_NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
+    VBS_LAUNCH(h, s, "k_stage_lat", (k_stage_lat<NS>), dim3(2 * g.C, nb), dim3(LT_NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
                h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, h->slow_total, h->lat_hdr,
                h->lat_scratch, g);
     return true;
