@@ -42,7 +42,10 @@ Extra objects on the JSON line:
                 equal on every rank), pipelined_gather; frame0_ids = the device ID assignment and its host checker.
                 also: bgr_fps (the same workload fed as 3-channel BGR frames, the reference's input format),
                 host_path_fps (NumPy frames in host memory -> CSV on disk through MarkerTracker), the NCC decision
-                counters of the timed batch, world size / backend as torch.distributed reports them.
+                counters of the timed batch, world size / backend as torch.distributed reports them;
+                single_frame_us (BASELINE config 2, the way MarkerTracker.process calls: ONE resident frame per call, track ->
+                3-D, call + stream synchronise; `eager` and `graph_replay` = the same call captured once into a HIP graph;
+                `per_kernel_us` by HIP events).
 """
 import argparse
 import glob
@@ -246,6 +249,64 @@ def cpu_baseline(spec, seed, cam, single_frames, max_workers, per_worker, warm=2
                       f"{limits} ({logical} logical CPUs"
                       f"{'; capped by --cpu-workers' if workers < available else ''}) x {per_worker} frames after "
                       f"{warm} warm-ups each = value; pool wall incl. spawn {wall:.1f}s"}
+
+
+def single_frame_us(spec, seed, cam_params, reps=200):
+    """One frame per call (marker_detection.py:434-453): latency of vbs_track_to_3d on one resident frame, stream synchronised."""
+    import torch
+    import vbs_amd.synth as S
+    from vbs_amd import _lib as L
+    from vbs_amd.engine import Engine
+    from vbs_amd.pipeline import reference_from_frame0
+    eng = Engine(spec.height, spec.width, max_markers=1024 if spec.n_markers > 400 else 512, max_batch=1)
+    ft = S.make_frames_torch(spec, range(8), seed=seed, device="cuda")
+    cam = L.make_camera(*cam_params, 2.0)
+    ids, xy = reference_from_frame0(eng, ft[:1], 5, "full", "optimal")
+    xy_d = torch.as_tensor(xy, dtype=torch.float64, device="cuda")
+    for i in range(5):
+        eng.track_to_3d(ft[i % 8:i % 8 + 1], xy_d, 20.0, cam, 5.0)
+    torch.cuda.synchronize()
+    ts = []
+    for i in range(reps):
+        t0 = time.perf_counter()
+        table, _, _ = eng.track_to_3d(ft[i % 8:i % 8 + 1], xy_d, 20.0, cam, 5.0)
+        torch.cuda.synchronize()
+        ts.append(time.perf_counter() - t0)
+    tracked = int((table[..., 0].int() & 1).sum())
+    eng.profile(True)
+    for i in range(20):
+        eng.track_to_3d(ft[i % 8:i % 8 + 1], xy_d, 20.0, cam, 5.0)
+    torch.cuda.synchronize()
+    per = {k: round(1e3 * v[1] / v[0], 1) for k, v in eng.profile_read().items()}
+    eng.profile(False)
+    out = {"eager": round(1e6 * sorted(ts)[len(ts) // 2], 1), "eager_mean": round(1e6 * sum(ts) / len(ts), 1), "per_kernel_us": per,
+           "tracked": tracked, "markers": len(ids), "frame": f"{spec.width}x{spec.height}"}
+    try:                                                    # the same call as a HIP graph: copy the frame in, replay, synchronise
+        buf = ft[:1].clone()
+        g = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side):
+                gt, _, _ = eng.track_to_3d(buf, xy_d, 20.0, cam, 5.0)
+        torch.cuda.current_stream().wait_stream(side)
+        for i in range(5):
+            buf.copy_(ft[i % 8:i % 8 + 1]); g.replay()
+        torch.cuda.synchronize()
+        tg = []
+        for i in range(reps):
+            t0 = time.perf_counter()
+            buf.copy_(ft[i % 8:i % 8 + 1]); g.replay()
+            torch.cuda.synchronize()
+            tg.append(time.perf_counter() - t0)
+        ref, _, _ = eng.track_to_3d(ft[(reps - 1) % 8:(reps - 1) % 8 + 1], xy_d, 20.0, cam, 5.0)
+        torch.cuda.synchronize()
+        out["graph_replay"] = round(1e6 * sorted(tg)[len(tg) // 2], 1)
+        out["graph_equals_eager"] = bool(torch.equal(ref, gt))
+    except Exception as e:
+        out["graph_replay"] = None
+        out["graph_error"] = f"{type(e).__name__}: {e}"
+    eng.close()
+    return out
 
 
 def host_path_fps(spec, n, seed, batch):
@@ -640,6 +701,10 @@ def main():
             result["config"]["host_path_fps"] = host_path_fps(spec, args.host_frames, args.seed, 128)
         except Exception as e:
             result["config"]["host_path_fps"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            result["config"]["single_frame_us"] = single_frame_us(spec, args.seed, (K, dist, R, T))
+        except Exception as e:
+            result["config"]["single_frame_us"] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not crop:
         try:
             result["cpu_baseline"] = cpu_baseline(spec, args.seed, (K, dist, R, T), args.cpu_single_frames,

@@ -837,6 +837,15 @@ def test_batch_and_chunk_independence():
     tc, _, _ = eng_b.track_to_3d(ft[perm.cuda()].contiguous(), xy, 20.0, cam)
     assert torch.equal(tc, ta[perm.cuda()])
     assert int((ta[..., 0].int() & 1).sum()) == n * spec.n_markers
+    # one frame per call and per internal pass (MarkerTracker.process, marker_detection.py:434-453: the several-workgroups
+    # labelling kernel and the one-launch finalize + track): the same rows
+    eng_1 = engine(spec.height, spec.width, max_batch=1)
+    t1, _, _ = eng_1.track_to_3d(ft, xy, 20.0, cam)
+    assert torch.equal(t1, ta)
+    for i in (0, 7, 23):
+        ti, _, _ = eng_1.track_to_3d(ft[i:i + 1], xy, 20.0, cam)
+        assert torch.equal(ti[0], ta[i])
+    eng_1.close()
     # torch-rendered frames are the same bytes as the NumPy renderer's
     assert np.array_equal(ft[3].cpu().numpy(), S.make_frames(spec, [3], seed=2)[0])
     eng_a.close()
