@@ -5,6 +5,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import vbs_amd.synth as S
 from vbs_amd import _lib as L
+if os.environ.get("VBS_LIB_SUFFIX"):                      # e.g. _dbg: the tools build with its environment knobs
+    L.LIB_PATH = L.LIB_PATH.replace("libvbs.so", f"libvbs{os.environ['VBS_LIB_SUFFIX']}.so")
 from vbs_amd.engine import Engine
 from vbs_amd.pipeline import reference_from_frame0
 
@@ -33,6 +35,8 @@ for impl in (int(x) for x in os.environ.get('STAGE_IMPLS', '0').split(',')):
   print("stage impl", impl, {k: round(1e3 * v[1] / v[0], 1) for k, v in p.items()}, "us per launch")
   eng.profile(False)
 
+if os.environ.get("VBS_LIB_SUFFIX"):
+    sys.exit(0)
 # the same call captured into a HIP graph once and replayed per frame (the frame copied into a fixed buffer first): what a
 # caller that feeds one frame at a time (marker_detection.py:434-453) can do about launch latency
 xy_d = torch.as_tensor(xy, dtype=torch.float64, device="cuda")

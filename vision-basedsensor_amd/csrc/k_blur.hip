@@ -883,6 +883,7 @@ void launch_blur(vbs_handle* h, const u8* gray, int64_t gstride_n, int64_t gstri
         const int gx16 = (4 * h->WW + B16_NSW - 1) / B16_NSW, tiles16 = (h->H + 15) / 16;
         int nseg = std::min(tiles16 / 8, std::max(1, (2048 + gx16 * nb - 1) / (gx16 * nb)));     // few frames: split the columns
         nseg = std::max(nseg, 1);
+        if (VBS_KNOB("VBS_BLUR16_NSEG")) nseg = VBS_KNOB("VBS_BLUR16_NSEG");
         const int tps = (tiles16 + nseg - 1) / nseg;
         nseg = (tiles16 + tps - 1) / tps;
         // many frames: a 1-D grid that the kernel maps to (frame, strip group, segment) with a frame's workgroups on one XCD
