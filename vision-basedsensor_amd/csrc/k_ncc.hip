@@ -955,7 +955,7 @@ void launch_ncc(vbs_handle* h, int nb, u8* mask_u8, double* ncc_out, hipStream_t
         // few frames: split the columns - into as many segments as keep every workgroup resident at once (256 CUs x 4): a
         // second, partly filled round costs a one-frame call more than the longer segments (21.0 -> 18.1 us at 1280x1024)
         const int want = h->WW * nb <= 512 ? 1024 : 2048;
-        int nseg = std::min(tilesY, std::max(1, want / (h->WW * nb)));
+        int nseg = std::min(tilesY, std::max(1, want == 1024 ? want / (h->WW * nb) : (want + h->WW * nb - 1) / (h->WW * nb)));
         if (VBS_KNOB("VBS_NCC_NSEG")) nseg = VBS_KNOB("VBS_NCC_NSEG");
         const int tps = (tilesY + nseg - 1) / nseg;
         nseg = (tilesY + tps - 1) / tps;
