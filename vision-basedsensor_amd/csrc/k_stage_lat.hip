@@ -58,7 +58,7 @@ struct LatGeom {
     int H, W, WW, G, NB, R, C, FT, maxm;                  // FT = 256 C threads per frame, NB = 4 C G row blocks of R rows
     u32 mom_comps;
     u32 stride;                                           // bytes of scratch per frame
-    u32 o_node, o_pq, o_lroot, o_rst, o_mrec;             // byte offsets into it
+    u32 o_node, o_pq, o_lroot, o_rst;                     // byte offsets into it
     u32 l_node, l_comp, l_acc, l_tmp;                     // byte offsets into the dynamic LDS of the resolving workgroup (parents at 0)
 };
 
@@ -186,22 +186,45 @@ __device__ __forceinline__ u32 lat_resolve(const LatGeom& geo, unsigned short* P
                                            const unsigned short* lroot, const u32* xpq, const u32* nxpq, u32* comp_pos, u32* pre,
                                            u32* tmp, u32 limit, u32* nnodes, u32* hdr, int st0) {
     const int tid = threadIdx.x;
-    lat_prefix(nnode, geo.C, LT_NODE, pre);
-    const u32 T = pre[geo.C];
+    u32* prx = pre + 32;                                  // prefix of the pair counts (pre keeps the nodes': the moments use it again)
+    __syncthreads();
+    if (tid < geo.C) { pre[tid + 1] = min(nnode[tid], (u32)LT_NODE); prx[tid + 1] = min(nxpq[tid], (u32)LT_XPQ); }    // (one round of loads)
+    __syncthreads();
+    if (tid == 0) { pre[0] = 0; prx[0] = 0; for (int c = 1; c <= geo.C; ++c) { pre[c] += pre[c - 1]; prx[c] += prx[c - 1]; } }
+    __syncthreads();
+    const u32 T = pre[geo.C], TX = prx[geo.C];
     *nnodes = T;
     if (T > (u32)LT_NODES) return NONE32 - 1u;
+    // the first 4 LT_NT pairs (all of them on marker frames) are fetched - pair, then both sides' nodes - while the nodes are staged
+    uint2 pv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const u32 i = (u32)tid + (u32)u * LT_NT;
+        if (i < TX) {
+            u32 w = 0;
+            for (int c = 1; c < geo.C; ++c) w += i >= prx[c];
+            const u32 pr = xpq[(size_t)w * LT_XPQ + (i - prx[w])];
+            pv[u] = make_uint2(lroot[pr >> 16], lroot[pr & 0xFFFFu]);
+        }
+    }
     struct NodeV { uint4 a, b; };
     lat_flat<4>(pre, geo.C, LT_NODE,
-                [&](size_t o) { NodeV v; v.a = nodes[2 * o]; if (BAND) v.b = nodes[2 * o + 1]; return v; },
+                [&](size_t o) { NodeV v; v.a = nodes[(BAND ? 2 : 8) * o]; if (BAND) v.b = nodes[2 * o + 1]; return v; },
                 [&](const NodeV& v, u32 i) {
                     N.id[i] = (unsigned short)v.a.x; N.pos[i] = v.a.y; P[v.a.x] = (unsigned short)v.a.x;
                     if (BAND) { N.cnt[i] = v.a.z; N.sx[i] = mk64(v.b.x, v.b.y); N.sy[i] = mk64(v.b.z, v.b.w); }
                 });
-    lat_prefix(nxpq, geo.C, LT_XPQ, pre);                 // (its barriers: every node's entry is in place)
+    __syncthreads();                                     // (every node's entry is in place)
     LT_STAMP(st0);
-    lat_flat<4>(pre, geo.C, LT_XPQ,
-                [&](size_t o) { const u32 pr = xpq[o]; return make_uint2(lroot[pr >> 16], lroot[pr & 0xFFFFu]); },
-                [&](const uint2& v, u32) { ccl_union(P, v.x, v.y); });
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+        if ((u32)tid + (u32)u * LT_NT < TX) ccl_union(P, pv[u].x, pv[u].y);
+    for (u32 i = (u32)tid + 4u * LT_NT; i < TX; i += LT_NT) {
+        u32 w = 0;
+        for (int c = 1; c < geo.C; ++c) w += i >= prx[c];
+        const u32 pr = xpq[(size_t)w * LT_XPQ + (i - prx[w])];
+        ccl_union(P, lroot[pr >> 16], lroot[pr & 0xFFFFu]);
+    }
     __syncthreads();
     LT_STAMP(st0 + 1);
     u32 nroot = 0;
@@ -267,6 +290,9 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     u32* w_mrec = reinterpret_cast<u32*>(smem);                                           // [LT_MREC][16]
     u32* w_spos = w_mrec + LT_MREC * 16;                                                  // [LT_SEG]
     u32* w_opos = w_spos + LT_SEG;                                                        // [LT_SEG]
+    unsigned short* w_nidx = reinterpret_cast<unsigned short*>(w_opos + LT_SEG);          // [LT_SEG] a node's index in the workgroup's list
+    u64* w_macc = reinterpret_cast<u64*>(w_nidx + LT_SEG);                                // [LT_NODE][NMOM] a node's moments about its first pixel
+    u32* w_nid = reinterpret_cast<u32*>(w_macc + LT_NODE * NMOM);                         // [LT_NODE] its id
     u32* comp_pos = reinterpret_cast<u32*>(smem + geo.l_comp);                            // [1024] first pixel of a component
     unsigned short* cidmap = reinterpret_cast<unsigned short*>(smem + geo.l_comp + 4096); // [1024] its rank = component id
     unsigned char* accb = smem + geo.l_acc;                                              // band sums | anchors + moments
@@ -285,11 +311,12 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     // the frame's scratch
     u32* hdr = hdr_all + (size_t)n * VBS_LAT_HDR;
     unsigned char* sc = scratch_all + (size_t)n * geo.stride;
-    uint4* nodes = reinterpret_cast<uint4*>(sc + geo.o_node) + (size_t)role * C * LT_NODE * 2;   // [2][C][LT_NODE][2] id, first pixel, count, - | sum x, sum y
+    // a workgroup's nodes: band [C][LT_NODE][2 x 16 B] id, first pixel, count, - | sum x, sum y; opened behind them [C][LT_NODE][8 x 16 B]
+    // id, first pixel, 15 moments about it (int64)
+    uint4* nodes = reinterpret_cast<uint4*>(sc + geo.o_node) + (size_t)role * C * LT_NODE * 2;
     u32* xpqg = reinterpret_cast<u32*>(sc + geo.o_pq) + (size_t)role * C * LT_XPQ;        // [2][C][LT_XPQ] pairs between workgroups
     unsigned short* lroot = reinterpret_cast<unsigned short*>(sc + geo.o_lroot) + (size_t)role * 8 * FT;   // [2][8 FT] a segment's node
     u64* rst = reinterpret_cast<u64*>(sc + geo.o_rst);   // [R][FT][4] opened walk: the slots' pixels in every row of every tile, their segments
-    u32* mrec = reinterpret_cast<u32*>(sc + geo.o_mrec);                                  // [C][LT_MREC][16]  segment id | node << 16, 15 moments
     const u32 base = (u32)wg * LT_SEG;                                                    // this workgroup's first segment id
     PairQ Q;
     Q.q = lpq;
@@ -725,39 +752,63 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         if (e4) atomicAdd(&misc[0], e4);
         if (why) misc[6] = (int)why;
         LT_STAMP(7); LT_STAMP_MIN(13);
-        // ---- this workgroup's own part of the resolve: its pairs, its segments' first pixels per node, its moment records out ----
+        // ---- this workgroup's own part of the resolve: its pairs, its segments' first pixels and moment records per node ----
         {
-            const uint4 o = make_uint4(NONE32, NONE32, NONE32, NONE32);
+            const uint4 o = make_uint4(NONE32, NONE32, NONE32, NONE32), z = make_uint4(0, 0, 0, 0);
             reinterpret_cast<uint4*>(w_opos)[2 * tid] = o; reinterpret_cast<uint4*>(w_opos)[2 * tid + 1] = o;
+            for (int q = tid; q < LT_NODE * NMOM / 2; q += LT_NT) reinterpret_cast<uint4*>(w_macc)[q] = z;
             u32 r[SG_SEGMAX];
             __syncthreads();                             // (every wave's walk is over: the counts stand)
             lat_local_roots(Pl, lpq, min(misc[5], LT_PQ), base, min(nseg, (u32)SG_SEGMAX), xl, &misc[12], r);
 #pragma unroll
-            for (u32 i = 0; i < SG_SEGMAX; ++i)
-                if (i < nseg) atomicMin(&w_opos[r[i]], w_spos[8u * (u32)tid + i]);
-            lat_local_out(Pl, base, xl, min(misc[12], LT_XPQ), r, xpqg + (size_t)wg * LT_XPQ, lroot + base);
-            const int nm = min(misc[7], LT_MREC);
-            for (int q = tid; q < nm; q += LT_NT) {      // the moment records, each with its segment's node beside the segment id
-                const uint4* src = reinterpret_cast<const uint4*>(w_mrec + (size_t)q * 16);
-                uint4* dst = reinterpret_cast<uint4*>(mrec + ((size_t)wg * LT_MREC + q) * 16);
-                uint4 w0 = src[0];
-                w0.x |= (base + Pl[w0.x - base]) << 16;
-                dst[0] = w0; dst[1] = src[1]; dst[2] = src[2]; dst[3] = src[3];
-            }
-            __syncthreads();
-#pragma unroll
             for (u32 i = 0; i < SG_SEGMAX; ++i) {
                 const u32 sl = 8u * (u32)tid + i;
-                if (i < nseg && r[i] == sl) {
-                    const int k = atomicAdd(&misc[13], 1);
-                    if (k < LT_NODE) nodes[2 * ((size_t)wg * LT_NODE + k)] = make_uint4(base + sl, w_opos[sl], 0u, 0u);
+                if (i < nseg) {
+                    atomicMin(&w_opos[r[i]], w_spos[sl]);
+                    if (r[i] == sl) {                    // a node: its place in the workgroup's list
+                        const int k = atomicAdd(&misc[13], 1);
+                        w_nidx[sl] = (unsigned short)min(k, LT_NODE);
+                        if (k < LT_NODE) w_nid[k] = base + sl;
+                    }
                 }
+            }
+            lat_local_out(Pl, base, xl, min(misc[12], LT_XPQ), r, xpqg + (size_t)wg * LT_XPQ, lroot + base);
+            __syncthreads();                             // (every node's first pixel and index stand)
+            // the moment records (about their tile's centre) -> their node's moments about ITS first pixel: exact in int64, so
+            // the frame's resolve shifts ~ 260 nodes to their component's first pixel instead of 1 500 records
+            const int nm = min(misc[7], LT_MREC);
+            for (int q = tid; q < nm; q += LT_NT) {
+                const uint4* src = reinterpret_cast<const uint4*>(w_mrec + (size_t)q * 16);
+                const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
+                const u32 sg = w0.x, nl = Pl[sg - base], k = w_nidx[nl];
+                if (k >= (u32)LT_NODE) continue;         // (more nodes than the list holds: the frame is handed on)
+                const u32 ot = sg / SG_SEGMAX, ol = ot & 63u, og = ol / (u32)WW;        // the thread that wrote it: its tile
+                const int ox = 64 * (int)(ol - og * (u32)WW) + 32, oy = (int)((ot >> 6) * (u32)G + og) * R + (R >> 1);
+                const u32 fp = w_opos[nl], fy = fp / (u32)W, fx = fp - fy * (u32)W;
+                const i64 m[NMOM] = {(int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w, (int)w2.x,
+                                     (int)w2.y, (int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y, (int)w3.z, (int)w3.w};
+                i64 ms[NMOM];
+                shift_moments_i64(m, (i64)(ox - (int)fx), (i64)(oy - (int)fy), ms);
+                u64* a = w_macc + (size_t)k * NMOM;
+#pragma unroll
+                for (int e = 0; e < NMOM; ++e)
+                    if (ms[e]) atomicAdd(&a[e], (u64)ms[e]);
+            }
+            __syncthreads();
+            const int nn = min(misc[13], LT_NODE);
+            if (tid < nn) {                              // node tid goes out: id, first pixel, its 15 moments
+                const u32 id = w_nid[tid], fp = w_opos[id - base];
+                const u64* a = w_macc + (size_t)tid * NMOM;
+                uint4* dst = nodes + ((size_t)wg * LT_NODE + tid) * 8;
+                dst[0] = make_uint4(id, fp, (u32)a[0], (u32)(a[0] >> 32));
+#pragma unroll
+                for (int e = 0; e < 7; ++e)
+                    dst[1 + e] = make_uint4((u32)a[1 + 2 * e], (u32)(a[1 + 2 * e] >> 32), (u32)a[2 + 2 * e], (u32)(a[2 + 2 * e] >> 32));
             }
         }
         __syncthreads();
         if (tid == 0) {
             if (misc[5] > LT_PQ || misc[12] > LT_XPQ || misc[13] > LT_NODE) misc[6] = SLOW_SLOTS;
-            hdr[LH_NMREC + wg] = (u32)min(misc[7], LT_MREC);
             hdr[LH_NPQO + wg] = (u32)min(misc[12], LT_XPQ);
             hdr[LH_NSEG + wg] = (u32)min(misc[13], LT_NODE);
             if (misc[0]) atomicAdd(&hdr[LH_EULER], (u32)misc[0]);
@@ -799,25 +850,25 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     }
     // ---- segment moments -> component moments about its first pixel, `mom_comps` components per pass -----------------------------
     i64* as = area_sums + (int64_t)n * maxm * VBS_AREA_SUMS;
-    lat_prefix(hdr + LH_NMREC, C, LT_MREC, pre);
     for (u32 c0 = 0; c0 < ncomp; c0 += geo.mom_comps) {
         const u32 nc = min(geo.mom_comps, ncomp - c0);
         for (u32 c = tid; c < nc * NMOM; c += LT_NT) acc[c] = 0;
         __syncthreads();
-        struct MomV { uint4 w0, w1, w2, w3; };
-        lat_flat<2>(pre, C, LT_MREC,
-                    [&](size_t o) { const uint4* src = reinterpret_cast<const uint4*>(mrec + o * 16); return MomV{src[0], src[1], src[2], src[3]}; },
-                    [&](const MomV& v, u32) {
-                const uint4 w0 = v.w0, w1 = v.w1, w2 = v.w2, w3 = v.w3;
-                const u32 s = w0.x & 0xFFFFu, cid = (u32)cidmap[P[w0.x >> 16] & 0x7FFFu] - c0;
+        struct MomV { uint4 w[8]; };
+        lat_flat<2>(pre, C, LT_NODE,
+                    [&](size_t o) { MomV v; const uint4* src = nodes + o * 8;
+#pragma unroll
+                                    for (int e = 0; e < 8; ++e) v.w[e] = src[e];
+                                    return v; },
+                    [&](const MomV& v, u32 t) {
+                const u32 cid = (u32)cidmap[P[ND.root[t]] & 0x7FFFu] - c0;
                 if (cid >= nc) return;                   // another pass's component
-                const u32 ot = s / SG_SEGMAX, ol = ot & 63u, og = ol / (u32)WW;         // the thread that wrote it: its tile
-                const int ox = 64 * (int)(ol - og * (u32)WW) + 32, oy = (int)((ot >> 6) * (u32)G + og) * R + (R >> 1);
-                const u32 fp = anchor[cid + c0];
-                const i64 m[NMOM] = {(int)w0.y, (int)w0.z, (int)w0.w, (int)w1.x, (int)w1.y, (int)w1.z, (int)w1.w, (int)w2.x,
-                                     (int)w2.y, (int)w2.z, (int)w2.w, (int)w3.x, (int)w3.y, (int)w3.z, (int)w3.w};
-                i64 o[NMOM];
-                shift_moments_i64(m, (i64)(ox - (int)(fp & 0xFFFFu)), (i64)(oy - (int)(fp >> 16)), o);
+                const u32 np = v.w[0].y, ny = np / (u32)W, nx = np - ny * (u32)W, fp = anchor[cid + c0];
+                i64 m[NMOM], o[NMOM];
+                m[0] = (i64)mk64(v.w[0].z, v.w[0].w);
+#pragma unroll
+                for (int e = 0; e < 7; ++e) { m[1 + 2 * e] = (i64)mk64(v.w[1 + e].x, v.w[1 + e].y); m[2 + 2 * e] = (i64)mk64(v.w[1 + e].z, v.w[1 + e].w); }
+                shift_moments_i64(m, (i64)((int)nx - (int)(fp & 0xFFFFu)), (i64)((int)ny - (int)(fp >> 16)), o);
                 u64* a = acc + cid * NMOM;
 #pragma unroll
                 for (int q = 0; q < NMOM; ++q)
@@ -908,11 +959,10 @@ static bool lat_geom(const vbs_handle* h, LatGeom* g, size_t* lds_bytes) {
     auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
     size_t o = 0;
     auto take = [&](size_t bytes) { const size_t at = o; o += up16(bytes); return (u32)at; };
-    g->o_node = take((size_t)2 * C * LT_NODE * 32);
+    g->o_node = take((size_t)C * LT_NODE * (32 + 128));
     g->o_pq = take((size_t)2 * C * LT_XPQ * 4);
     g->o_lroot = take(2 * 8 * FT * 2);
     g->o_rst = take((size_t)R * FT * 32);
-    g->o_mrec = take((size_t)C * LT_MREC * 64);
     g->stride = (u32)((o + 255) / 256 * 256);
     // LDS of the resolving workgroup | of a walking one (the kernel's prologue has the layouts)
     const size_t par = up16(8 * FT * 2);
@@ -922,8 +972,9 @@ static bool lat_geom(const vbs_handle* h, LatGeom* g, size_t* lds_bytes) {
     g->l_comp = (u32)(par + (size_t)LT_NODES * 28);
     g->l_acc = g->l_comp + 4096 + 2048;
     g->l_tmp = (u32)(g->l_acc + (acc_band > acc_open ? acc_band : acc_open));
-    const size_t res = g->l_tmp + 128;
-    const size_t walk_band = (size_t)LT_REC * 18 + (size_t)LT_SEG * 24, walk_open = (size_t)LT_MREC * 64 + (size_t)LT_SEG * 8;
+    const size_t res = g->l_tmp + 256;
+    const size_t walk_band = (size_t)LT_REC * 18 + (size_t)LT_SEG * 24;
+    const size_t walk_open = (size_t)LT_MREC * 64 + (size_t)LT_SEG * 10 + (size_t)LT_NODE * (NMOM * 8 + 8);
     *lds_bytes = std::max(res, std::max(walk_band, walk_open));
     return *lds_bytes <= 160 * 1024;
 }
