@@ -15,7 +15,7 @@ typedef uint8_t u8;
 #define VBS_NCC_MAXL 80
 #define VBS_RUN_CAP 30720          // union-find nodes (runs) per mask per frame kept in LDS
 #define VBS_AREA_SUMS 16           // n, 14 moments up to order 4, spare
-#define VBS_LAT_MAXN 8             // passes of at most this many frames may take the few-frames labelling kernel (k_stage_lat.hip)
+#define VBS_LAT_MAXN 32            // passes of at most this many frames may take the few-frames labelling kernel (k_stage_lat.hip)
 #define VBS_LAT_HDR 128            // dwords of counters / flags per frame of that kernel
 
 struct BranchParams {              // marker_detection.py:117-126,129,170
@@ -99,7 +99,7 @@ struct vbs_handle {
     u64* ncc_tot;      // [4]  running NCC decision counters (vbs_ncc_counters)
     u32* lat_hdr;      // [VBS_LAT_MAXN][VBS_LAT_HDR] k_stage_lat's per-frame counters; slow_total / slow_flag follow (one fill clears all)
     unsigned char* lat_scratch = nullptr;   // [VBS_LAT_MAXN][stage_lat_scratch()] what the workgroups of a frame share; null = path not available
-    int lat_frames = 4;             // vbs_set_option(VBS_OPT_LATENCY_FRAMES): passes of <= this many frames take k_stage_lat (0: never)
+    int lat_frames = 24;            // vbs_set_option(VBS_OPT_LATENCY_FRAMES): passes of <= this many frames take k_stage_lat (0: never)
     size_t lat_lds_set = 0;
     bool pass_cleared = false;      // detect_pass cleared the labelling headers / flags of this pass together with fstat
     u32* slow_total;   // [1]  frames of this pass the fused kernel handed on (lets the general kernels leave at once)

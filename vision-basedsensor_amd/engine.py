@@ -151,7 +151,7 @@ class Engine:
     def set_option(self, option: int, value: int):
         """`vbs_set_option`: L.OPT_GRAY_COEFFS (15 | 14), L.OPT_GRAY_SIDE_STREAM (0 | 1), test hooks L.OPT_FORCE_SEQ_MATCH,
         L.OPT_NCC_MARGIN (units of 1e-6), L.OPT_STAGE_IMPL / L.OPT_BLUR_IMPL (0 | 1), L.OPT_PASS_STREAMS (1 | 2),
-        L.OPT_LATENCY_FRAMES (0 .. 8: passes of at most that many frames take the several-workgroups-per-frame labelling kernel)."""
+        L.OPT_LATENCY_FRAMES (0 .. 32: passes of at most that many frames take the several-workgroups-per-frame labelling kernel)."""
         self._check(self.lib.vbs_set_option(self._h, int(option), int(value)), "vbs_set_option")
         if int(option) == L.OPT_PASS_STREAMS:
             self.pass_streams = int(value)
