@@ -1285,6 +1285,39 @@ def test_blur16_hand_shake_that_expires_is_reported_in_counts():
     assert out["4"] == {"counts": [L.VBS_EINTERNAL] * 3, "status": [L.VBS_EINTERNAL] * 3}
 
 
+def test_stage_lat_wait_that_expires_is_reported_in_counts():
+    """k_stage_lat has ONE wait: the workgroup that resolves a frame's opened plane needs the band centroids (the other
+    workgroups' resolve) for its probes.  The wait is bounded, and a wait that expires must not answer the probes from
+    whatever the memory holds: the frame's status becomes VBS_EINTERNAL -> counts[].  Shown once with the debug library
+    (VBS_LAT_DROP = 2: frame 1's band resolve "forgets" to raise its flag); the other frames of the pass are untouched."""
+    import subprocess
+    import sys
+    import vbs_amd._build as B
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbg = B.LIB.replace(".so", "_dbg.so")
+    if not os.path.exists(dbg):
+        B.build(extra_flags=["-DVBS_DEBUG_KNOBS"], suffix="_dbg")
+    code = (
+        "import os, sys, json; sys.path.insert(0, %r)\n"
+        "import torch, vbs_amd.synth as S\n"
+        "from vbs_amd import _lib as L\n"
+        "L.LIB_PATH = %r\n"
+        "from vbs_amd.engine import Engine\n"
+        "spec = S.config2(); ft = S.make_frames_torch(spec, range(3), seed=2, device='cuda')\n"
+        "eng = Engine(spec.height, spec.width, max_markers=512, max_batch=3)\n"
+        "out = {}\n"
+        "for drop in ('0', '2'):\n"
+        "    os.environ['VBS_LAT_DROP'] = drop\n"
+        "    _, _, counts = eng.track_to_3d(ft); torch.cuda.synchronize()\n"
+        "    out[drop] = {'counts': counts.tolist(), 'status': eng.frame_stats(3)[:, 2].astype('int32').tolist()}\n"
+        "print(json.dumps(out))\n" % (root, dbg))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["0"] == {"counts": [169, 169, 169], "status": [0, 0, 0]}
+    assert out["2"] == {"counts": [169, L.VBS_EINTERNAL, 169], "status": [0, L.VBS_EINTERNAL, 0]}
+
+
 def test_passes_on_two_streams_equal_one():
     """VBS_OPT_PASS_STREAMS: the odd internal passes of vbs_track_to_3d on the handle's second workspace and stream
     (default) give, row for row, what all passes on the caller's stream give - tables, detections, counts and the running

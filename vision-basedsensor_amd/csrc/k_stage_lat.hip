@@ -60,6 +60,7 @@ struct LatGeom {
     u32 stride;                                           // bytes of scratch per frame
     u32 o_node, o_pq, o_lroot, o_rst;                     // byte offsets into it
     u32 l_node, l_comp, l_acc, l_tmp;                     // byte offsets into the dynamic LDS of the resolving workgroup (parents at 0)
+    int dbg_drop;                                         // tools build: frame `dbg_drop - 1`'s band resolve "forgets" its flag
 };
 
 // exclusive prefix sum over the LT_NT threads; tmp holds >= 8 words
@@ -533,7 +534,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             // the band sums are out (or the frame is handed on): the opened plane's resolve reads the centroids for its probes
             __threadfence();
             __syncthreads();
-            if (tid == 0) atomicExch(&hdr[LH_FLAG], go);
+            if (tid == 0 && geo.dbg_drop != n + 1) atomicExch(&hdr[LH_FLAG], go);
         }
         return;
     }
@@ -955,6 +956,7 @@ static bool lat_geom(const vbs_handle* h, LatGeom* g, size_t* lds_bytes) {
     if (R > 128 || R < 1) return false;
     g->H = h->H; g->W = h->W; g->WW = h->WW; g->G = G; g->NB = NB; g->R = R; g->C = C; g->FT = LT_NT * C; g->maxm = h->maxm;
     g->mom_comps = (u32)CCL_MOM_COMPS;
+    g->dbg_drop = VBS_KNOB("VBS_LAT_DROP");
     const size_t FT = (size_t)g->FT;
     auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
     size_t o = 0;
