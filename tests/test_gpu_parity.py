@@ -1285,6 +1285,19 @@ def test_blur16_hand_shake_that_expires_is_reported_in_counts():
     assert out["4"] == {"counts": [L.VBS_EINTERNAL] * 3, "status": [L.VBS_EINTERNAL] * 3}
 
 
+def test_stage_lat_under_repetition():
+    """k_stage_lat's workgroups talk through global memory (arrival counters, lists written on one XCD and read on another): a
+    missing fence shows as a RARE wrong table.  tools/gpu_lat_stress.py: 64 frames of each size, their tables by the batch
+    kernel once, then calls with 1 / 3 / 8 / 19 frames in shuffled order through the few-frames kernel (here 6 rounds, ~1 400
+    calls; 40 rounds = 9 120 calls ran clean when it was written): every table, detection row and count identical."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "gpu_lat_stress.py"), "6"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0 and "lat stress all OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_stage_lat_wait_that_expires_is_reported_in_counts():
     """k_stage_lat has ONE wait: the workgroup that resolves a frame's opened plane needs the band centroids (the other
     workgroups' resolve) for its probes.  The wait is bounded, and a wait that expires must not answer the probes from
