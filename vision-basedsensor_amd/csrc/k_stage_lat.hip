@@ -1,25 +1,31 @@
 // a9-a13 for a FEW frames per call (marker_detection.py:170-196 as MarkerTracker.process calls it, one frame at a time,
-// :434-453): k_stage.hip's method with a frame spread over C workgroups of four waves instead of one workgroup of twelve.
+// :434-453): k_stage.hip's method with a frame spread over 2 C workgroups of four waves instead of one workgroup of twelve.
 //
 // k_stage labels a frame on ONE compute unit - the right shape for a batch (one frame per CU, 256 CUs), 190 us for a
-// single frame.  Here a thread's tile is 64 px x ~8 rows instead of x 29, a frame has 256 C threads (C = 11 at
-// 1280x1024) and every wave has a SIMD to itself; what the workgroups of a frame share goes through global memory - and
-// a workgroup on another XCD sees it only through memory, at 1 - 3 us per dependent access, so everything shared is a flat
-// list that is read with many independent loads in flight, never a table that is chased:
+// single frame.  Here a thread's tile is 64 px x ~8 rows instead of x 29, a plane has 256 C threads (C = 11 at
+// 1280x1024), every wave has a SIMD to itself, and the band plane and the opened plane are walked by DIFFERENT workgroups at
+// the same time (workgroups 0 .. C - 1 / C .. 2 C - 1 of a frame).  What the workgroups of a frame share goes through
+// global memory - and a workgroup on another XCD sees it only through memory, at 1.5 - 3 us per dependent access, so
+// everything shared is a flat list that is read with many independent loads in flight, never a table that is chased:
 //   walk      as k_stage (same helpers, stage_common.h): rows through register delay lines, segments in slots, what
-//             crosses a tile only NOTED as a pair.  The link between a tile and the tile BELOW it is made by the upper tile's
-//             thread, which computes the first row of the tile below itself (one more row step; the opened walk has that
-//             row anyway) and knows that tile's segment ids - its first row's runs are its segments 0, 1, .. in order.
-//             Records, pairs, segment first pixels and moment records go to the workgroup's own region of the frame's
-//             scratch (index from an LDS counter: no global atomic on the walk).
-//   resolve   the LAST workgroup of a frame to finish a walk (an arrival counter, nobody waits for a workgroup that has
-//             not started) does what k_stage does after it, alone: parents in its LDS, the queued pairs, flatten, number
-//             the roots, first pixel, rank, sums.  After the band walk the other workgroups of the frame wait for it (the
-//             probe requests of the opened walk come out of the band centroids: a list every wave filters for its own
-//             lanes); after the opened walk they simply leave.  A wait that expires reports VBS_EINTERNAL in the frame's
-//             status, never a wrong table.
-// Results are bit-identical to k_stage's (tests/test_gpu_parity.py::test_latency_stage_equals_the_batch_stage), frames
-// it cannot take are handed on with the same slow flags.
+//             crosses a tile only NOTED as a pair (in LDS).  The link between a tile and the tile BELOW it is made by the
+//             upper tile's thread, which computes the first row of the tile below itself (one more row step; the opened
+//             walk has that row anyway) and knows that tile's segment ids - its first row's runs are its segments 0, 1, ..
+//             The opened walk also writes its slots' pixels and segment ids for every row (32 B per thread and row): the
+//             probes are answered from that table once both planes are resolved.
+//   own part  every workgroup, all at once: the pairs between its own segments united in its LDS; its segments' sums (band:
+//             count / sum x / sum y / first pixel; opened: first pixel, the 15 moments shifted to it) gathered per NODE =
+//             root within the workgroup.  Out go ~ 25 nodes, ~ 20 pairs that reach into the next workgroup (own side
+//             already a node) and every segment's node (lroot).
+//   resolve   the LAST workgroup of a plane to arrive (an arrival counter; nobody waits for a workgroup that has not
+//             started) stages the frame's ~ 260 nodes in its LDS, unites the pairs between workgroups, numbers the roots,
+//             ranks them by first pixel and gathers the nodes' sums per component.  The opened plane's resolve then needs
+//             the band centroids for the probes: the ONE wait of the kernel (the band resolve is the shorter one and has
+//             a lower block index); it is bounded, and expiring reports VBS_EINTERNAL in the frame's status, never a
+//             wrong table.
+// Results are bit-identical to k_stage's (tests/test_gpu_parity.py::test_latency_stage_equals_the_batch_stage,
+// tools/gpu_lat_stress.py), frames it cannot take are handed on to k_label with the same kind of slow flag.
+// DESIGN 4.5 has the measurements that led here (356 -> 48 us per frame).
 #include "stage_common.h"
 
 #define LT_NT 256                  // threads per workgroup: four waves, one per SIMD
@@ -39,9 +45,8 @@
 #define LH_WHY 3
 #define LH_EULER 4
 #define LH_WHYO 5                  // LH_WHY of the opened plane's walk
-#define LH_NREC 16                 // [C] band nodes / pairs out of the band walk / moment records / pairs out of the opened walk / opened nodes
+#define LH_NREC 16                 // [C] band nodes / pairs out of the band walk / pairs out of the opened walk / opened nodes
 #define LH_NPQB 32
-#define LH_NMREC 48
 #define LH_NPQO 64
 #define LH_NSEG 80
 
@@ -265,7 +270,8 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                                                         LatGeom geo) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int misc[16];         // [0] Euler sum, [4] records, [5] queued pairs, [6] why the frame is handed on, [7] moment records,
-                                     // [8] this workgroup is the last of its frame, [9] the flag the others waited for, [10] opened segments
+                                     // [8] this workgroup is the last of its plane, [9] the band plane's flag, [12] pairs between
+                                     // workgroups, [13] nodes
     __shared__ u32 lpq[LT_PQ];                                   // the pairs this workgroup's walk queues
     __shared__ u32 xl[LT_XPQ];                                   // of them, the pairs with a side in another workgroup
     __shared__ __align__(16) unsigned short Pl[LT_SEG];          // parents over its own segments (lat_local)
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
     u32* comp_pos = reinterpret_cast<u32*>(smem + geo.l_comp);                            // [1024] first pixel of a component
     unsigned short* cidmap = reinterpret_cast<unsigned short*>(smem + geo.l_comp + 4096); // [1024] its rank = component id
     unsigned char* accb = smem + geo.l_acc;                                              // band sums | anchors + moments
-    u32* tmp = reinterpret_cast<u32*>(smem + geo.l_tmp);                                  // [8], then [24]: prefix of a region list
+    u32* tmp = reinterpret_cast<u32*>(smem + geo.l_tmp);                                  // [8], then prefixes of the node / pair counts
     u32* pre = tmp + 8;
     const int H = geo.H, W = geo.W, WW = geo.WW, G = geo.G, R = geo.R, maxm = geo.maxm, C = geo.C;
     // workgroups 0 .. C - 1 of a frame take its band plane, C .. 2 C - 1 its opened plane, at the same time
@@ -522,7 +528,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                     atomicAdd(&acnt[c], ND.cnt[t]); atomicAdd(&asx[c], ND.sx[t]); atomicAdd(&asy[c], ND.sy[t]);
                 }
                 lat_rank(comp_pos, cidmap, ncomp);
-                // the sums go out; the probe requests (2x2 pixel cell around every centroid) go to the threads that own the pixels
+                // the sums go out (the opened plane's resolve reads the centroids back for its probes)
                 u64* bs = band_sums + (int64_t)n * maxm * 4;
                 for (u32 cu = tid; cu < ncomp; cu += LT_NT) {
                     const u32 c = cidmap[cu];                // (the sums were gathered by component NUMBER: the id is its rank)
