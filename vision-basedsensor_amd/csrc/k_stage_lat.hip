@@ -357,7 +357,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         };
         auto rowval = [&](u64 raw, int r) -> u64 {       // source row y0 + r; outside the image: ones (ignored by the erosion)
             const int y = y0 + r;
-            return (act && y >= 0 && y < H) ? (raw | ~vm) : ~0ull;
+            return (act && y >= 0 && y < H) ? or_not(raw, vm) : ~0ull;
         };
         u64 pf[4];
 #pragma unroll
@@ -403,7 +403,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             const int t = r - NBL;                       // the row whose window ends at r
             if (t < 0) continue;                         // (uniform)
             const u64 eh = hwin<NS, true>(e, hasl, hasr);
-            const u64 B = (act && y0 + t < H) ? (cr[NBL] & ~eh & vm) : 0ull;      // :171-174  maxima = mask & (window holds a 0)
+            const u64 B = (act && y0 + t < H) ? and_not_and(cr[NBL], eh, vm) : 0ull;      // :171-174  maxima = mask & (window holds a 0)
             if (t == R) {                                // (uniform) this tile's last row against the segments of the tile below
                 u64 N = B;
                 u32 i = 0;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
         };
         auto rowval = [&](u64 raw, int r) -> u64 {
             const int y = y0 + r;
-            return (act && y >= 0 && y < H) ? (raw | ~vm) : ~0ull;
+            return (act && y >= 0 && y < H) ? or_not(raw, vm) : ~0ull;
         };
         u64 pf[4];
 #pragma unroll
@@ -630,11 +630,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                     const u64 a = qq ? 0ull : o1, bq = qq ? o1 : o0;
                     const u32 an = qq ? 0u : r1, bn = qq ? r1 : r0;
                     if (a | bq | an | bn) {
-                        const u64 a1 = (a >> 1) | ((u64)an << 63), b1 = (bq >> 1) | ((u64)bn << 63);
-                        const u64 x2 = (a ^ a1) ^ (bq ^ b1);
-                        const u64 pairs = (a & a1) | (a & bq) | (a & b1) | (a1 & bq) | (a1 & b1) | (bq & b1);
-                        const u64 qd = (a & b1 & ~a1 & ~bq) | (a1 & bq & ~a & ~b1);
-                        e4 += __popcll(x2 & ~pairs) - __popcll(x2 & pairs) - 2 * __popcll(qd);
+                        e4 += euler_quads(a, bq, an, bn);
                         if (j == 0) e4 += (int)((a ^ bq) & 1ull);           // window x = -1: only (0,y), (0,y+1)
                     }
                 }
@@ -671,23 +667,8 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                 else { p63 = NONE16; prs0 = NONE16; }    // (no pixel at a word edge in this row: nothing for the next row to meet)
                 // ---- contour vertices -------------------------------------------------------------------------------------
                 if (__any(B != 0ull)) {
-                    const u64 D0 = (B >> 1) | ((u64)r1 << 63), D4 = (B << 1) | (u64)l1;
-                    const u64 D2 = o2, D1 = (o2 >> 1) | ((u64)r2 << 63), D3 = (o2 << 1) | (u64)l2;
-                    const u64 D6 = o0, D7 = (o0 >> 1) | ((u64)r0 << 63), D5 = (o0 << 1) | (u64)l0;
-#define KEPT_EVEN(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ((Dp1) | (Dp2) | ~(Dp3)))
-#define KEPT_ODD(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ~(Dp1) & ((Dp2) | ~(Dp3)))
-                    const u64 k0 = KEPT_EVEN(D0, D7, D1, D2, D3), k1 = KEPT_ODD(D1, D0, D2, D3, D4);
-                    const u64 k2 = KEPT_EVEN(D2, D1, D3, D4, D5), k3 = KEPT_ODD(D3, D2, D4, D5, D6);
-                    const u64 k4 = KEPT_EVEN(D4, D3, D5, D6, D7), k5 = KEPT_ODD(D5, D4, D6, D7, D0);
-                    const u64 k6 = KEPT_EVEN(D6, D5, D7, D0, D1), k7 = KEPT_ODD(D7, D6, D0, D1, D2);
-#undef KEPT_EVEN
-#undef KEPT_ODD
-                    const u64 iso = ~(D0 | D1 | D2 | D3 | D4 | D5 | D6 | D7);    // an isolated pixel is written once
-                    u64 V1 = k0, V2 = 0, V3 = 0;
-#define ADDP(Kp) { V3 |= V2 & (Kp); V2 |= V1 & (Kp); V1 |= (Kp); }
-                    ADDP(k1) ADDP(k2) ADDP(k3) ADDP(k4) ADDP(k5) ADDP(k6) ADDP(k7) ADDP(iso)
-#undef ADDP
-                    V1 &= B; V2 &= B; V3 &= B;
+                    u64 V1, V2, V3;                        // at least one / two / three vertices at a pixel (stage_common.h)
+                    vertex_planes(B, o2, o0, l2, l1, l0, r2, r1, r0, V1, V2, V3);
                     if (V3) why = SLOW_VERTEX;            // multiplicity > 2: impossible after a 5x5 opening; general path
                     const int tc = c - tch, tc2 = __mul24(tc, tc), tc3 = __mul24(tc2, tc), tc4 = tc2 * tc2;
 #pragma unroll

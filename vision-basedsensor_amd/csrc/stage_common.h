@@ -23,6 +23,12 @@ __device__ __forceinline__ u64 brev64(u64 x) {
     return mk64(__builtin_bitreverse32((u32)(x >> 32)), __builtin_bitreverse32((u32)x));
 }
 
+// a & ~b & c and a | ~b on 32-bit halves (one v_bitop3_b32 per half: see vertex_planes32)
+__device__ __forceinline__ u64 and_not_and(u64 a, u64 b, u64 c) {
+    return mk64((u32)a & ~(u32)b & (u32)c, (u32)(a >> 32) & ~(u32)(b >> 32) & (u32)(c >> 32));
+}
+__device__ __forceinline__ u64 or_not(u64 a, u64 b) { return mk64((u32)a | ~(u32)b, (u32)(a >> 32) | ~(u32)(b >> 32)); }
+
 // bit p of the result = bit p + s of the row (this word, then the right neighbour's); `fill` = what lies past the row
 // end.  Every lane must execute it (DPP), s = 1 .. 31.
 __device__ __forceinline__ u64 shift_from_right(u64 x, int s, bool hasr, u32 fill) {
@@ -71,10 +77,72 @@ __device__ __forceinline__ u64 hwin(u64 v, bool hasl, bool hasr) {
 // the runs of B that hold a bit of S (S a subset of B); rB = brev64(B).  Adding S to B carries from the lowest seed of
 // every run to the run's top; the same on the reversed words fills from the highest seed down.
 __device__ __forceinline__ u64 fill_runs(u64 B, u64 rB, u64 S) {
-    const u64 up = ((S + B) ^ B) & B;
-    const u64 rS = brev64(S);
-    const u64 dn = brev64(((rS + rB) ^ rB) & rB);
-    return up | dn | S;
+    // (the boolean parts on 32-bit halves: one v_bitop3_b32 each, see vertex_planes32)
+    const u64 su = S + B;
+    const u32 upl = (u32)B & ~(u32)su, uph = (u32)(B >> 32) & ~(u32)(su >> 32);          // ((S + B) ^ B) & B
+    const u64 rS = brev64(S), sd = rS + rB;
+    const u32 dl = (u32)rB & ~(u32)sd, dh = (u32)(rB >> 32) & ~(u32)(sd >> 32);           // reversed: lo half = bits 63 .. 32 of dn
+    return mk64(upl | __builtin_bitreverse32(dh) | (u32)S, uph | __builtin_bitreverse32(dl) | (u32)(S >> 32));
+}
+
+// ---- the CHAIN_APPROX_SIMPLE vertex multiplicity of every pixel of a word, bit-parallel (see k_stage.hip) -------------------
+// On 32-BIT HALVES on purpose: gfx950 has v_bitop3_b32 (any boolean function of three inputs in one instruction) and the
+// compiler forms it from 32-bit expression trees only - 64-bit logic is split after instruction selection, when every
+// and / or / not is already its own instruction (135 -> 96 vector instructions for this function, tools' vtx prototype).
+// D0 .. D7: bit k = the neighbour of pixel k in chain direction d is foreground.  A vertex per maximal arc of background
+// neighbours that starts at direction a (a background, a - 1 foreground), holds a 4-neighbour and is not exactly
+// {a, a + 1, a + 2} (the border passes straight through); an isolated pixel is written once.  V1 / V2 / V3: at least one /
+// two / three of the nine planes.
+__device__ __forceinline__ void vertex_planes32(u32 B, u32 D0, u32 D1, u32 D2, u32 D3, u32 D4, u32 D5, u32 D6, u32 D7, u32& V1,
+                                                u32& V2, u32& V3) {
+#define KEPT_EVEN(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ((Dp1) | (Dp2) | ~(Dp3)))
+#define KEPT_ODD(Da, Dm1, Dp1, Dp2, Dp3) (~(Da) & (Dm1) & ~(Dp1) & ((Dp2) | ~(Dp3)))
+    const u32 k0 = KEPT_EVEN(D0, D7, D1, D2, D3), k1 = KEPT_ODD(D1, D0, D2, D3, D4);
+    const u32 k2 = KEPT_EVEN(D2, D1, D3, D4, D5), k3 = KEPT_ODD(D3, D2, D4, D5, D6);
+    const u32 k4 = KEPT_EVEN(D4, D3, D5, D6, D7), k5 = KEPT_ODD(D5, D4, D6, D7, D0);
+    const u32 k6 = KEPT_EVEN(D6, D5, D7, D0, D1), k7 = KEPT_ODD(D7, D6, D0, D1, D2);
+#undef KEPT_EVEN
+#undef KEPT_ODD
+    const u32 iso = ~(D0 | D1 | D2 | D3 | D4 | D5 | D6 | D7);
+    V1 = k0; V2 = 0; V3 = 0;
+#define ADDP(Kp) { V3 |= V2 & (Kp); V2 |= V1 & (Kp); V1 |= (Kp); }
+    ADDP(k1) ADDP(k2) ADDP(k3) ADDP(k4) ADDP(k5) ADDP(k6) ADDP(k7) ADDP(iso)
+#undef ADDP
+    V1 &= B; V2 &= B; V3 &= B;
+}
+// B = row c of the opened plane, o2 / o0 = the rows above / below it, l? / r? = bit 63 of the word to the left / bit 0 of the
+// word to the right in those rows (2: above, 1: this row, 0: below)
+__device__ __forceinline__ void vertex_planes(u64 B, u64 o2, u64 o0, u32 l2, u32 l1, u32 l0, u32 r2, u32 r1, u32 r0, u64& V1, u64& V2,
+                                              u64& V3) {
+    const u32 Bl = (u32)B, Bh = (u32)(B >> 32), al = (u32)o2, ah = (u32)(o2 >> 32), bl = (u32)o0, bh = (u32)(o0 >> 32);
+    // >> 1 with the right neighbour's bit 0 coming in at the top; << 1 with the left neighbour's bit 63 coming in at the bottom
+    auto shr_lo = [](u32 lo, u32 hi) { return __builtin_amdgcn_alignbit(hi, lo, 1u); };
+    auto shr_hi = [](u32 hi, u32 in) { return __builtin_amdgcn_alignbit(in, hi, 1u); };
+    auto shl_lo = [](u32 lo, u32 in) { return (lo << 1) | in; };
+    auto shl_hi = [](u32 lo, u32 hi) { return __builtin_amdgcn_alignbit(hi, lo, 31u); };
+    u32 v1l, v2l, v3l, v1h, v2h, v3h;
+    vertex_planes32(Bl, shr_lo(Bl, Bh), shr_lo(al, ah), al, shl_lo(al, l2), shl_lo(Bl, l1), shl_lo(bl, l0), bl, shr_lo(bl, bh), v1l, v2l,
+                    v3l);
+    vertex_planes32(Bh, shr_hi(Bh, r1), shr_hi(ah, r2), ah, shl_hi(al, ah), shl_hi(Bl, Bh), shl_hi(bl, bh), bh, shr_hi(bh, r0), v1h, v2h,
+                    v3h);
+    V1 = mk64(v1l, v1h); V2 = mk64(v2l, v2h); V3 = mk64(v3l, v3h);
+}
+
+// 4 x the Euler number's share of one word: the 2x2 windows whose top row is `a` and bottom row `bq` (an / bn: bit 0 of the
+// words to their right), by bit quads - Q1 - Q3 - 2 QD (8-connected foreground).  On 32-bit halves (v_bitop3_b32, above).
+__device__ __forceinline__ int euler_quads(u64 a, u64 bq, u32 an, u32 bn) {
+    int e = 0;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const u32 x = h ? (u32)(a >> 32) : (u32)a, y = h ? (u32)(bq >> 32) : (u32)bq;
+        const u32 x1 = h ? __builtin_amdgcn_alignbit(an, x, 1u) : __builtin_amdgcn_alignbit((u32)(a >> 32), x, 1u);
+        const u32 y1 = h ? __builtin_amdgcn_alignbit(bn, y, 1u) : __builtin_amdgcn_alignbit((u32)(bq >> 32), y, 1u);
+        const u32 x2 = (x ^ x1) ^ (y ^ y1);
+        const u32 pairs = (x & x1) | (x & y) | (x & y1) | (x1 & y) | (x1 & y1) | (y & y1);
+        const u32 qd = (x & y1 & ~x1 & ~y) | (x1 & y & ~x & ~y1);
+        e += __popc(x2 & ~pairs) - __popc(x2 & pairs) - 2 * __popc(qd);
+    }
+    return e;
 }
 
 // sum of the positions of the set bits
@@ -108,7 +176,10 @@ __device__ __forceinline__ u64 seg_update(u64 B, u64 rB, const u64 (&pm)[K], con
         Rn[k] = 0;
         if (k >= 2 && !__any(pm[k] != 0ull)) continue;   // (wave-uniform; slots 0 and 1 always run: their chains interleave)
         u64 adj = pm[k];
-        if (C8) adj |= (adj << 1) | (adj >> 1);
+        if (C8) {                                        // (halves: v_or3 / v_bitop3 per 32 bits)
+            const u32 al = (u32)adj, ah = (u32)(adj >> 32);
+            adj = mk64(al | (al << 1) | __builtin_amdgcn_alignbit(ah, al, 1u), ah | __builtin_amdgcn_alignbit(ah, al, 31u) | (ah >> 1));
+        }
         u64 Rk = fill_runs(B, rB, B & adj);
         const u64 ov = Rk & claimed;
         if (ov) {
