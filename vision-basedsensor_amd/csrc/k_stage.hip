@@ -205,8 +205,10 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                 rec_sx[r] = 64u * (u32)j * cnt_ + sk_; rec_sy[r] = sy_;
             } else fail = true;
         };
-#pragma unroll 1
-        for (int q = 0; q < R + NS - 1; ++q) {
+        // Two steps per trip: what the delay lines shift between two steps is register renaming then, not moves (0.755 ->
+        // 0.74 us per frame).  As a lambda called twice: the same body as an unrolled inner loop keeps the moves, four
+        // steps per trip need the 168th register and 100 KB of code for nothing more.
+        auto band_step = [&](const int q) __attribute__((always_inline)) {
             const int r = q - NA;                        // source row of this step
             const u64 v = rowval(pf[0], r);
             pf[0] = pf[1]; pf[1] = pf[2]; pf[2] = pf[3]; pf[3] = ldraw(r + 4);
@@ -226,14 +228,14 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
             a2[1] = a2[0]; a2[0] = n2;
             h1 = v;
             const int t = r - NBL;                       // the row whose window ends at r
-            if (t < 0) continue;                         // (uniform)
+            if (t < 0) return;                         // (uniform)
             const u64 eh = hwin<NS, true>(e, hasl, hasr);
             const u64 B = (act && y0 + t < H) ? and_not_and(cr[NBL], eh, vm) : 0ull;      // :171-174  maxima = mask & (window holds a 0)
             if (t == 0) firstB = B;
             bool live = false;
 #pragma unroll
             for (int k = 0; k < SG_KB; ++k) live |= pm[k] != 0ull;
-            if (!__any(B != 0ull || live)) continue;     // (wave-uniform)
+            if (!__any(B != 0ull || live)) return;     // (wave-uniform)
             const u32 y = (u32)(y0 + t);
             const u64 rB = brev64(B);
             u64 Rn[SG_KB];
@@ -268,6 +270,11 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                 if (!done) fail = true;
             }
             if (__any(((B >> 63) | B) & 1ull)) seg_hlinks<SG_KB, false>(pm, sid, hasr, p63, prs0, la, lb, Q);    // (wave-uniform)
+                };
+#pragma unroll 1
+        for (int q = 0; q < R + NS - 1; q += 2) {
+            band_step(q);
+            if (q + 1 < R + NS - 1) band_step(q + 1);
         }
 #pragma unroll
         for (int k = 0; k < SG_KB; ++k) {
@@ -397,8 +404,8 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
 #pragma unroll
             for (int q = 0; q < NMOM; ++q) m[q] = 0;
         };
-#pragma unroll 1
-        for (int q = 0; q < R + 10; ++q) {
+        // (two steps per trip, as in the band loop)
+        auto open_step = [&](const int q) __attribute__((always_inline)) {
             const int r = q - 5;                         // source row of this step
             const u64 v = rowval(pf[0], r);
             pf[0] = pf[1]; pf[1] = pf[2]; pf[2] = pf[3]; pf[3] = ldraw(r + 4);
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
             const u64 vd = er | d5[0] | d5[1] | d5[2] | d5[3];
             d5[3] = d5[2]; d5[2] = d5[1]; d5[1] = d5[0]; d5[0] = er;
             const int rho = r - 4;                       // the opened row this step completes (relative to y0)
-            if (rho < -1) continue;                      // (uniform)
+            if (rho < -1) return;                      // (uniform)
             u64 o0 = hwin<5, false>(vd, hasl, hasr);
             {
                 const int y = y0 + rho;
@@ -530,6 +537,11 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                 p63 = NONE16; prs0 = NONE16;             // an empty row: nothing to link the next one with
             }
             o2 = o1; o1 = o0; l2 = l1; l1 = l0; r2 = r1; r1 = r0;
+                };
+#pragma unroll 1
+        for (int q = 0; q < R + 10; q += 2) {
+            open_step(q);
+            if (q + 1 < R + 10) open_step(q + 1);
         }
 #pragma unroll
         for (int k = 0; k < SG_KO; ++k) {
