@@ -22,14 +22,14 @@ for name, src in (("pageable", fr), ("pinned", pin)):
 import tempfile
 with tempfile.TemporaryDirectory() as td, contextlib.redirect_stdout(sys.stderr):
     clip = os.path.join(td, "c.npy"); open(clip, "wb").close()
-    for batch in (64, 128, 256, 512):
+    for batch, div in ((64, 4), (128, 1), (128, 2), (128, 4), (128, 8), (256, 4), (512, 4)):
         for name, src in (("pinned", pin), ("pageable", fr)):
             best = 0
-            for rep in range(3):
-                trk = MarkerTracker({"video_path": clip, "output_dir": os.path.join(td, f"o{batch}{name}{rep}"), "crop_ratios": (0, 0, 0, 0),
-                                     "id_mode": "full", "batch": batch})
+            for rep in range(5):
+                trk = MarkerTracker({"video_path": clip, "output_dir": os.path.join(td, f"o{batch}{div}{name}{rep}"), "crop_ratios": (0, 0, 0, 0),
+                                     "id_mode": "full", "batch": batch, "first_batch_div": div})
                 t0 = time.perf_counter(); rows = trk.process_frames(src); t1 = time.perf_counter()
                 trk._save_results(rows); t2 = time.perf_counter()
                 best = max(best, n / (t2 - t0))
                 last = (n / (t1 - t0), n / (t2 - t0))
-            print(f"batch {batch} {name}: {last[0]:.0f} frames/s to rows, {last[1]:.0f} to CSV (best {best:.0f})", file=sys.__stdout__, flush=True)
+            print(f"batch {batch} (first batch 1/{div}) {name}: {last[0]:.0f} frames/s to rows, {last[1]:.0f} to CSV (best of 5: {best:.0f})", file=sys.__stdout__, flush=True)
