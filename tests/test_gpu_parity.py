@@ -523,6 +523,14 @@ def test_marker_tracker_process_frames(tmp_path, tag, id_mode):
     trk.process()
     df = pd.read_csv(trk.output_csv, float_precision="round_trip")     # the default parser is 1 ulp lossy
     assert list(df.columns) == CSV_COLUMNS
+    # the upload pipeline's batch schedule (a short first batch, then full ones: here 1 + 2 + 2 frames from page-locked
+    # memory) does not show in the CSV
+    from vbs_amd.marker_detection import pinned_frames
+    pin = pinned_frames(frames.shape)
+    pin[:] = frames
+    t2 = MarkerTracker(dict(cfg, batch=2, output_dir=str(tmp_path / "out2")))
+    t2._save_results(t2.process_frames(pin))
+    assert open(t2.output_csv, "rb").read() == open(trk.output_csv, "rb").read()
     rows, ref = O.process_frames(list(frames), crop_ratios=crop, id_mode=id_mode)
     assert list(trk.first_frame_markers.keys()) == list(ref.keys())
     assert len(df) == len(rows)
