@@ -351,7 +351,7 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
-    ap.add_argument("--batch", type=int, default=512, help="frames per internal pass (workspace size)")
+    ap.add_argument("--batch", type=int, default=512, help="frames per internal pass (workspace size): 256 / 512 / 1024 / 2048 ran at 270.5 / 274.1 / 277.9 / 278.8 k frames/s in one sweep (tools/batch_sweep.sh) - within the run-to-run noise of the 512 line, which all profiles are taken at")
     ap.add_argument("--roofline-frames", type=int, default=1024)
     ap.add_argument("--pass-streams", type=int, default=2, choices=[1, 2],
                     help="VBS_OPT_PASS_STREAMS: 2 = odd internal passes on a second workspace and stream (the library's default)")
