@@ -1293,6 +1293,43 @@ def test_blur16_hand_shake_that_expires_is_reported_in_counts():
     assert out["4"] == {"counts": [L.VBS_EINTERNAL] * 3, "status": [L.VBS_EINTERNAL] * 3}
 
 
+def test_latency_stage_on_the_widest_geometry():
+    """4096 x 2048: 64 word columns (one row block per wave), 16 workgroups per plane - the cap, 32 rows per tile - and 4 MB of
+    per-row slot table per frame (the scratch holds fewer frames than VBS_LAT_MAXN there): the few-frames kernel against the
+    batch kernel on ragged blobs."""
+    from vbs_amd.engine import Engine
+    h, w, n = 2048, 4096, 2
+    rng = np.random.default_rng(5)
+    mask = np.zeros((n, h, w), np.uint8); area = np.zeros((n, h, w), np.uint8)
+    for f in range(n):
+        for _ in range(60):
+            cx, cy = int(rng.integers(40, w - 40)), int(rng.integers(40, h - 40))
+            a, b = int(rng.integers(6, 36)), int(rng.integers(6, 36))
+            yy, xx = np.mgrid[-b:b + 1, -a:a + 1]
+            e = (xx / a) ** 2 + (yy / b) ** 2
+            area[f, cy - b:cy + b + 1, cx - a:cx + a + 1][e <= 1] = 255
+            mask[f, cy - b:cy + b + 1, cx - a:cx + a + 1][e <= 0.5] = 1
+    eng = Engine(h, w, max_markers=512, max_batch=n)
+    mt, at = torch.from_numpy(mask).cuda(), torch.from_numpy(area).cuda()
+    out = []
+    for lat in (32, 0):
+        eng.set_option(L.OPT_LATENCY_FRAMES, lat)
+        det, counts = eng.marker_center(mt, at)
+        torch.cuda.synchronize()
+        out.append((det.clone(), counts.clone(), eng.stage_tables(n)))
+    (d0, c0, t0), (d1, c1, t1) = out
+    assert torch.equal(c0, c1) and torch.equal(d0, d1) and int(c0.min()) > 20
+    keep = (t0["slow"] == 0) & (t1["slow"] == 0)
+    assert int(keep.sum()) > 0
+    for i in np.nonzero(keep)[0]:
+        nb, na = (int(v) for v in t0["ncomp"][i])
+        assert (nb, na) == tuple(int(v) for v in t1["ncomp"][i])
+        assert np.array_equal(t0["band_sums"][i][:nb, :3], t1["band_sums"][i][:nb, :3])
+        assert np.array_equal(t0["area_sums"][i][:na, :15], t1["area_sums"][i][:na, :15])
+        assert np.array_equal(t0["probe"][i][:nb], t1["probe"][i][:nb])
+    eng.close()
+
+
 def test_stage_lat_under_repetition():
     """k_stage_lat's workgroups talk through global memory (arrival counters, lists written on one XCD and read on another): a
     missing fence shows as a RARE wrong table.  tools/gpu_lat_stress.py: 64 frames of each size, their tables by the batch

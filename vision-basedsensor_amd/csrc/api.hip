@@ -174,7 +174,13 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     h->slow_total = h->lat_hdr + (size_t)VBS_LAT_MAXN * VBS_LAT_HDR;
     h->slow_flag = h->slow_total + 4;
     h->fstat = h->slow_flag + B;
-    if (const size_t per = stage_lat_scratch(h)) ALLOC(lat_scratch, per * (size_t)std::min<size_t>(B, VBS_LAT_MAXN));
+    // the few-frames labelling kernel's scratch: optional (without it such passes take the batch kernel), at most 256 MB
+    h->lat_slots = 0;
+    if (const size_t per = stage_lat_scratch(h)) {
+        const size_t slots = std::min<size_t>(std::min<size_t>(B, VBS_LAT_MAXN), ((size_t)256 << 20) / per);
+        if (slots >= 1 && dev_alloc(h, &h->lat_scratch, per * slots) == VBS_OK) h->lat_slots = (int)slots;
+        else { h->lat_scratch = nullptr; h->err.clear(); (void)hipGetLastError(); }
+    }
     ALLOC(lut, 256);
     ALLOC(blur_frags, frags.size() / 4);
     if (!frags16h.empty()) { ALLOC(blur16_h, frags16h.size() / 4); ALLOC(blur16_v, frags16v.size() / 4); }
@@ -264,7 +270,7 @@ static int need_gray(vbs_handle* h, int planes, hipStream_t s) {
 // The per-frame statistics of a pass <- 0; for a pass of a few frames also what launch_labelling would clear (k_stage_lat's
 // headers, the slow counter and flags lie in front of fstat in one allocation): one launch instead of two
 static void clear_pass(vbs_handle* h, int nb, hipStream_t s) {
-    if (nb <= h->lat_frames && h->stage_impl == 0 && h->lat_scratch) {
+    if (nb <= h->lat_frames && h->stage_impl == 0 && nb <= h->lat_slots) {
         launch_fill(h->lat_hdr, 0u, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + 4 + (size_t)h->maxb + (size_t)nb * 8, s);
         h->pass_cleared = true;
     } else {

@@ -99,6 +99,7 @@ struct vbs_handle {
     u64* ncc_tot;      // [4]  running NCC decision counters (vbs_ncc_counters)
     u32* lat_hdr;      // [VBS_LAT_MAXN][VBS_LAT_HDR] k_stage_lat's per-frame counters; slow_total / slow_flag follow (one fill clears all)
     unsigned char* lat_scratch = nullptr;   // [VBS_LAT_MAXN][stage_lat_scratch()] what the workgroups of a frame share; null = path not available
+    int lat_slots = 0;              // frames lat_scratch holds (min(max_batch, VBS_LAT_MAXN), fewer for very large frames)
     int lat_frames = 24;            // vbs_set_option(VBS_OPT_LATENCY_FRAMES): passes of <= this many frames take k_stage_lat (0: never)
     size_t lat_lds_set = 0;
     bool pass_cleared = false;      // detect_pass cleared the labelling headers / flags of this pass together with fstat

@@ -996,6 +996,6 @@ static bool stage_lat_launch_t(vbs_handle* h, int nb, const LatGeom& g, size_t l
 bool launch_stage_lat(vbs_handle* h, int nb, hipStream_t s) {
     LatGeom g;
     size_t lds = 0;
-    if (nb > VBS_LAT_MAXN || !h->lat_scratch || !lat_geom(h, &g, &lds)) return false;
+    if (nb > h->lat_slots || !h->lat_scratch || !lat_geom(h, &g, &lds)) return false;
     return h->bp.ns == 14 ? stage_lat_launch_t<14>(h, nb, g, lds, s) : stage_lat_launch_t<8>(h, nb, g, lds, s);
 }
