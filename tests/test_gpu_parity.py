@@ -1028,6 +1028,18 @@ def test_latency_stage_equals_the_batch_stage():
         same_tables({k: v[keep] for k, v in t0.items()}, {k: v[keep] for k, v in t1.items()})
         assert torch.equal(c0, c1) and torch.equal(d0, d1) and int(c0.min()) > 0
         eng.close()
+    # with reference positions (the tracking rows come out of the same launch as the fits), on frames the labelling kernel hands
+    # on to k_label (the 450x480 corner of large-marker frames: holes)
+    spec = S.config2()
+    ft = S.make_frames_torch(spec, range(5), seed=5, device="cuda")[:, 0:450, 0:480]
+    eng = Engine(450, 480, max_markers=512, max_batch=5)
+    _, d_ref, c_ref = eng.track_to_3d(ft[:1], None, want_det=True)
+    xy = d_ref[0, :int(c_ref[0]), :2].cpu().numpy()
+    cam = L.make_camera(*S.default_camera(spec), 2.0)
+    ((ta, da, ca), t0), ((tb, db, cb), t1) = both(eng, lambda: eng.track_to_3d(ft, xy, 20.0, cam, 5.0, want_det=True), 5)
+    assert int((t0["slow"] != 0).sum()) > 0 and np.array_equal(t0["slow"], t1["slow"])
+    assert torch.equal(ta, tb) and torch.equal(da, db) and torch.equal(ca, cb) and int(ca.min()) > 0
+    eng.close()
     rng = np.random.default_rng(11)
     for (h, w) in ((450, 480), (700, 900), (1000, 1200)):
         n = 6
