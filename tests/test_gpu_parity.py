@@ -1475,6 +1475,23 @@ def test_real_sensor_frame(golden_dir, tmp_path):
         from vbs_amd.marker_detection import _det_to_markers
         compare_markers(_det_to_markers(det[0].cpu().numpy(), 65), want)
         assert eng.frame_stats(1)[0, 5] == 65 and eng.frame_stats(1)[0, 6] == 65
+        # the real layout stays on the fast labelling path under BOTH labelling kernels (few-frames and batch): no frame is
+        # handed on to the general kernel (65 dots of ~27 px at a pitch of 35-42 px)
+        assert int(eng.stage_tables(1)["slow"][0]) == 0
+        eng8 = engine(h, w, max_markers=1024, max_batch=8)
+        eng8.set_option(L.OPT_LATENCY_FRAMES, 0)
+        _, det8, counts8 = eng8.track_to_3d(ft.expand(8, -1, -1, -1).contiguous(), None, want_det=True)
+        assert (counts8 == 65).all() and torch.equal(det8[7, :65], det[0, :65])
+        assert not eng8.stage_tables(8)["slow"].any()
+        eng8.close()
+        if bits == 15:
+            # ... and against the reference's own published result for this scene (tests/figure_check.py): centres, the
+            # 65 `full` IDs as printed in img/2d_visualization.png, axes as a bounded offset - from the HIP path's rows
+            from figure_check import check_against_figure
+            hip = _det_to_markers(det[0].cpu().numpy(), 65)
+            table = I.assign_ids(hip, 5, "full", "optimal")
+            rep = check_against_figure(golden_dir, hip, table)
+            assert rep["ids_equal"] == 65 and rep["centre_max_px"] <= 0.75
         eng.close()
     clip = np.stack([bgr, bgr])
     np.save(tmp_path / "real.npy", clip)
