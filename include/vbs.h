@@ -81,7 +81,8 @@ int vbs_version(void);
  * (never below the 20 the error bound needs); a wide margin sends thousands of pixels per frame through the queued
  * float64 re-evaluation.  VBS_OPT_STAGE_IMPL (test hook / fallback, results identical): 0 (default) runs band / open /
  * labelling / sums of `_marker_center` (:170-196) in the fused kernel (k_stage.hip) where the frame geometry allows it,
- * 1 always runs the separate kernels (k_morph + k_ccl) that other geometries take.  VBS_OPT_BLUR_IMPL (test hook /
+ * 1 always runs the separate kernels (k_morph + k_ccl) that other geometries take, 2 labels EVERY frame with the general
+ * kernel (k_morph + k_label: what a frame with holes / beyond the fast path's tables takes).  VBS_OPT_BLUR_IMPL (test hook /
  * fallback, results identical): 0 (default) runs the two GaussianBlurs (:118-129) on 16-column strips (k_blur16) where the
  * frame allows it (large branch, width >= 240 and a multiple of 8, rows that load as aligned dwords), 1 always runs the 32-column
  * kernel (k_blur_mfma) that every other frame takes.  VBS_OPT_PASS_STREAMS (tuning, results identical): 2 (default) lets
@@ -178,7 +179,7 @@ int vbs_frame_stats(vbs_handle* h, uint32_t* out, int n);
  * the LAST internal pass (synchronises; any pointer may be NULL): ncomp [n][2] components of the band / opened mask,
  * band_sums [n][max_markers][4] (count, sum x, sum y, spare), area_first [n][max_markers] first pixel (y * w + x) of every
  * opened component, area_sums [n][max_markers][16] contour-vertex moments about it, probe [n][max_markers][4] component ids
- * of the 2x2 pixel cell around every band centroid (0xFFFF = background), slow [n] 1 = the general kernel redid the frame.
+ * of the 2x2 pixel cell around every band centroid (0xFFFF = background), slow [n] non-zero = the general kernel redid the frame (the value says why: +16 = in the opened-mask half; 1 slots, 2 components, 3 mailbox, 4 holes, 5 vertex multiplicity, 6 segments per tile, 7 records, 8 queued unions).
  * Entries past a frame's component counts are unspecified. */
 int vbs_stage_tables(vbs_handle* h, int n, uint32_t* ncomp, uint64_t* band_sums, uint32_t* area_first, int64_t* area_sums,
                      uint16_t* probe, uint32_t* slow);

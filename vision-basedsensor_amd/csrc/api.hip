@@ -162,6 +162,7 @@ extern "C" int vbs_create(int device, int height, int width, int max_markers, in
     ALLOC(open_bits, B * HW);
     ALLOC(ncc_rx, (size_t)width); ALLOC(ncc_ry, (size_t)height);
     ALLOC(wbase, B * 2 * HW);
+    if (2 * HW < (size_t)16 * SG_REC) ALLOC(stage_mrec, B * 16 * SG_REC);   // (k_stage.hip: stage_geom)
     ALLOC(node_pos, B * 2 * VBS_RUN_CAP); ALLOC(node_comp, B * 2 * VBS_RUN_CAP);
     ALLOC(ncomp, B * 2);
     ALLOC(band_first, B * max_markers); ALLOC(band_sums, B * max_markers * 4);
@@ -457,7 +458,7 @@ extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
             h->ncc_margin_ppm = value;
             return VBS_OK;
         case VBS_OPT_STAGE_IMPL:
-            if (value != 0 && value != 1) break;
+            if (value < 0 || value > 2) break;
             h->stage_impl = value;
             return VBS_OK;
         case VBS_OPT_LATENCY_FRAMES:

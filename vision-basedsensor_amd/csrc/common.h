@@ -49,6 +49,7 @@ static inline GrayCoef gray_coef(int bits) {
 
 struct ProfRec { const char* name; hipEvent_t a, b; };
 
+#define SG_REC 2048                // k_stage / k_stage_lat: segment records per frame, at most (StageGeom::rec_cap)
 struct vbs_handle {
     bool prof = false;                     // record a HIP event pair around every kernel launch
     std::vector<ProfRec> recs;
@@ -85,6 +86,8 @@ struct vbs_handle {
     double* ncc_tab;   // [VBS_NCC_MAXL] g, then [VBS_NCC_MAXL + 1] cg: the exact path of k_ncc_mfma reads them from memory
     u32* fstat;        // [maxb][8]  0: area popcount, 1: ambiguous ncc pixels, 2: status
     u32* wbase;        // [maxb][2][H*WW]   first node index of each word
+    u32* stage_mrec = nullptr;   // k_stage's moment records when a frame's slice of wbase would hold fewer than SG_REC of them
+                                 // (small frames with many blobs: the reference's real 65-dot layout); null = they live in wbase
     u32* node_pos;     // [maxb][2][RUN_CAP]  y*W + x0 of each run
     u32* node_comp;    // [maxb][2][RUN_CAP]  component id (0-based, raster order) of each run
     u32* ncomp;        // [maxb][2]

@@ -912,7 +912,7 @@ void launch_labelling(vbs_handle* h, int nb, hipStream_t s) {
         nslow = h->slow_total;
     } else {
         launch_morph(h, nb, nullptr, s);
-        all = launch_ccl(h, nb, s) ? 0 : 1;
+        all = (h->stage_impl != 2 && launch_ccl(h, nb, s)) ? 0 : 1;       // (2: the general kernel labels EVERY frame - its rate, tests)
     }
     VBS_LAUNCH(h, s, "k_label", k_label<0>, dim3(nb < 64 ? nb : 64), dim3(1024), 0, s, h->band_bits, h->open_bits, h->wbase,
                h->node_pos, h->node_comp, h->ncomp, h->band_first, h->band_sums, h->area_first, h->area_sums, h->fstat,

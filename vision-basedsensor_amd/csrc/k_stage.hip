@@ -303,7 +303,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         const u32 nrec = (u32)misc[4];
         const u32 ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, nullptr, comp_pos, cidmap, tmp,
                                       min((u32)maxm, 1024u), Q);
-        if (misc[5] > Q.cap) { hand_on(SLOW_SLOTS); return; }
+        if (misc[5] > Q.cap) { hand_on(SLOW_PAIRS); return; }
         if (ncomp == NONE32) { hand_on(SLOW_NCOMP); return; }
         if (geo.stop == 4) return;
         // ---- component sums (center_of_mass :181) ----------------------------------------------------------------------
@@ -400,7 +400,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                 dst[1] = make_uint4((u32)m[3], (u32)m[4], (u32)m[5], (u32)m[6]);
                 dst[2] = make_uint4((u32)m[7], (u32)m[8], (u32)m[9], (u32)m[10]);
                 dst[3] = make_uint4((u32)m[11], (u32)m[12], (u32)m[13], (u32)m[14]);
-            } else why = SLOW_SLOTS;
+            } else why = SLOW_RECS;
 #pragma unroll
             for (int q = 0; q < NMOM; ++q) m[q] = 0;
         };
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                             if (nseg < SG_SEGMAX) {
                                 sid[k] = sbase + nseg; P[sbase + nseg] = (unsigned short)(sbase + nseg);
                                 seg_pos[sbase + nseg] = (u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
-                            } else why = SLOW_SLOTS;
+                            } else why = SLOW_SEGS;
                             ++nseg;
                             pm[k] = gg;
                             done = true;
@@ -576,7 +576,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         if (geo.stop == 13) return;
         ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), nullptr, nullptr, 0, seg_pos, comp_pos, cidmap, tmp,
                             min((u32)maxm, (u32)CCL_OPEN_COMPS), Q);
-        if (misc[5] > Q.cap) { hand_on(16u + SLOW_SLOTS); return; }
+        if (misc[5] > Q.cap) { hand_on(16u + SLOW_PAIRS); return; }
         if (ncomp == NONE32) { hand_on(16u + SLOW_NCOMP); return; }
         if ((int)ncomp - misc[0] / 4 != 0) {             // holes: RETR_EXTERNAL needs the fill passes of the general path
             hand_on(16u + SLOW_HOLES);
@@ -661,8 +661,10 @@ static bool stage_geom(const vbs_handle* h, StageGeom* g, size_t* lds_bytes) {
     g->off_mb = (u32)(g->off_pq + pq);
     g->off_tmp = (u32)(g->off_mb + mb);
     *lds_bytes = g->off_tmp + misc;
-    // moment records live in the frame's slice of the general path's word table (idle on the fast path)
-    g->mrec_stride = 2u * (u32)h->H * (u32)h->WW;
+    // moment records live in the frame's slice of the general path's word table (idle on the fast path) - unless that
+    // slice holds fewer than SG_REC of them: small frames with many blobs (the reference's real layout: 65 dots in 467x437,
+    // tiles of 5 rows, ~650 records against the 437 its slice holds) have their own buffer (vbs_create: stage_mrec)
+    g->mrec_stride = h->stage_mrec ? 16u * (u32)SG_REC : 2u * (u32)h->H * (u32)h->WW;
     g->mrec_cap = g->mrec_stride / 16u < (u32)SG_REC ? g->mrec_stride / 16u : (u32)SG_REC;
     return *lds_bytes <= 160 * 1024;
 }
@@ -685,7 +687,8 @@ static bool stage_launch_t(vbs_handle* h, int nb, const StageGeom& g, size_t lds
         h->stage_lds_set = lds;
     }
     VBS_LAUNCH(h, s, "k_stage", (k_stage<NS>), dim3(nb), dim3(ST_NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
-               h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, h->slow_total, h->wbase, g);
+               h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, h->slow_total,
+               h->stage_mrec ? h->stage_mrec : h->wbase, g);
     return true;
 }
 

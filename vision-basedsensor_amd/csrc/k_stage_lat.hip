@@ -585,7 +585,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                 dst[1] = make_uint4((u32)m[3], (u32)m[4], (u32)m[5], (u32)m[6]);
                 dst[2] = make_uint4((u32)m[7], (u32)m[8], (u32)m[9], (u32)m[10]);
                 dst[3] = make_uint4((u32)m[11], (u32)m[12], (u32)m[13], (u32)m[14]);
-            } else why = SLOW_SLOTS;
+            } else why = SLOW_RECS;
 #pragma unroll
             for (int q = 0; q < NMOM; ++q) m[q] = 0;
         };
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                             if (nseg < SG_SEGMAX) {
                                 sid[k] = sbase + nseg;
                                 w_spos[sbase + nseg - base] = (u32)(y0 + c) * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
-                            } else why = SLOW_SLOTS;
+                            } else why = SLOW_SEGS;
                             ++nseg;
                             pm[k] = gg;
                             done = true;

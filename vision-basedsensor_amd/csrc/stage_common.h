@@ -7,7 +7,7 @@
 #define SG_KB 4                    // slots of the band walk (a ring crosses a tile as two arcs)
 #define SG_KO 3                    // slots of the opened-mask walk
 #define SG_SEGMAX 8                // segments a thread can start; segment id = 8 tid + i
-#define SG_REC 2048                // segment records per frame, at most (StageGeom::rec_cap)
+// (SG_REC, the segment records per frame: common.h - vbs_create sizes a buffer by it)
 #define SG_PQ 4096                 // segment pairs waiting to be united, at most (StageGeom::pq_cap)
 #define NONE32 0xFFFFFFFFu
 // why a frame was handed on (slow_flag value)
@@ -16,6 +16,9 @@
 #define SLOW_MAILBOX 3
 #define SLOW_HOLES 4
 #define SLOW_VERTEX 5              // a contour vertex of multiplicity > 2
+#define SLOW_SEGS 6                // a tile started more than SG_SEGMAX segments
+#define SLOW_RECS 7                // more segment / moment records than the frame's tables hold
+#define SLOW_PAIRS 8               // more queued unions than the queue holds
 
 
 __device__ __forceinline__ u64 mk64(u32 lo, u32 hi) { return ((u64)hi << 32) | lo; }
