@@ -558,10 +558,21 @@ def test_assign_ids_on_device(tag, id_mode):
     _, det, counts = eng.track_to_3d(frame, None, want_det=True)
     n0 = int(counts[0].item())
     assert n0 == spec.n_markers
-    table = I.assign_ids(_det_to_markers(det[0].cpu().numpy(), n0), 5, id_mode, "optimal")
-    want_ids, want_xy = I.reference_arrays(table)
+    markers = _det_to_markers(det[0].cpu().numpy(), n0)
     ids, xy = eng.assign_ids(det, counts, 5, id_mode)
     ids, xy = ids.cpu().numpy().astype(np.int64), xy.cpu().numpy()
+    # (1) against the ORACLE (`oracle.process_first_frame`, pinned to the reference body's golden for `as_written` and to the
+    #     reference's published figure for `full`): same keys in the same dict order, and every slot holds the coordinates
+    #     the oracle gives that key (up to the order among markers at mathematically equal angles, checked below)
+    oref = O.process_first_frame(markers, 5, id_mode, "optimal")
+    assert [tuple(int(v) for v in k) for k in ids.tolist()] == list(oref.keys())
+    okeys = list(oref.keys())
+    oxy = np.array([[oref[k]["Ox"], oref[k]["Oy"]] for k in okeys])
+    assert sorted(map(tuple, xy.tolist())) == sorted(map(tuple, oxy.tolist()))
+    assert int((xy != oxy).any(axis=1).sum()) <= 4
+    # (2) against the product's host restatement (the checker of pipeline.reference_from_frame0)
+    table = I.assign_ids(markers, 5, id_mode, "optimal")
+    want_ids, want_xy = I.reference_arrays(table)
     assert np.array_equal(ids, want_ids)
     # bit-exact float64 coordinates in the same order - except among markers whose angles are mathematically equal
     # (collinear with the centre: np.arctan2's last bit orders them on the host, the device's atan2 here)
@@ -576,6 +587,26 @@ def test_assign_ids_on_device(tag, id_mode):
     empty = torch.zeros_like(counts)
     with pytest.raises(ValueError, match="No markers detected"):
         eng.assign_ids(det, empty, 5, id_mode)
+    eng.close()
+
+
+@pytest.mark.parametrize("name", ["ring65", "grid7"])
+def test_assign_ids_on_device_against_the_reference_golden(golden_dir, name):
+    """f4 against the reference itself: `tests/golden/ids_as_written.json` holds marker lists and the table that the
+    reference's own `_process_first_frame` body (marker_detection.py:275-347, executed by make_golden.py) made of them -
+    `vbs_assign_ids` on the same markers gives the same keys in the same order with the same (Ox, Oy), bit for bit."""
+    g = json.load(open(os.path.join(golden_dir, "ids_as_written.json")))[name]
+    markers = g["frames"][0]
+    m = len(markers)
+    eng = engine(480, 640, max_markers=256, max_batch=1)
+    det = torch.zeros((1, 256, 6), dtype=torch.float64, device="cuda")
+    det[0, :m] = torch.tensor([[mk["center"][0], mk["center"][1], mk["major_axis"], mk["minor_axis"], mk["angle"], i]
+                               for i, mk in enumerate(markers)], dtype=torch.float64)
+    counts = torch.tensor([m], dtype=torch.int32, device="cuda")
+    ids, xy = eng.assign_ids(det, counts, int(g["num_layers"]), "as_written")
+    ids, xy = ids.cpu().numpy().astype(np.int64), xy.cpu().numpy()
+    ref = np.array(g["ref"], dtype=np.float64)
+    assert np.array_equal(ids, ref[:, :2].astype(np.int64)) and np.array_equal(xy, ref[:, 2:4])
     eng.close()
 
 
@@ -1246,6 +1277,43 @@ def test_frame_stats_follow_the_last_pass_onto_the_second_workspace():
         assert (views[1][0][:, 5] == spec.n_markers).all() and (views[1][0][:, 0] > 0).all(), n
 
 
+def test_frame_stats_after_normxcorr2_describe_that_pass():
+    """every pass entry point records itself as the last pass.  A multi-pass vbs_track_to_3d whose last pass
+    ran on the second workspace, then vbs_normxcorr2 on the same handle: vbs_frame_stats must show the NCC pass's
+    counters (area popcount of ITS masks), not the second workspace's."""
+    from vbs_amd.engine import Engine
+    spec = S.config1()
+    ft = S.make_frames_torch(spec, range(28), seed=9, device="cuda")
+    eng = Engine(spec.height, spec.width, max_markers=256, max_batch=8)
+    eng.set_option(L.OPT_PASS_STREAMS, 2)
+    eng.track_to_3d(ft)                                    # passes of 4, 8, 8, 8: the last one on the second workspace
+    before = eng.frame_stats(8).copy()
+    area = torch.zeros((2, spec.height, spec.width), dtype=torch.uint8, device="cuda")
+    area[0, 100:140, 200:260] = 255                        # 2 400 foreground pixels
+    area[1, 50:60, 50:70] = 255                            # 200
+    eng.normxcorr2(area)
+    st = eng.frame_stats(2)
+    assert st[:, 0].tolist() == [2400, 200], (st[:, 0], before[:2, 0])
+    eng.close()
+
+
+def test_num_layers_beyond_the_device_kernel_runs_on_the_host(tmp_path):
+    """k_assign_ids covers num_layers <= 16; a configuration beyond that must run as it always did (host
+    assignment) instead of failing the device check."""
+    from vbs_amd.marker_detection import MarkerTracker
+    spec = S.config1()
+    frames = S.make_frames(spec, range(2), seed=3)
+    np.save(tmp_path / "clip.npy", frames)
+    trk = MarkerTracker({"video_path": str(tmp_path / "clip.npy"), "output_dir": str(tmp_path / "o"), "crop_ratios": (0, 0, 0, 0),
+                         "num_layers": 20, "id_mode": "full"})
+    trk.process()
+    assert trk.ids_device_check == {"on_device": False, "used": "host"} and len(trk.first_frame_markers) == spec.n_markers
+    trk5 = MarkerTracker({"video_path": str(tmp_path / "clip.npy"), "output_dir": str(tmp_path / "o5"), "crop_ratios": (0, 0, 0, 0),
+                          "num_layers": 5, "id_mode": "full"})
+    trk5.process()
+    assert trk5.ids_device_check["used"] in ("device", "host") and trk5.ids_device_check["equal_to_host"] == (trk5.ids_device_check["used"] == "device")
+
+
 def test_gray_plane_is_allocated_at_first_bgr_use_and_not_under_capture():
     """The gray plane of 3-channel input no longer exists on a handle that only sees gray frames; the first BGR call
     allocates it - unless that call is being captured, which is refused with a message instead of breaking the capture."""
@@ -1268,6 +1336,32 @@ def test_gray_plane_is_allocated_at_first_bgr_use_and_not_under_capture():
     torch.cuda.synchronize()
     m_bgr, a_bgr = eng.find_markers(bgr)                    # allocates the plane (B = G = R: the same masks)
     assert torch.equal(m_bgr, m_gray) and torch.equal(a_bgr, a_gray)
+    eng.close()
+    # with two pass streams the second workspace converts its own passes; its plane exists as soon as the
+    # handle's does, so that a MULTI-pass 3-channel call can be captured after a SINGLE-pass 3-channel warm-up
+    g6 = S.make_frames_torch(spec, range(6), seed=1, device="cuda")
+    bgr6 = g6.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
+    eng = Engine(spec.height, spec.width, max_markers=256, max_batch=2)
+    from vbs_amd.pipeline import reference_from_frame0
+    eng.set_option(L.OPT_PASS_STREAMS, 2)                   # builds the second workspace (no gray planes yet)
+    _, xy = reference_from_frame0(eng, g6[:1], 5, "full", "optimal")
+    xy_d = torch.as_tensor(xy, dtype=torch.float64, device="cuda")
+    cam = L.make_camera(*S.default_camera(spec), 2.0)
+    want, _, wc = eng.track_to_3d(g6, xy_d, 20.0, cam, 5.0)
+    eng.track_to_3d(bgr6[:2], xy_d, 20.0, cam, 5.0)         # one pass, 3 channels: allocates BOTH workspaces' planes
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            table, _, counts = eng.track_to_3d(bgr6, xy_d, 20.0, cam, 5.0)     # three passes, two streams, under capture
+    torch.cuda.current_stream().wait_stream(side)
+    table.zero_(); counts.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(counts, wc) and torch.equal(table, want)
+    del graph
     eng.close()
 
 
@@ -1629,21 +1723,24 @@ def test_capacity_frame_inside_a_batch_is_reported(tmp_path):
     eng.close()
 
 
-def test_track_shard_two_ranks_on_one_gpu(tmp_path):
-    """e (config 4's path at small scale): two ranks as fresh child processes sharing GPU 0 (gloo), contiguous shards of
-    12 config-2 frames, reference-table broadcast, all-gather of the tables, per-rank last-seen displacement with a
-    look-back across the shard edge - everything equal to the single-rank result."""
+@pytest.mark.parametrize("workload,pipelined", [("c2", 1), ("c2", 0), ("c5", 1)])
+def test_track_shard_two_ranks_on_one_gpu(tmp_path, workload, pipelined):
+    """e (config 4's path at small scale; `c5` = config 5's: 1920x1200, 441 markers, plane fit per shard): two ranks as
+    fresh child processes sharing GPU 0 (gloo), contiguous shards, reference-table broadcast, the tables gathered either
+    pass pair by pass pair (`pipelined`, dist.TableGather) or by the single collective of SURVEY 8(e) (dist.gather_tables),
+    per-rank last-seen displacement with a look-back across the shard edge, per-shard plane fit - everything equal to the
+    single-rank result.  (No scaling number follows from this: both ranks share one GPU and the transport is gloo.)"""
     import socket
     import subprocess
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), "helpers"))
     import shard_worker as SW
     from vbs_amd.pipeline import track_shard
-    n_total = 12
-    spec, frames = SW.make_clip(n_total)
+    n_total = 12 if workload == "c2" else 6
+    spec, frames = SW.make_clip(n_total, workload)
     K, dist, R, T = S.default_camera(spec)
     cam = L.make_camera(K, dist, R, T, 2.0)
-    eng = engine(spec.height, spec.width, max_batch=4)
+    eng = engine(spec.height, spec.width, max_markers=1024 if workload == "c5" else 512, max_batch=2 if workload == "c5" else 4)
     one = track_shard(eng, torch.from_numpy(frames).cuda(), n_total, cam=cam, warmup_frames=0)
     table1, disp1 = one.table.cpu().numpy(), one.disp.cpu().numpy()
     assert (one.counts.cpu().numpy() == np.where(np.arange(n_total) == n_total // 2, spec.n_markers - 1, spec.n_markers)).all()
@@ -1652,21 +1749,26 @@ def test_track_shard_two_ranks_on_one_gpu(tmp_path):
     port = s.getsockname()[1]
     s.close()
     worker = os.path.join(os.path.dirname(__file__), "helpers", "shard_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(n_total), str(tmp_path)],
+    procs = [subprocess.Popen([sys.executable, worker, str(r), "2", str(port), str(n_total), str(tmp_path), workload, str(pipelined)],
                               stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     for r in range(2):
         z = np.load(tmp_path / f"rank{r}.npz")
         a, b = int(z["span"][0]), int(z["span"][1])
-        assert (a, b) == ((0, 6), (6, 12))[r]
+        assert (a, b) == ((0, n_total // 2), (n_total // 2, n_total))[r]
         assert np.array_equal(z["ids"], one.ids) and np.array_equal(z["xy"], one.ref_xy)
         assert np.array_equal(z["table"], table1)                      # the gathered table, bit for bit
         assert np.array_equal(z["disp"], disp1[a:b], equal_nan=True)   # this rank's frames of the displacement
         assert np.array_equal(z["plane"], one.plane.cpu().numpy()[a:b], equal_nan=True)
-    # the look-back did cross the edge: the painted-out marker is unseen in frame 6 and measured in frame 7 against frame 5
-    slot = int(np.nonzero((table1[6, :, 0].astype(int) & 1) == 0)[0][0])
-    assert disp1[7, slot, 0] == 1 and disp1[6, slot, 0] == 0
-    want = table1[7, slot, 6:9] - table1[5, slot, 6:9]
-    assert np.allclose(disp1[7, slot, 1:4], want, atol=2e-6)
+    # the look-back did cross the edge: the painted-out marker is unseen in the first frame of rank 1 and measured in the next
+    # against the last frame of rank 0
+    e = n_total // 2
+    slot = int(np.nonzero((table1[e, :, 0].astype(int) & 1) == 0)[0][0])
+    assert disp1[e + 1, slot, 0] == 1 and disp1[e, slot, 0] == 0
+    want = table1[e + 1, slot, 6:9] - table1[e - 1, slot, 6:9]
+    assert np.allclose(disp1[e + 1, slot, 1:4], want, atol=2e-6)
+    if workload == "c5":                                   # the per-shard plane fit is the single-rank one (441 markers per frame)
+        pl = one.plane.cpu().numpy()
+        assert pl.shape[0] == n_total and np.isfinite(pl[:, :4]).all()
     eng.close()

@@ -265,12 +265,20 @@ static int need_gray(vbs_handle* h, int planes, hipStream_t s) {
         int rc = dev_alloc(h, slot[i], (size_t)h->maxb * h->H * h->P);
         if (rc != VBS_OK) return rc;
     }
+    // the second workspace converts its own passes: its first plane exists whenever this handle's does, so that a multi-pass
+    // call on 3-channel frames captured into a graph finds it in place after ANY uncaptured 3-channel call
+    if (h->twin && !h->twin->gray && h->gray && !capturing(s)) {
+        int rc = need_gray(h->twin, 1, s);
+        if (rc != VBS_OK) { h->err = "second pass workspace: " + h->twin->err; return rc; }
+    }
     return VBS_OK;
 }
 
 // The per-frame statistics of a pass <- 0; for a pass of a few frames also what launch_labelling would clear (k_stage_lat's
 // headers, the slow counter and flags lie in front of fstat in one allocation): one launch instead of two
 static void clear_pass(vbs_handle* h, int nb, hipStream_t s) {
+    h->last_ws = h; h->last_nb = nb;                     // every pass entry point records itself (vbs_track_to_3d names the
+                                                         // workspace of ITS last pass afterwards): vbs_frame_stats / vbs_stage_tables
     if (nb <= h->lat_frames && h->stage_impl == 0 && nb <= h->lat_slots) {
         launch_fill(h->lat_hdr, 0u, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + 4 + (size_t)h->maxb + (size_t)nb * 8, s);
         h->pass_cleared = true;
@@ -439,7 +447,8 @@ static int twin_of(vbs_handle* h);
 
 extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
     if (!h) return VBS_EINVAL;
-    if (h->twin && option != VBS_OPT_PASS_STREAMS) (void)vbs_set_option(h->twin, option, value);   // (same checks, same answer)
+    // (same checks, same answer; the twin never converts a pass ahead on a side stream: its second gray plane would be dead memory)
+    if (h->twin && option != VBS_OPT_PASS_STREAMS && option != VBS_OPT_GRAY_SIDE_STREAM) (void)vbs_set_option(h->twin, option, value);
     switch (option) {
         case VBS_OPT_PASS_STREAMS:
             if (value != 1 && value != 2) break;
@@ -690,6 +699,7 @@ static int twin_of(vbs_handle* h) {
     }
     h->twin_stream = st; h->ev_tfork = ef; h->ev_tjoin = ej;
     h->twin = t;
+    if (h->gray) { int rg = need_gray(t, 1, nullptr); if (rg != VBS_OK) { h->err = "second pass workspace: " + t->err; return rg; } }
     return VBS_OK;
 }
 

@@ -492,8 +492,10 @@ __device__ __forceinline__ u32 comp_at(const u64* __restrict__ bits, const u32* 
 // MORPH = 14 | 8 (the few-frames path): the workgroup first makes the frame's band / opened planes itself (k_morph's waves,
 // its sixteen in turn) - one launch less on a path where a launch costs as much as a kernel; 0: the planes are there
 template <int MORPH>
-__global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bits,
-                                                u64* __restrict__ open_bits,
+// (band_bits / open_bits: plain pointers - the MORPH instances WRITE the planes (morph_wave) and read them back later in the
+//  kernel; a write through a restrict-qualified pointer-to-const was undefined behaviour)
+__global__ __launch_bounds__(1024) void k_label(u64* band_bits,
+                                                u64* open_bits,
                                                 u32* __restrict__ wbase_all, u32* __restrict__ node_pos_all,
                                                 u32* __restrict__ node_comp_all, u32* __restrict__ ncomp_all,
                                                 u32* __restrict__ band_first, u64* __restrict__ band_sums,
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(1024) void k_label(const u64* __restrict__ band_bit
     if (!all && !slow_flag[n]) continue;
     if (MORPH) {                                        // (the stage loop's first fence + barrier publish the planes)
         for (int wv = (int)(threadIdx.x >> 6); wv < mwpf; wv += 16)
-            morph_wave<(MORPH ? MORPH : 14)>(mbits, abits, const_cast<u64*>(band_bits), open_bits, H, W, WW, mG, mstrips, mrps, n, wv);
+            morph_wave<(MORPH ? MORPH : 14)>(mbits, abits, band_bits, open_bits, H, W, WW, mG, mstrips, mrps, n, wv);
     }
     for (int stage = 0; stage < 4; ++stage) {
     __threadfence();                                    // the previous stage's global writes (holes, filled bits, tables)

@@ -372,15 +372,23 @@ class MarkerTracker:
         with ThreadPoolExecutor(1) as ahead:
             fut = ahead.submit(self.cap.read_batch, batch, bufs[0])
             while True:
-                m = fut.result()
-                if not m:
-                    break
-                fut = ahead.submit(self.cap.read_batch, batch, bufs[(k + 1) & 1])
                 try:
+                    m = fut.result()                       # (a decode error - a corrupt frame - surfaces here)
+                    fut = None
+                    if not m:
+                        break
+                    fut = ahead.submit(self.cap.read_batch, batch, bufs[(k + 1) & 1])
                     data.append(self._process_batch(bufs[k & 1][:m]))
                 except Exception:
-                    fut.cancel()
-                    if data:                               # the rows of the batches before the failing frame are kept
+                    # the rows of the batches before the failing frame are kept, whichever side failed; the reader is
+                    # released only once the decode running ahead has finished with its buffers (a running task cannot be
+                    # cancelled)
+                    if fut is not None and not fut.cancel():
+                        try:
+                            fut.result()
+                        except Exception:
+                            pass
+                    if data:
                         self._save_results(data)
                     self._cleanup()
                     raise
@@ -422,9 +430,14 @@ class MarkerTracker:
                 from ._lib import VbsError
                 raise VbsError(f"device status {n0} in frame 0")
             self._process_first_frame(_det_to_markers(det[0].cpu().numpy(), n0))
-            # f4: the same assignment on the device (vbs_assign_ids), checked against the host table that is kept (the
-            # reference's own order: the two may only differ in the order of markers at mathematically equal angles)
-            if self.config.get("kmeans", "optimal") == "optimal" and self.config.get("ids_on_device", True):
+            # f4: the same assignment on the device (vbs_assign_ids) with the host table as its checker: where the two agree
+            # bit for bit the device's arrays are the ones the tracking calls use, else the host's (the reference's own
+            # order: the two may only differ in the order of markers at mathematically equal angles).  `first_frame_markers`
+            # - the reference's attribute, marker dicts and all - is the host table either way.  The kernel covers
+            # num_layers <= 16 (k_ids.hip): a configuration beyond that runs on the host alone, as it always did.
+            self._ref_arrays = None
+            if (self.config.get("kmeans", "optimal") == "optimal" and self.config.get("ids_on_device", True)
+                    and int(self.config.get("num_layers", 5)) <= 16):
                 ids_h, xy_h = _ids.reference_arrays(self.first_frame_markers)
                 ids_d, xy_d = eng.assign_ids(det, counts, self.config.get("num_layers", 5),
                                              self.config.get("id_mode", "as_written"))
@@ -432,9 +445,14 @@ class MarkerTracker:
                 if ids_d.shape != np.asarray(ids_h).shape or not np.array_equal(ids_d, ids_h):
                     from ._lib import VbsError
                     raise VbsError("vbs_assign_ids disagrees with the host assignment on the marker IDs of frame 0")
-                self.ids_device_check = {"equal_to_host": bool(np.array_equal(xy_d, xy_h)),
+                same = bool(np.array_equal(xy_d, xy_h))
+                self.ids_device_check = {"equal_to_host": same, "used": "device" if same else "host",
                                          "slots_in_another_order": int((xy_d != np.asarray(xy_h)).any(axis=1).sum())}
-        ids, ref_xy = _ids.reference_arrays(self.first_frame_markers)
+                if same:
+                    self._ref_arrays = (ids_d, xy_d)
+            else:
+                self.ids_device_check = {"on_device": False, "used": "host"}
+        ids, ref_xy = getattr(self, "_ref_arrays", None) or _ids.reference_arrays(self.first_frame_markers)
         table, det, counts = eng.track_to_3d(ft, ref_xy, self.config.get("min_marker_distance", 20),
                                              want_det=True)
         counts = counts.cpu().numpy()

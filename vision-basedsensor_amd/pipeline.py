@@ -33,14 +33,19 @@ ID_CHECK = {}                  # what the last reference_from_frame0 found (benc
 def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mode="full", kmeans="optimal",
                           ids_on_device=True):
     """Detect frame 0 on the device and assign the identities (once per video, `marker_detection.py:275-347`).
-    `ids_on_device` (default) runs the assignment on the GPU (`vbs_assign_ids`, deterministic clustering only) WITH THE HOST
-    ASSIGNMENT AS ITS CHECKER: the host restatement (`ids.assign_ids`, pinned to the reference body's golden) runs on the
-    same detections, and what is returned is always the host's table - the reference's own order.  The two differ at most
-    among markers whose angles are mathematically equal (collinear with the centre), which np.arctan2's last bit orders
-    on the host and the device's atan2 on the GPU; `ID_CHECK` says whether they agreed and in how many slots not."""
+    `ids_on_device` (default) runs the assignment on the GPU (`vbs_assign_ids`, deterministic clustering only) and the host
+    restatement (`ids.assign_ids`, pinned to the reference body's golden) on the same detections as its checker:
+      * the two tables agree bit for bit (every benchmark frame 0, the reference's real frame) -> the DEVICE table is what is
+        returned and used (`ID_CHECK["used"] == "device"`);
+      * they hold the same IDs but order markers at mathematically equal angles differently (collinear with the centre:
+        np.arctan2's last bit decides on the host, the device's atan2 on the GPU) -> the host table, the reference's own
+        order (`"host"`, `slots_in_another_order` says how many slots);
+      * anything else raises.
+    The device kernel covers `num_layers <= 16` (k_ids.hip: IDS_MAXK) and `kmeans == "optimal"`; other configurations run
+    on the host alone (`"host"`, `on_device: False`) as they always did."""
     _, det, counts = eng.track_to_3d(frame0[:1], None, want_det=True)
     dev = None
-    if ids_on_device and kmeans == "optimal":
+    if ids_on_device and kmeans == "optimal" and int(num_layers) <= 16:
         ids_d, xy_d = eng.assign_ids(det, counts, num_layers, id_mode)      # raises the reference's ValueError on no markers
         dev = (ids_d.cpu().numpy().astype("int64"), xy_d.cpu().numpy())
     n0 = int(counts[0].item())
@@ -49,7 +54,7 @@ def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mo
     table = _ids.assign_ids(_det_to_markers(det[0].cpu().numpy(), n0), num_layers, id_mode, kmeans)
     ids, xy = _ids.reference_arrays(table)
     ID_CHECK.clear()
-    ID_CHECK.update({"on_device": dev is not None})
+    ID_CHECK.update({"on_device": dev is not None, "used": "host"})
     if dev is not None:
         same_ids = dev[0].shape == np.asarray(ids).shape and bool(np.array_equal(dev[0], ids))
         if not same_ids:
@@ -60,6 +65,9 @@ def reference_from_frame0(eng: Engine, frame0: torch.Tensor, num_layers=5, id_mo
         if differ and sorted(map(tuple, dev[1].tolist())) != sorted(map(tuple, np.asarray(xy).tolist())):
             raise L.VbsError("vbs_assign_ids returned reference coordinates the host assignment does not have")
         ID_CHECK.update({"equal_to_host": differ == 0, "slots_in_another_order": differ, "markers": int(len(ids))})
+        if differ == 0:
+            ID_CHECK["used"] = "device"
+            return dev[0], dev[1]
     return ids, xy
 
 

@@ -150,13 +150,18 @@ class AviReader:
         if m:
             first = self._next
             self._next += m
-            workers = max(1, min(m, threads or min(16, os.cpu_count() or 1)))
-            if workers == 1:
+            workers = max(1, threads or min(16, os.cpu_count() or 1))
+            if workers == 1 or m == 1:
                 for i in range(m):
                     self._decode_into(first + i, out[i])
             else:
+                # ONE pool per reader, of the size asked for (a short last batch simply leaves workers idle: replacing the
+                # pool when the batch length changed leaked the old one's threads)
                 pool = getattr(self, "_pool", None)
-                if pool is None or getattr(self, "_pool_workers", 0) != workers:
+                if pool is not None and getattr(self, "_pool_workers", 0) != workers:
+                    pool.shutdown(wait=True)
+                    pool = None
+                if pool is None:
                     pool = self._pool = ThreadPoolExecutor(workers)
                     self._pool_workers = workers
                 list(pool.map(lambda i: self._decode_into(first + i, out[i]), range(m)))
