@@ -26,6 +26,13 @@ Extra objects on the JSON line:
                 `band_stage` = the 8(d) stage proper (band half of the kernel, from the committed phase log), `valu` = the
                 vector-issue share of the SIMDs' cycles in k_stage (committed SQ counters): the yardstick of a kernel that
                 reads 0.3 x its algorithmic bytes.
+                The per-kernel leg runs every pass on ONE stream with an event pair around each launch (>= 8 launches per
+                kernel after a warm-up call), the timed region runs the passes on TWO streams: the sum of the kernels' times
+                per frame may therefore exceed `us_per_frame_per_gpu`, and `roofline.frac` is the pessimistic reading of the
+                two.  `band_stage` is MEASURED IN THIS RUN (`measured_in_this_run`): a child process (fresh interpreter, the
+                debug library with its stop-after-the-band-half knob, 512 frames) started once the parent's GPU work is
+                done.  `valu` comes from committed counters and says whether the kernel's sources are still the ones they
+                were taken on (`same_sources`).
   roofline_mfma k_blur16 / k_blur_mfma (int8) and k_ncc_mfma (float16) against the dense matrix-core peaks: algorithmic
                 operations of the separable filters / live kernel time (same HIP events)
   kernels       live average ms per launch of every kernel of the fused path (one launch = `batch` frames)
@@ -73,6 +80,42 @@ def _newest(pattern):
         return (int(m.group(1)), 0 if m.group(2).startswith("pre") else 1, m.group(2))
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=key)
     return files[-1] if files else None
+
+
+def _sources_sha16(names=("k_stage.hip", "stage_common.h", "ccl_common.h")):
+    """Fingerprint of the labelling kernel's sources: committed counter files carry it, so that the line can say whether a
+    number taken from them belongs to the kernel that ran."""
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(ROOT, "vision-basedsensor_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def _band_stage_live(workload, frames=512, timeout=240):
+    """us per frame of k_stage stopped after the band half's sums are out (band + 4-connected labels + count /
+    sum x / sum y per label), measured NOW: tools/gpu_stage_phase.py as a child process (a fresh interpreter that loads
+    libvbs_dbg.so and reads VBS_STAGE_STOP=10; the product library has no such knob).  None + reason when it cannot run."""
+    import subprocess
+    tool = os.path.join(ROOT, "tools", "gpu_stage_phase.py")
+    dbg = os.path.join(ROOT, "vision-basedsensor_amd", "csrc", "libvbs_dbg.so")
+    if not os.path.exists(dbg):
+        return None, "libvbs_dbg.so is not built (__graft_entry__.build())"
+    out = {}
+    for stop in (10, 0):
+        try:
+            r = subprocess.run([sys.executable, tool, str(frames), workload, "child"], env=dict(os.environ, VBS_STAGE_STOP=str(stop)),
+                               capture_output=True, text=True, timeout=timeout)
+        except Exception as e:
+            return None, f"{type(e).__name__}: {e}"
+        if r.returncode != 0:
+            return None, (r.stderr or r.stdout).strip()[-300:]
+        try:
+            out[stop] = json.loads(r.stdout.strip().splitlines()[-1])["k_stage"]
+        except Exception as e:
+            return None, f"unparsable child output: {r.stdout[-200:]!r}"
+    return out, None
 
 
 def _cpu_worker(args):
@@ -363,11 +406,16 @@ def main():
     ap.add_argument("--cpu-frames-per-worker", type=int, default=3)
     ap.add_argument("--host-frames", type=int, default=1024)
     ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c1"],
+    ap.add_argument("--workload", default="c3", choices=["c3", "c5", "c1", "real"],
                     help="c3 = BASELINE config 3/4 (1280x1024, 13x13; the headline metric); c5 = config 5 (1920x1200, 21x21, "
                          "adds the plane-fit pose per frame; the JSON line then names that workload); c1 = the reference's REAL "
                          "configuration: 640x480 BGR frames (collecting.py:29-31) through its default crop (1/8, 1/8, 1/16, 0) "
-                         "(marker_detection.py:481) = 480 wide x 450 high, small branch, 7x7 dots; --frames defaults to 16384")
+                         "(marker_detection.py:481) = 480 wide x 450 high, small branch, 7x7 dots; --frames defaults to 16384; "
+                         "real = the reference's REAL LAYOUT AND TEXTURE: its one published frame (img/raw_markers.png -> "
+                         "tests/golden/raw_markers_bgr.npz, 467x437 BGR, 65 dots of ~27 px at a pitch of 35-42 px) expanded on "
+                         "the device to --frames (default 16384) frames by seeded shifts of +-3 px and noise sigma 2; the line "
+                         "adds the labelling path every frame took (`slow_path_frames`, reasons) and the rate of the general "
+                         "labelling kernel on the same frames")
     ap.add_argument("--channels", type=int, default=1, choices=[1, 3],
                     help="1 = gray frames (headline); 3 = the whole benchmark on BGR frames (the line then says so)")
     ap.add_argument("--backend", default="nccl", help="nccl (= RCCL, the real thing) | gloo (rehearsal of N>1 on one GPU)")
@@ -410,7 +458,15 @@ def main():
         else:
             td.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    spec = {"c3": S.config2, "c5": S.config5, "c1": S.config1}[args.workload]()
+    real_bgr = None
+    if args.workload == "real":
+        real_bgr = np.load(os.path.join(ROOT, "tests", "golden", "raw_markers_bgr.npz"))["bgr"]
+        spec = S.FrameSpec(int(real_bgr.shape[1]), int(real_bgr.shape[0]), np.zeros((65, 2), np.int64), 27 * 16, name="real")
+        args.channels = 3
+        if args.frames == 4096:
+            args.frames = 16384
+    else:
+        spec = {"c3": S.config2, "c5": S.config5, "c1": S.config1}[args.workload]()
     crop = None
     if args.workload == "c1":
         from vbs_amd.marker_detection import _crop_box
@@ -424,17 +480,24 @@ def main():
     n_local, n_total = args.frames, args.frames * world
     K, dist, R, T = S.default_camera(spec)
     cam = L.make_camera(K, dist, R, T, 2.0)
-    eng = Engine(H, W, max_markers={"c3": 512, "c5": 1024, "c1": 256}[args.workload], max_batch=args.batch, device=local_rank)
+    eng = Engine(H, W, max_markers={"c3": 512, "c5": 1024, "c1": 256, "real": 256}[args.workload], max_batch=args.batch, device=local_rank)
     eng.set_option(L.OPT_PASS_STREAMS, args.pass_streams)
 
     # synthetic frames of this rank's contiguous block, rendered on the device (same bytes as NumPy)
     a, b = D.shard_bounds(n_total, world, rank)
-    gray = S.make_frames_torch(spec, range(a, b), seed=args.seed, device=dev, chunk=16)
+    if real_bgr is not None:
+        # this rank's block of the sequence (frame 0 = the still itself, on rank 0)
+        allf, shifts = S.jittered_copies_torch(real_bgr, b - a, seed=args.seed, device=dev, start=a, total=n_total)
+        gray = None
+    else:
+        gray = S.make_frames_torch(spec, range(a, b), seed=args.seed, device=dev, chunk=16)
 
     def as_bgr(g):
         return g.unsqueeze(-1).expand(-1, -1, -1, 3).contiguous()
 
-    if crop:
+    if real_bgr is not None:
+        frames = allf
+    elif crop:
         # rendered as BGR in slices (the full-size gray copy and its BGR copy would not both be needed at once); what the
         # engine sees is the reference's cropped view: a pointer offset and the full frames' strides, no copy
         full = torch.empty((gray.shape[0], spec.height, spec.width, 3), dtype=torch.uint8, device=dev)
@@ -508,7 +571,11 @@ def main():
     tracked = int((table[..., 0].int() & 1).sum().item())
     solved = int(((table[..., 0].int() & 2) > 0).sum().item())
     assert int(counts.min().item()) >= 0, "a frame reported a device status"
-    assert tracked == n_total * M, f"tracked {tracked} of {n_total * M} marker observations"
+    if args.workload == "real":
+        # noise on real texture: a frame may miss a dot; every frame must still be found almost whole
+        assert tracked >= 0.999 * n_total * M, f"tracked {tracked} of {n_total * M} marker observations"
+    else:
+        assert tracked == n_total * M, f"tracked {tracked} of {n_total * M} marker observations"
     table_sums = None
     if world > 1:
         # the same gathered table on every rank: (sum, xor-fold) of its bits, exchanged and compared everywhere
@@ -537,7 +604,10 @@ def main():
                                     f"(21x21 dots), plus plane-fit pose" if args.workload == "c5" else
                                     f"the reference's real configuration (BASELINE config 1's frames in bulk): {args.frames} "
                                     f"synthetic 640x480 {fmt} frames per GPU (7x7 dots) through the default crop "
-                                    f"(1/8, 1/8, 1/16, 0) = {W}x{H} strided views, small branch") +
+                                    f"(1/8, 1/8, 1/16, 0) = {W}x{H} strided views, small branch" if args.workload == "c1" else
+                                    f"the reference's real layout and texture: {args.frames} frames per GPU made on the device from "
+                                    f"its one published frame (img/raw_markers.png, {W}x{H} BGR, 65 dots of ~27 px at a pitch of "
+                                    f"35-42 px) by seeded shifts of +-3 px and noise sigma 2; small branch") +
                                    f", resident in HBM; fused track->3D table + "
                                    f"{'RCCL all-gather + ' if world > 1 else ''}last-seen displacement",
                        "frames_per_gpu": args.frames, "internal_batch": args.batch, "pass_streams": args.pass_streams, "markers": M, "channels": args.channels,
@@ -557,7 +627,8 @@ def main():
         }
 
     # ---- the same workload on BGR frames (the reference's input format; gray stays the headline) ----------------------
-    if args.channels == 1 and not args.no_extras and not crop:
+    side_legs = not crop and args.workload != "real"       # legs that render their own synthetic frames
+    if args.channels == 1 and not args.no_extras and side_legs:
         nb_ = min(n_local, 2048)
         fb = as_bgr(gray[:nb_])
         n_keep = n_total
@@ -589,8 +660,11 @@ def main():
     # ---- live per-kernel timing + the threshold+CCL roofline (rank 0; other ranks idle at the barrier) ----
     if rank == 0:
         nk = min(args.roofline_frames, n_local)
-        eng.profile(True)
-        reps = 2
+        eng.profile(True)                                                    # (passes on ONE stream from here on)
+        eng.track_to_3d(frames[:nk], xy, 20.0, cam, 5.0)                     # warm-up in the profiled configuration,
+        eng.profile_read()                                                   # its timings discarded
+        passes = max(1, -(-nk // args.batch))
+        reps = max(2, -(-8 // passes))                                       # >= 8 launches of every kernel
         for _ in range(reps):
             eng.track_to_3d(frames[:nk], xy, 20.0, cam, 5.0)
         prof = eng.profile_read()
@@ -622,25 +696,23 @@ def main():
         #     after the band half's sums are out, `stop 10`); `opened_half_us_per_frame` is the rest of the live time.
         # (b) the stage reads 0.3 x its algorithmic bytes and is bound by vector-instruction issue: `valu` = the share of the
         #     SIMDs' cycles in which k_stage issues a vector instruction, from the newest committed SQ counters.
-        ph = _newest(f"*_stage_phase_timing_{args.workload}.log")
-        if ph:
-            stops = {}
-            for line in open(ph):
-                parts = line.split(None, 2)
-                if len(parts) == 3 and parts[0] == "stop":
-                    try:
-                        stops[int(parts[1])] = json.loads(parts[2])
-                    except ValueError:
-                        pass
-            pick = next((k for k in (10, 4, 3, 2) if k in stops and "k_stage" in stops[k]), None)
-            if pick is not None:
-                band_us = float(stops[pick]["k_stage"])
-                live_us = 1e3 * stage_ms_launch / fpl
+        result["roofline"]["measured_in_this_run"] = True
+        if world == 1 and args.workload in ("c3", "c5") and not args.no_extras:
+            live, why = _band_stage_live(args.workload)
+            if live:
+                band_us = float(live[10])
                 result["roofline"]["band_stage"] = {
                     "what": "band + 4-connected labels + count / sum x / sum y per label: the SURVEY 8(d) stage proper",
                     "us_per_frame": band_us, "frac": round(alg_bytes_frame / (band_us * 1e-6) / 1e9 / HBM_PEAK_GBS, 5),
-                    "opened_half_us_per_frame": round(max(live_us - band_us, 0.0), 3),
-                    "source": f"{os.path.basename(ph)} (stop {pick}; debug library, batch 512, not measured in this run)"}
+                    "achieved": round(alg_bytes_frame / (band_us * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "whole_kernel_us_per_frame_same_child": float(live[0]),
+                    "opened_half_us_per_frame": round(max(float(live[0]) - band_us, 0.0), 4),
+                    "measured_in_this_run": True,
+                    "how": "child process (fresh interpreter) of this run: tools/gpu_stage_phase.py, libvbs_dbg.so, VBS_STAGE_STOP=10 "
+                           "(the kernel returns once the band half's sums are out) and 0 (whole kernel), 512 frames per launch, "
+                           "HIP events"}
+            else:
+                result["roofline"]["band_stage"] = {"measured_in_this_run": False, "error": why}
         sqf = _newest("*_sq_counters_stage.json")
         if sqf and args.workload == "c3":
             sj = json.load(open(sqf))
@@ -653,10 +725,12 @@ def main():
                     "instructions_per_frame": round(ks["SQ_INSTS_VALU"] / sj["frames_per_launch"]),
                     "cycles_per_instruction": round(cyc / ks["SQ_INSTS_VALU"], 2),
                     "simd_cycles_per_frame": round(avail / sj["frames_per_launch"]),
-                    "frac": round(cyc / avail, 4), "waves_per_simd": 3,
-                    "source": f"{os.path.basename(sqf)} (rocprofv3 --pmc passes over a {sj['frames_per_launch']}-frame launch, not this run)"}
+                    "frac": round(cyc / avail, 4), "waves_per_simd": 3, "measured_in_this_run": False,
+                    "same_sources": (sj.get("src_sha16") == _sources_sha16()) if sj.get("src_sha16") else None,
+                    "source": f"{os.path.basename(sqf)} (rocprofv3 --pmc passes over a {sj['frames_per_launch']}-frame launch, not this run; "
+                              f"`same_sources`: the file's fingerprint of k_stage's sources equals today's - null = the file carries none)"}
         # the staged entry on uint8 images (the reference's `_marker_center(mask, area_mask)` interface)
-        if args.channels == 1 and not crop:
+        if args.channels == 1 and side_legs:
             mask, area = eng.find_markers(frames[:nk])
             torch.cuda.synchronize()
             eng.marker_center(mask, area)                       # warm
@@ -674,6 +748,40 @@ def main():
             del mask, area
         eng.profile(False)
         result["kernels"] = kernels
+        # which labelling path did the frames take?  vbs_stage_tables describes the last internal pass: pass by pass over the
+        # first `nk` frames (every frame of the `real` workload).  0 = the fused kernel kept the frame; anything else = it
+        # was handed to the general kernel (k_morph + k_label), the value says why (include/vbs.h).
+        import collections
+        hist = collections.Counter()
+        n_chk = n_local if args.workload == "real" else nk
+        for s0 in range(0, n_chk, args.batch):
+            e0 = min(n_chk, s0 + args.batch)
+            eng.track_to_3d(frames[s0:e0], xy, 20.0, cam, 5.0)
+            hist.update(int(v) for v in eng.stage_tables(e0 - s0)["slow"])
+        result["config"]["slow_path_frames"] = int(sum(v for k, v in hist.items() if k))
+        result["config"]["slow_path_reasons"] = {str(k): int(v) for k, v in sorted(hist.items()) if k}
+        result["config"]["slow_path_frames_checked"] = int(n_chk)
+        if args.workload == "real":
+            # the general labelling kernel on the same frames (VBS_OPT_STAGE_IMPL = 2: k_morph + k_label label EVERY frame):
+            # what a frame costs that the fast path hands on
+            e2 = Engine(H, W, max_markers=256, max_batch=args.batch, device=local_rank)
+            e2.set_option(L.OPT_STAGE_IMPL, 2)
+            e2.set_option(L.OPT_PASS_STREAMS, 1)
+            n2 = min(n_local, 2 * args.batch)
+            t2, _, c2 = e2.track_to_3d(frames[:n2], xy, 20.0, cam, 5.0)
+            tf, _, cf = eng.track_to_3d(frames[:n2], xy, 20.0, cam, 5.0)
+            assert torch.equal(t2, tf) and torch.equal(c2, cf), "the general labelling kernel must give the fused kernel's table"
+            e2.profile(True)
+            for _ in range(3):
+                e2.track_to_3d(frames[:n2], xy, 20.0, cam, 5.0)
+            p2 = e2.profile_read()
+            e2.profile(False)
+            result["config"]["general_labelling_path"] = {
+                "what": "VBS_OPT_STAGE_IMPL = 2: k_morph + k_label label every frame (the path of a frame with holes or beyond the "
+                        "fast path's tables); same table as the fused kernel, asserted",
+                "us_per_frame": {k: round(1e3 * v[1] / (3 * n2), 4) for k, v in p2.items() if k in ("k_morph", "k_label", "k_finalize")},
+                "frames": n2}
+            e2.close()
         # the two matrix-core kernels of the front end against the dense MFMA peaks (MI355X_MICROARCH.md: bf16/f16
         # ~2.5 PFLOP/s, int8 2x that); algorithmic operations = the separable filters as written in the reference
         # (Toeplitz padding, hi/lo splits and the count product are overhead, not counted)
@@ -694,7 +802,7 @@ def main():
     if world > 1:
         td.barrier()
 
-    if rank == 0 and world == 1 and not args.no_extras and not crop:
+    if rank == 0 and world == 1 and not args.no_extras and side_legs:
         try:
             del frames
             torch.cuda.empty_cache()
@@ -705,7 +813,7 @@ def main():
             result["config"]["single_frame_us"] = single_frame_us(spec, args.seed, (K, dist, R, T))
         except Exception as e:
             result["config"]["single_frame_us"] = {"error": f"{type(e).__name__}: {e}"}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and not crop:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and side_legs:
         try:
             result["cpu_baseline"] = cpu_baseline(spec, args.seed, (K, dist, R, T), args.cpu_single_frames,
                                                   args.cpu_workers, args.cpu_frames_per_worker, probe=cpu_probe)

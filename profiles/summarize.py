@@ -32,6 +32,16 @@ def kname(s):
     return k.split("<")[0]
 
 
+def kfull(s):
+    """The kernel with its template arguments (`k_blur16<false, false, false>`): the by-shape table keys on THIS, so that
+    the product instantiation is not averaged with the uint8-output one of the staged entry (same grid, 9 % slower: round
+    4's table quoted 1.27 / 2.11 us for kernels that ran at 1.17 / 2.02)."""
+    k = s.split("(")[0].replace("void ", "").strip()
+    if k.startswith("k_ccl<"):
+        return "k_ccl_band" if k.startswith("k_ccl<0") else "k_ccl_open"
+    return k
+
+
 rows = list(csv.reader(open(one(f"prof_{tag}/**/*kernel_stats.csv"))))
 with open(os.path.join(ROOT, "profiles", f"{tag}_rocprofv3_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
@@ -49,7 +59,7 @@ trace = one(f"prof_{tag}/**/*kernel_trace.csv", required=False)
 if trace:
     by = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(trace)):
-        k = kname(r["Kernel_Name"])
+        k = kfull(r["Kernel_Name"])
         if not k.startswith("k_"):
             continue
         grid = (int(r["Grid_Size_X"]), int(r["Grid_Size_Y"]), int(r["Grid_Size_Z"]))
@@ -65,10 +75,11 @@ if trace:
                                       for g, v in groups.items() if g != grid},
                      "all_calls_avg_ns": round(sum(sum(v) for v in groups.values()) / sum(len(v) for v in groups.values()), 1)}
     json.dump({"tag": tag, "frames_per_launch": frames, "source": "rocprofv3 --kernel-trace, calls grouped by grid size; the "
-               "group with the largest total duration per kernel (the benchmark shape)", "kernels": shapes},
+               "group with the largest total duration per kernel INSTANTIATION (template arguments kept) = the benchmark shape",
+               "kernels": shapes},
               open(os.path.join(ROOT, "profiles", f"{tag}_kernel_trace_by_shape.json"), "w"), indent=1)
     for k, v in shapes.items():
-        print(f"{k:16s} {v['calls']:4d} launches of grid {v['grid']}: {v['us_per_frame']:.3f} us/frame "
+        print(f"{k:44s} {v['calls']:4d} launches of grid {v['grid']}: {v['us_per_frame']:.3f} us/frame "
               f"(all {sum(len(x) for x in by[k].values())} calls averaged: {v['all_calls_avg_ns'] / frames / 1e3:.3f})")
 
 

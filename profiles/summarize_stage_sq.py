@@ -39,7 +39,11 @@ for k, c in sq.items():
     if c.get("SQ_BUSY_CYCLES") and c.get("SQ_ACTIVE_INST_VALU"):
         # SQ_BUSY_CYCLES is summed over the SQs (one per CU-pair group); ACTIVE_INST_VALU in quad-cycles over all waves
         c["valu_quadcycles_per_frame"] = round(c["SQ_ACTIVE_INST_VALU"] / frames)
-json.dump({"tag": tag, "frames_per_launch": frames,
+import hashlib
+_h = hashlib.sha256()
+for _n in ("k_stage.hip", "stage_common.h", "ccl_common.h"):        # (bench.py: _sources_sha16 - the kernel these counters are of)
+    _h.update(open(os.path.join(ROOT, "vision-basedsensor_amd", "csrc", _n), "rb").read())
+json.dump({"tag": tag, "frames_per_launch": frames, "src_sha16": _h.hexdigest()[:16],
            "note": "one launch over `frames_per_launch` frames of the fused path (tools/gpu_detect_run.py); SQ_WAVE_CYCLES / "
                    "SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles summed over all waves; *_per_wave = instructions per wave",
            "kernels": sq}, open(os.path.join(ROOT, "profiles", f"{tag}_sq_counters_stage.json"), "w"), indent=1)

@@ -11,7 +11,8 @@ echo "bench c3 done"
 timeout -k 10 300 python bench.py --workload c5 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_c5.json 2> $OUT/${TAG}_bench_c5.err
 timeout -k 10 300 python bench.py --channels 3 --steps 3 --warmup 1 --no-cpu-baseline --no-extras > $OUT/${TAG}_bench_bgr.json 2> $OUT/${TAG}_bench_bgr.err
 timeout -k 10 300 python bench.py --workload c1 --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_c1.json 2> $OUT/${TAG}_bench_c1.err
-echo "bench c5 / bgr / c1 done"
+timeout -k 10 300 python bench.py --workload real --steps 3 --warmup 1 --no-cpu-baseline > $OUT/${TAG}_bench_real.json 2> $OUT/${TAG}_bench_real.err
+echo "bench c5 / bgr / c1 / real done"
 timeout -k 10 300 python tools/gpu_stage_phase.py 512 c3 > $OUT/${TAG}_stage_phase_timing_c3.log 2>&1
 timeout -k 10 300 python tools/gpu_ncc_phase.py 512 > $OUT/${TAG}_ncc_phase_timing.log 2>&1
 timeout -k 10 120 python tools/gpu_single_frame.py > $OUT/${TAG}_single_frame.log 2>&1

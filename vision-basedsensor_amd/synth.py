@@ -229,30 +229,34 @@ def default_camera(spec: FrameSpec):
     return K, dist, R, T
 
 
-def jittered_copies_torch(frame, n: int, seed: int = 0, shift: int = 3, sigma: float = 2.0, device="cuda", chunk: int = 256):
-    """`n` frames made from ONE real frame (uint8 [H, W] or [H, W, 3], e.g. the reference's img/raw_markers.png): frame i
-    is the original moved by a seeded integer (dx, dy) in [-shift, shift]^2 (edge pixels repeated) plus seeded Gaussian
-    noise of `sigma` grey levels, rounded and clipped; frame 0 is the original itself (it defines the IDs).  Made on
-    `device` (the shifts come from a CPU generator, the noise from the device's): the real-layout workload of bench.py and
-    tests - whoever needs the bytes on the host copies them back."""
+def jittered_copies_torch(frame, n: int, seed: int = 0, shift: int = 3, sigma: float = 2.0, device="cuda", chunk: int = 256,
+                          start: int = 0, total=None):
+    """Frames `start .. start + n - 1` of a sequence of `total` (default n) frames made from ONE real frame (uint8 [H, W] or
+    [H, W, 3], e.g. the reference's img/raw_markers.png): frame i is the original moved by a seeded integer (dx, dy) in
+    [-shift, shift]^2 (edge pixels repeated) plus seeded Gaussian noise of `sigma` grey levels, rounded and clipped; frame
+    0 is the original itself (it defines the IDs).  Made on `device` (the shifts of the whole sequence come from a CPU
+    generator, the noise from the device's, seeded per block): the real-layout workload of bench.py and tests - whoever
+    needs the bytes on the host copies them back.  Returns (frames, shifts [n, 2])."""
     import torch
     base = torch.as_tensor(np.ascontiguousarray(frame), device=device)
     H, W = base.shape[:2]
+    total = n if total is None else int(total)
     g = torch.Generator(device="cpu")
     g.manual_seed(int(seed))
-    d = torch.randint(-shift, shift + 1, (n, 2), generator=g)
+    d = torch.randint(-shift, shift + 1, (total, 2), generator=g)
     d[0] = 0
+    d = d[start:start + n]
     ys = (torch.arange(H)[None, :] - d[:, 1:2]).clamp_(0, H - 1).to(device)          # source row of every output row
     xs = (torch.arange(W)[None, :] - d[:, 0:1]).clamp_(0, W - 1).to(device)
     gd = torch.Generator(device=device)
-    gd.manual_seed(int(seed) + 1)
+    gd.manual_seed(int(seed) + 1 + 7919 * int(start))
     out = torch.empty((n,) + tuple(base.shape), dtype=torch.uint8, device=device)
     for s in range(0, n, chunk):
         e = min(n, s + chunk)
         f = base[ys[s:e, :, None], xs[s:e, None, :]].to(torch.float32)             # [c, H, W(, 3)]
         if sigma > 0:
             noise = torch.randn(f.shape, generator=gd, device=device) * sigma
-            if s == 0:
+            if s == 0 and start == 0:
                 noise[0] = 0
             f = f + noise
         out[s:e] = f.round_().clamp_(0, 255).to(torch.uint8)
