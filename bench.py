@@ -662,7 +662,8 @@ def main():
         nk = min(args.roofline_frames, n_local)
         eng.profile(True)                                                    # (passes on ONE stream from here on)
         eng.track_to_3d(frames[:nk], xy, 20.0, cam, 5.0)                     # warm-up in the profiled configuration,
-        eng.profile_read()                                                   # its timings discarded
+        torch.cuda.synchronize()
+        eng.profile(True)                                                    # its records dropped (vbs_profile clears them)
         passes = max(1, -(-nk // args.batch))
         reps = max(2, -(-8 // passes))                                       # >= 8 launches of every kernel
         for _ in range(reps):
