@@ -425,26 +425,14 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
             const u64 rB = brev64(B);
             u64 Rn[SG_KB];
             const u64 claimed = seg_update<SG_KB, false, true>(B, rB, pm, sid, Rn, Q);
-            {
-                // sums of the row's pixels per slot.  One run per slot (every lane of the wave): count and positions from the
-                // run's ends; a slot that holds several runs anywhere in the wave sends the wave through the popcounts.
-                u32 cs[SG_KB], los[SG_KB];
-                bool several = false;
 #pragma unroll
-                for (int k = 0; k < SG_KB; ++k) {
-                    const u64 Rk = Rn[k];
-                    cs[k] = (u32)__popcll(Rk);
-                    los[k] = (u32)(__ffsll((long long)Rk) - 1);
-                    several |= Rk != 0ull && (u32)(64 - __clzll((long long)Rk)) - los[k] != cs[k];
-                    pm[k] = Rk;
+            for (int k = 0; k < SG_KB; ++k) {
+                const u64 Rk = Rn[k];
+                if (k < 2 || __any(Rk != 0ull)) {
+                    const u32 c = (u32)__popcll(Rk);
+                    cnt[k] += c; sy[k] += c * y; sk[k] += sum_bitpos(Rk);
                 }
-                if (!__any(several)) {
-#pragma unroll
-                    for (int k = 0; k < SG_KB; ++k) { cnt[k] += cs[k]; sy[k] += cs[k] * y; sk[k] += run_bitpos(los[k], cs[k]); }
-                } else {
-#pragma unroll
-                    for (int k = 0; k < SG_KB; ++k) { cnt[k] += cs[k]; sy[k] += cs[k] * y; sk[k] += sum_bitpos(Rn[k]); }
-                }
+                pm[k] = Rk;
             }
             u64 N = B & ~claimed;
             while (N) {                                  // runs no segment reaches: new segments
@@ -460,7 +448,7 @@ __global__ __launch_bounds__(LT_NT, 1) void k_stage_lat(const u64* __restrict__ 
                         ++nseg;
                         const u32 c = (u32)__popcll(gg);
                         pos[k] = y * (u32)W + 64u * (u32)j + (u32)(__ffsll((long long)gg) - 1);
-                        pm[k] = gg; cnt[k] = c; sy[k] = c * y; sk[k] = run_bitpos((u32)(__ffsll((long long)gg) - 1), c);   // (gg is one run)
+                        pm[k] = gg; cnt[k] = c; sy[k] = c * y; sk[k] = sum_bitpos(gg);
                         done = true;
                     }
                 }

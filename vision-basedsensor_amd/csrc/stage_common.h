@@ -160,11 +160,6 @@ __device__ __forceinline__ u32 sum_bitpos(u64 x) {
     return s;
 }
 
-// The same sum for ONE run of c bits whose lowest is bit lo (c <= 64; c = 0 gives 0): c lo + c (c - 1) / 2.  A segment's
-// pixels in a row are one run except where a blob's outline folds back (round 5: the band walk takes this form whenever
-// every slot of the wave holds at most one run - 17 instead of ~30 operations per slot and row).
-__device__ __forceinline__ u32 run_bitpos(u32 lo, u32 c) { return __umul24(c, lo) + (__umul24(c, c - 1u) >> 1); }
-
 // Segments found to belong together are only NOTED during a walk (a pair in an LDS queue, a handful of instructions where
 // it happens); the unions run densely, one pair per thread, once the walk is over.
 struct PairQ { u32* q; int* n; int cap; };
