@@ -1606,6 +1606,46 @@ def test_real_sensor_frame(golden_dir, tmp_path):
             assert Counter(df[df.frameno == 0].row.tolist()) == {0: 1, 1: 6, 2: 12, 3: 18, 4: 24, 5: 4}
 
 
+def test_real_layout_jittered_frames_against_the_oracle(golden_dir):
+    """The real-layout workload of `bench.py --workload real` (the reference's published frame moved by seeded shifts of
+    +-3 px, noise sigma 2: real texture, real dot size and pitch, coloured BGR) frame by frame against the oracle: masks,
+    band centroids (bit-exact), ellipse axes, through the batch labelling kernel and through the few-frames one; every
+    frame stays on the fast labelling path; tracking rows equal the oracle's `_track_markers` rows."""
+    from vbs_amd.marker_detection import _det_to_markers
+    bgr = np.load(os.path.join(golden_dir, "raw_markers_bgr.npz"))["bgr"]
+    n = 12
+    ft, shifts = S.jittered_copies_torch(bgr, n, seed=3, device="cuda")
+    frames = ft.cpu().numpy()
+    assert np.array_equal(frames[0], bgr) and (np.abs(shifts[1:]).max(axis=1) > 0).any()
+    h, w = bgr.shape[:2]
+    want = []
+    for f in frames:
+        om, oa = O.find_markers(f)
+        want.append((om, oa, O.marker_center(om, oa)))
+    ref = O.process_first_frame(want[0][2], 5, "full", "optimal")
+    xy = np.array([[v["Ox"], v["Oy"]] for v in ref.values()])
+    for lat in (24, 0):                                   # few-frames kernel / batch kernel
+        eng = engine(h, w, max_markers=256, max_batch=n)
+        eng.set_option(L.OPT_LATENCY_FRAMES, lat)
+        mask, area = eng.find_markers(ft)
+        table, det, counts = eng.track_to_3d(ft, xy, 20.0, want_det=True)
+        assert not eng.stage_tables(n)["slow"].any(), lat
+        mask, area, det, counts, table = mask.cpu().numpy(), area.cpu().numpy(), det.cpu().numpy(), counts.cpu().numpy(), table.cpu().numpy()
+        for i in range(n):
+            om, oa, markers = want[i]
+            assert np.array_equal(mask[i], om) and np.array_equal(area[i], oa), (lat, i)
+            assert counts[i] == len(markers), (lat, i, counts[i], len(markers))
+            compare_markers(_det_to_markers(det[i], int(counts[i])), markers)
+            rows = O.track_markers(ref, markers, i + 1, 20)
+            got = table[i]
+            assert int((got[:, 0].astype(int) & 1).sum()) == len(rows), (lat, i)
+            keys = list(ref.keys())
+            for r in rows:
+                t = got[keys.index((r["row"], r["col"]))]
+                assert abs(t[1] - r["Cx"]) < 2.5e-4 and abs(t[2] - r["Cy"]) < 2.5e-4 and abs(t[3] - r["major_axis"]) < 1e-3
+        eng.close()
+
+
 def test_bgr_frames_large_branch_fused_and_fallback():
     """a3 + a4 on coloured 1280x1024 BGR frames (large branch): dense 16-byte-aligned frames take `k_gray`'s coalesced
     path, a crop view at an odd offset its strided one; both equal the oracle, under both coefficient sets."""
