@@ -412,7 +412,8 @@ def main():
                          "configuration: 640x480 BGR frames (collecting.py:29-31) through its default crop (1/8, 1/8, 1/16, 0) "
                          "(marker_detection.py:481) = 480 wide x 450 high, small branch, 7x7 dots; --frames defaults to 16384; "
                          "real = the reference's REAL LAYOUT AND TEXTURE: its one published frame (img/raw_markers.png -> "
-                         "tests/golden/raw_markers_bgr.npz, 467x437 BGR, 65 dots of ~27 px at a pitch of 35-42 px) expanded on "
+                         "tests/golden/raw_markers_bgr.npz, 467x437 BGR, 65 dots of ~27 px at a pitch of 35-42 px; put back into the "
+                         "480x450 crop frame it was cut from by repeating its edge pixels) expanded on "
                          "the device to --frames (default 16384) frames by seeded shifts of +-3 px and noise sigma 2; the line "
                          "adds the labelling path every frame took (`slow_path_frames`, reasons) and the rate of the general "
                          "labelling kernel on the same frames")
@@ -461,6 +462,11 @@ def main():
     real_bgr = None
     if args.workload == "real":
         real_bgr = np.load(os.path.join(ROOT, "tests", "golden", "raw_markers_bgr.npz"))["bgr"]
+        # the still is a 467x437 window of the reference's 480x450 crop frame (marker_detection.py:481), 11 px from its left
+        # and 12 px from its top edge (the similarity fit of its markers to the reference's figure, tests/figure_check.py):
+        # put back into that frame by repeating its edge pixels, so that the workload has the camera's real geometry
+        real_bgr = np.pad(real_bgr, ((12, 1), (11, 2), (0, 0)), mode="edge")
+        assert real_bgr.shape == (450, 480, 3)
         spec = S.FrameSpec(int(real_bgr.shape[1]), int(real_bgr.shape[0]), np.zeros((65, 2), np.int64), 27 * 16, name="real")
         args.channels = 3
         if args.frames == 4096:
@@ -606,8 +612,9 @@ def main():
                                     f"synthetic 640x480 {fmt} frames per GPU (7x7 dots) through the default crop "
                                     f"(1/8, 1/8, 1/16, 0) = {W}x{H} strided views, small branch" if args.workload == "c1" else
                                     f"the reference's real layout and texture: {args.frames} frames per GPU made on the device from "
-                                    f"its one published frame (img/raw_markers.png, {W}x{H} BGR, 65 dots of ~27 px at a pitch of "
-                                    f"35-42 px) by seeded shifts of +-3 px and noise sigma 2; small branch") +
+                                    f"its one published frame (img/raw_markers.png, 467x437 BGR, 65 dots of ~27 px at a pitch of "
+                                    f"35-42 px, edge-padded to the {W}x{H} crop frame it was cut from) by seeded shifts of +-3 px and "
+                                    f"noise sigma 2; small branch") +
                                    f", resident in HBM; fused track->3D table + "
                                    f"{'RCCL all-gather + ' if world > 1 else ''}last-seen displacement",
                        "frames_per_gpu": args.frames, "internal_batch": args.batch, "pass_streams": args.pass_streams, "markers": M, "channels": args.channels,
