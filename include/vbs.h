@@ -105,6 +105,21 @@ int vbs_version(void);
 #define VBS_OPT_PASS_STREAMS     7
 #define VBS_OPT_LATENCY_FRAMES   8
 int vbs_set_option(vbs_handle* h, int option, int value);
+/* Motion-JPEG front end (the reference reads its AVI through cv2.VideoCapture, marker_detection.py:50-76).
+ * vbs_mjpeg_probe: headers of one JPEG frame -> info[8] = {width, height, components, luma h, luma v, restart interval,
+ * int16 coefficients per frame, plane bytes per frame}; VBS_EINVAL for a stream this decoder does not take (progressive,
+ * arithmetic, 12-bit, sampling other than 4:4:4 / 4:2:2 / 4:2:0 / gray): the caller then decodes with its own reader.
+ * vbs_mjpeg_entropy_batch: Huffman-decodes n frames (buf + offs[i], sizes[i]; all of the probed geometry) on `threads` host
+ * threads into coef [n][info[6]] (quantised blocks in natural order; HOST memory, e.g. page-locked) and qt [n][3][64];
+ * status[i] per frame; returns the number of frames that failed.  vbs_mjpeg_reconstruct: DEVICE pointers coef / qt ->
+ * BGR frames `out` (byte strides out_frame / out_row), planes = device scratch of n * info[7] bytes; dequantisation, the
+ * 8x8 "islow" inverse DCT, "fancy" chroma upsampling and the YCbCr -> RGB tables as published in libjpeg, so that the
+ * frames equal a libjpeg(-turbo) decode bit for bit; asynchronous on `stream`. */
+int vbs_mjpeg_probe(const uint8_t* jpeg, int64_t size, int32_t* info);
+int vbs_mjpeg_entropy_batch(const uint8_t* buf, const int64_t* offs, const int32_t* sizes, int n, const int32_t* info,
+                            int16_t* coef, uint16_t* qt, int32_t* status, int threads);
+int vbs_mjpeg_reconstruct(const int16_t* coef, const uint16_t* qt, int n, const int32_t* info, uint8_t* planes, uint8_t* out,
+                          int64_t out_frame, int64_t out_row, void* stream);
 /* host-only helper: the 256-entry table that classifies a border pixel's 8-neighbourhood into the
  * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain
  * direction d is foreground; 0=E,1=NE,2=N,...,7=SE). */

@@ -643,6 +643,95 @@ def test_marker_tracker_process_on_avi(tmp_path):
     b = pd.DataFrame(rows)
     assert len(a) == len(b) > 3 * 40 and list(a.columns) == list(b.columns)
     assert np.array_equal(a.to_numpy(dtype=np.float64), b.to_numpy(dtype=np.float64))
+    # the clip went through the native Motion-JPEG decoder (entropy decode on C++ threads, IDCT + colour on the device); the
+    # Pillow path gives the same file byte for byte
+    assert t1.decode_path == "device"
+    t3 = MarkerTracker({**cfg, "output_dir": str(tmp_path / "o3"), "mjpeg_on_device": False})
+    t3.process()
+    assert t3.decode_path == "pillow"
+    assert open(t1.output_csv, "rb").read() == open(t3.output_csv, "rb").read()
+
+
+def _jpeg_test_frames(h, w, n, seed, gray):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w]
+    out = []
+    for i in range(n):
+        base = 128 + 90 * np.sin(xx / (7.0 + i)) * np.cos(yy / (5.0 + 2 * i))
+        img = np.stack([base, 255 - base, 128 + 100 * np.sin((xx + yy) / 11.0)], axis=2)
+        img += rng.normal(0, 12 + 8 * i, img.shape)
+        img[h // 4:h // 2, w // 3:w // 2] = rng.integers(0, 256, 3)            # hard edges, saturated patches
+        img[:6, :9] = 255
+        img[-5:, -7:] = 0
+        img = np.clip(img, 0, 255).astype(np.uint8)
+        out.append(img[:, :, 0] if gray else img)
+    return np.stack(out)
+
+
+@pytest.mark.parametrize("sub", [0, 1, 2, "gray"])
+def test_mjpeg_device_decode_equals_libjpeg(tmp_path, sub):
+    """f4(c): the native Motion-JPEG decoder (`vbs_mjpeg_entropy_batch` on the host + `vbs_mjpeg_reconstruct` on the device)
+    against Pillow's libjpeg on the same chunks, bit for bit in every BGR byte: chroma 4:4:4 / 4:2:2 / 4:2:0 and gray,
+    qualities 35-100 (quality 100 = all-ones tables: the widest coefficient range), image sizes that are not multiples of
+    the MCU (the partial last MCU row / column, chroma upsampling at the padded edge), restart intervals, optimised
+    Huffman tables, batches that do not divide the clip.  cv2 - the reference's decoder - is the same libjpeg family with the
+    same defaults (islow IDCT, fancy upsampling)."""
+    pytest.importorskip("PIL")
+    from vbs_amd.video_io import AviReader, MjpegDeviceDecoder, write_avi
+    gray = sub == "gray"
+    cases = [(q, hw, {}) for q in (35, 75, 95, 100) for hw in ((48, 80), (61, 83), (17, 9))]
+    cases += [(75, (61, 83), o) for o in (dict(restart_marker_rows=1), dict(restart_marker_blocks=3), dict(optimize=True))]
+    cases += [(70, (480, 640), {})]
+    for q, (h, w), opts in cases:
+        fr = _jpeg_test_frames(h, w, 5, 7 * h + w + q, gray)
+        p = str(tmp_path / f"a_{q}_{h}_{len(opts)}.avi")
+        write_avi(p, fr, quality=q, subsampling=0 if gray else sub, **opts)
+        n, want = AviReader(p).read_batch(5, threads=1)
+        dec = MjpegDeviceDecoder(AviReader(p), torch.device("cuda:0"), batch=4, threads=2)
+        got, slot = [], 0
+        while dec.entropy(slot):
+            got.append(dec.reconstruct(slot).cpu().numpy().copy())
+            slot ^= 1
+        got = np.concatenate(got)
+        assert n == 5 and got.shape == want.shape and np.array_equal(got, want), (sub, q, h, w, opts)
+
+
+def test_mjpeg_device_decode_refusals_and_corrupt_frames(tmp_path):
+    """What the native decoder does not take is refused at construction (ValueError: the tracker then stays with Pillow),
+    and a frame that breaks inside a clip is an IOError naming the frame - with the rows of the batches before it kept."""
+    import io
+    from PIL import Image
+    from vbs_amd.marker_detection import MarkerTracker
+    from vbs_amd.video_io import AviReader, MjpegDeviceDecoder, write_avi
+    spec = S.config1()
+    frames = S.make_frames(spec, range(6), seed=6, channels=3)
+    prog = str(tmp_path / "prog.avi")
+    write_avi(prog, frames[:2], progressive=True)
+    with pytest.raises(ValueError):
+        MjpegDeviceDecoder(AviReader(prog), torch.device("cuda:0"), 2)
+    raw = str(tmp_path / "raw.avi")
+    write_avi(raw, frames[:2], codec="RAW")
+    with pytest.raises(ValueError):
+        MjpegDeviceDecoder(AviReader(raw), torch.device("cuda:0"), 2)
+    cfg = {"crop_ratios": (1 / 8, 1 / 8, 1 / 16, 0), "id_mode": "full", "batch": 2}
+    t = MarkerTracker({**cfg, "video_path": prog, "output_dir": str(tmp_path / "op")})
+    t.process()
+    assert t.decode_path == "pillow" and os.path.getsize(t.output_csv) > 1000
+    # frame 4 of 6 loses its header (a scan that merely ends early is padded with zero bits, as libjpeg does with a warning)
+    good = str(tmp_path / "good.avi")
+    write_avi(good, frames, quality=70)
+    b = bytearray(open(good, "rb").read())
+    rd = AviReader(good)
+    off, size = rd._frames[4]
+    b[off:off + 4] = bytes(4)
+    bad = str(tmp_path / "bad.avi")
+    open(bad, "wb").write(bytes(b))
+    t = MarkerTracker({**cfg, "video_path": bad, "output_dir": str(tmp_path / "ob")})
+    with pytest.raises(IOError, match="frame 4"):
+        t.process()
+    import pandas as pd
+    kept = pd.read_csv(t.output_csv)
+    assert sorted(kept["frameno"].unique()) == [0, 1, 2, 3]
 
 
 def test_track_markers_method_and_drop_rules():

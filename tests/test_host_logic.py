@@ -500,3 +500,52 @@ def test_status_text_names_every_per_frame_status():
     assert L.VBS_EINTERNAL == -5
     hdr = open(os.path.join(ROOT, "include", "vbs.h")).read()
     assert "#define VBS_EINTERNAL  -5" in hdr
+
+
+def test_mjpeg_entropy_decode_host_half(tmp_path):
+    """f4(c), the host half of the native Motion-JPEG decoder without a GPU: `vbs_mjpeg_probe` reads the frame geometry,
+    `vbs_mjpeg_entropy_batch` the quantised coefficients - checked by a float inverse DCT of them in NumPy against Pillow's
+    decode of the same gray frame (libjpeg's integer IDCT is within one grey level of the exact transform) - for plain,
+    restart-interval and optimised-table streams; progressive streams and garbage are refused."""
+    import ctypes as C
+    import io
+    from PIL import Image
+    from scipy.fft import idctn
+    from vbs_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(3)
+    yy, xx = np.mgrid[0:61, 0:83]
+    img = np.clip(128 + 80 * np.sin(xx / 6.0) * np.cos(yy / 9.0) + rng.normal(0, 10, (61, 83)), 0, 255).astype(np.uint8)
+    for opts in ({}, {"restart_marker_blocks": 3}, {"optimize": True}, {"quality": 100}):
+        bio = io.BytesIO()
+        Image.fromarray(img).save(bio, format="JPEG", **{"quality": 80, **opts})
+        data = bio.getvalue()
+        info = (C.c_int32 * 8)()
+        assert lib.vbs_mjpeg_probe(data, len(data), info) == 0
+        assert list(info)[:5] == [83, 61, 1, 1, 1] and info[6] == 11 * 8 * 64
+        two = data + data                                             # two frames in one buffer, two threads
+        offs = np.array([0, len(data)], dtype=np.int64)
+        sizes = np.array([len(data)] * 2, dtype=np.int32)
+        coef = np.zeros((2, info[6]), np.int16)
+        qt = np.zeros((2, 3, 64), np.uint16)
+        st = np.full(2, 99, np.int32)
+        assert lib.vbs_mjpeg_entropy_batch(two, offs.ctypes.data, sizes.ctypes.data, 2, info, coef.ctypes.data, qt.ctypes.data,
+                                           st.ctypes.data, 2) == 0
+        assert not st.any() and np.array_equal(coef[0], coef[1])
+        blocks = coef[0].reshape(8, 11, 8, 8).astype(np.float64) * qt[0, 0].reshape(8, 8)
+        pix = idctn(blocks, axes=(2, 3), norm="ortho") + 128.0
+        pix = pix.transpose(0, 2, 1, 3).reshape(64, 88)[:61, :83]
+        want = np.asarray(Image.open(io.BytesIO(data)).convert("L")).astype(np.float64)
+        assert np.abs(np.clip(pix, 0, 255) - want).max() <= 1.0, opts
+    bio = io.BytesIO()
+    Image.fromarray(img).save(bio, format="JPEG", progressive=True)
+    info = (C.c_int32 * 8)()
+    assert lib.vbs_mjpeg_probe(bio.getvalue(), len(bio.getvalue()), info) != 0
+    junk = bytes(rng.integers(0, 256, 500, dtype=np.uint8))
+    assert lib.vbs_mjpeg_probe(junk, len(junk), info) != 0
+    assert lib.vbs_mjpeg_probe(data[:40], 40, info) != 0
+    st = np.zeros(1, np.int32)
+    offs, sizes = np.zeros(1, np.int64), np.array([len(junk)], np.int32)
+    lib.vbs_mjpeg_probe(data, len(data), info)
+    assert lib.vbs_mjpeg_entropy_batch(junk, offs.ctypes.data, sizes.ctypes.data, 1, info, coef.ctypes.data, qt.ctypes.data,
+                                       st.ctypes.data, 1) == 1 and st[0] != 0

@@ -36,12 +36,47 @@ with tempfile.TemporaryDirectory() as td:
     try:
         import torch
         if torch.cuda.is_available():
+            from vbs_amd.video_io import MjpegDeviceDecoder
             from vbs_amd.marker_detection import MarkerTracker
-            for rep in range(2):
-                with contextlib.redirect_stdout(sys.stderr):
-                    trk = MarkerTracker({"video_path": path, "output_dir": os.path.join(td, f"o{rep}"),
-                                         "crop_ratios": (1 / 8, 1 / 8, 1 / 16, 0), "id_mode": "full", "batch": 64})
-                    t0 = time.perf_counter(); trk.process(); dt = time.perf_counter() - t0
-                print(f"MarkerTracker.process() on the AVI (decode ahead, default crop): {n / dt:.0f} frames/s", flush=True)
+            dev = torch.device("cuda:0")
+            for th in (1, 4, 8, 16):
+                cap = AviReader(path)
+                dec = MjpegDeviceDecoder(cap, dev, 64, th)
+                t0 = time.perf_counter(); k = 0
+                while True:
+                    m = dec.entropy(0)
+                    if not m:
+                        break
+                    k += m
+                dt = time.perf_counter() - t0
+                print(f"native entropy decode (host half), {th:2d} threads: {k / dt:.0f} frames/s", flush=True)
+            cap = AviReader(path)
+            dec = MjpegDeviceDecoder(cap, dev, 64, 16)
+            dec.entropy(0)
+            for _ in range(3):
+                dec.reconstruct(0)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                dec.reconstruct(0)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            print(f"native reconstruct (upload + IDCT + colour, device half): {20 * 64 / dt:.0f} frames/s", flush=True)
+            texts = {}
+            for on_dev in (False, True):
+                for batch in (64, 256):
+                    for rep in range(2):
+                        out = os.path.join(td, f"o{int(on_dev)}_{batch}_{rep}")
+                        with contextlib.redirect_stdout(sys.stderr):
+                            trk = MarkerTracker({"video_path": path, "output_dir": out, "mjpeg_on_device": on_dev,
+                                                 "crop_ratios": (1 / 8, 1 / 8, 1 / 16, 0), "id_mode": "full", "batch": batch})
+                            t0 = time.perf_counter(); trk.process(); dt = time.perf_counter() - t0
+                    texts[(on_dev, batch)] = open(trk.output_csv, "rb").read()
+                    print(f"MarkerTracker.process() on the AVI, decode path {trk.decode_path}, batch {batch}: {n / dt:.0f} frames/s",
+                          flush=True)
+            same = len(set(texts.values())) == 1
+            print("CSV files of the two decode paths and both batch sizes identical:", same, flush=True)
+            if not same:
+                sys.exit(1)
     except ImportError:
         pass

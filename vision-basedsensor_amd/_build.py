@@ -6,7 +6,7 @@ from concurrent.futures import ThreadPoolExecutor
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 LIB = os.path.join(CSRC, "libvbs.so")
-SOURCES = ("api.hip", "k_blur.hip", "k_ncc.hip", "k_label.hip", "k_ccl.hip", "k_stage.hip", "k_stage_lat.hip", "k_solve.hip", "k_undistort.hip", "k_ids.hip", "host_csv.hip")
+SOURCES = ("api.hip", "k_blur.hip", "k_ncc.hip", "k_label.hip", "k_ccl.hip", "k_stage.hip", "k_stage_lat.hip", "k_solve.hip", "k_undistort.hip", "k_ids.hip", "host_csv.hip", "host_mjpeg.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
 # k_ncc.hip: no SLP pairings (they cost registers, 127 -> 108, and instructions) and no packed float32 instructions at all:

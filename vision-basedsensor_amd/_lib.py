@@ -16,7 +16,8 @@ SYMBOLS = ("vbs_create", "vbs_destroy", "vbs_last_error", "vbs_version", "vbs_co
            "vbs_profile", "vbs_profile_read", "vbs_frame_stats", "vbs_undistort_points", "vbs_calculate_3d", "vbs_marker_center",
            "vbs_track", "vbs_solve3d", "vbs_track_to_3d", "vbs_displacement", "vbs_displacement_range", "vbs_displacement_f64",
            "vbs_plane_fit", "vbs_assign_ids", "vbs_set_option", "vbs_bgr2gray", "vbs_ncc_counters", "vbs_normxcorr2_general",
-           "vbs_stage_tables", "vbs_deviation_plane", "vbs_format_csv")
+           "vbs_stage_tables", "vbs_deviation_plane", "vbs_format_csv", "vbs_mjpeg_probe", "vbs_mjpeg_entropy_batch",
+           "vbs_mjpeg_reconstruct")
 
 
 class Camera(C.Structure):
@@ -88,6 +89,9 @@ def lib():
         "vbs_stage_tables": (i32, [vp, i32, vp, vp, vp, vp, vp, vp]),
         "vbs_deviation_plane": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, vp, vp]),
         "vbs_format_csv": (i64, [vp, vp, vp, vp, i32, i64, vp, i64, i32]),
+        "vbs_mjpeg_probe": (i32, [vp, i64, vp]),
+        "vbs_mjpeg_entropy_batch": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32]),
+        "vbs_mjpeg_reconstruct": (i32, [vp, vp, i32, vp, vp, vp, i64, i64, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)            # AttributeError here = stale library

@@ -360,25 +360,45 @@ class MarkerTracker:
         self._cleanup()
 
     def _process_decoding_ahead(self, batch):
-        """`process` on the package's own AVI reader (no OpenCV): batch k + 1 is decoded by the reader's thread pool into
-        the other of two page-locked buffers while batch k is uploaded, computed and turned into rows."""
+        """`process` on the package's own AVI reader (no OpenCV): batch k + 1 is decoded while batch k is computed and
+        turned into rows.  A Motion-JPEG clip of the variant the native decoder takes (`video_io.MjpegDeviceDecoder`:
+        baseline Huffman, 4:4:4 / 4:2:2 / 4:2:0 or gray) is entropy-decoded by C++ threads and reconstructed on the device
+        (`config["mjpeg_on_device"]`, default on; `self.decode_path` says which ran); anything else goes through the
+        reader's Pillow thread pool into one of two page-locked buffers."""
         from concurrent.futures import ThreadPoolExecutor
-        shape = (batch, self.height, self.width, 3)
-        try:
-            bufs = [pinned_frames(shape), pinned_frames(shape)]
-        except Exception:                                   # (no GPU runtime to pin with: ordinary memory)
-            bufs = [np.empty(shape, np.uint8), np.empty(shape, np.uint8)]
+        dec = None
+        if self.config.get("mjpeg_on_device", True) and getattr(self.cap, "_codec", b"").upper() == b"MJPG":
+            try:
+                import torch
+                from .video_io import MjpegDeviceDecoder
+                dev = torch.device(self.config.get("device") or "cuda:0")
+                if dev.type == "cuda":
+                    dec = MjpegDeviceDecoder(self.cap, dev, batch, self.config.get("decode_threads"))
+            except ValueError:                              # a JPEG variant outside the native decoder: Pillow
+                dec = None
+        self.decode_path = "device" if dec is not None else "pillow"
+        if dec is not None:
+            def ahead_of(slot): return dec.entropy(slot)
+            def frames_of(slot, m): return dec.reconstruct(slot)
+        else:
+            shape = (batch, self.height, self.width, 3)
+            try:
+                bufs = [pinned_frames(shape), pinned_frames(shape)]
+            except Exception:                               # (no GPU runtime to pin with: ordinary memory)
+                bufs = [np.empty(shape, np.uint8), np.empty(shape, np.uint8)]
+            def ahead_of(slot): return self.cap.read_batch(batch, bufs[slot])
+            def frames_of(slot, m): return bufs[slot][:m]
         data, k = [], 0
         with ThreadPoolExecutor(1) as ahead:
-            fut = ahead.submit(self.cap.read_batch, batch, bufs[0])
+            fut = ahead.submit(ahead_of, 0)
             while True:
                 try:
                     m = fut.result()                       # (a decode error - a corrupt frame - surfaces here)
                     fut = None
                     if not m:
                         break
-                    fut = ahead.submit(self.cap.read_batch, batch, bufs[(k + 1) & 1])
-                    data.append(self._process_batch(bufs[k & 1][:m]))
+                    fut = ahead.submit(ahead_of, (k + 1) & 1)
+                    data.append(self._process_batch(frames_of(k & 1, m)))
                 except Exception:
                     # the rows of the batches before the failing frame are kept, whichever side failed; the reader is
                     # released only once the decode running ahead has finished with its buffers (a running task cannot be

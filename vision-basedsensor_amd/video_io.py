@@ -185,8 +185,97 @@ class AviReader:
         self._ok = False
 
 
-def write_avi(path: str, frames: np.ndarray, fps: float = 30.0, codec: str = "MJPG", quality: int = 95):
-    """frames uint8 [N,H,W,3] BGR or [N,H,W] gray -> AVI with one 'movi' list and an 'idx1' index."""
+class MjpegDeviceDecoder:
+    """Native Motion-JPEG front end for an `AviReader` (csrc/host_mjpeg.hip): the Huffman entropy decode of a batch runs
+    on C++ threads (no GIL, no Python per frame) into page-locked int16 coefficients; de-quantisation, libjpeg's `islow`
+    inverse DCT, its "fancy" chroma upsampling and its fixed-point YCbCr -> RGB tables run as HIP kernels, so the pixels
+    are born in HBM and only ~1.0-1.5 bytes per pixel cross PCIe (int16 coefficients of the 4:2:0 / 4:2:2 planes).  The BGR
+    frames equal Pillow's / cv2's (libjpeg, default settings) bit for bit - tests/test_gpu_parity.py.
+
+    Baseline sequential 8-bit JPEG with 1 (gray) or 3 components, luma sampling 1x1 / 2x1 / 2x2, chroma 1x1, Huffman tables
+    in every frame: what cameras' MJPG streams, `cv2.VideoWriter('MJPG')` and Pillow write.  Anything else (progressive,
+    arithmetic coding, 12 bit, CMYK, missing DHT): `ValueError` at construction, and the caller stays with Pillow.
+
+    Two slots of host / device buffers, so that `entropy(slot)` of batch k + 1 can run on a helper thread while
+    `reconstruct(slot)` and the tracker work on batch k."""
+
+    def __init__(self, reader: "AviReader", device, batch: int, threads: int | None = None):
+        import ctypes as C
+        import os
+
+        import torch
+
+        from . import _lib as L
+        if not reader.isOpened() or reader._codec.upper() != b"MJPG":
+            raise ValueError("not a Motion-JPEG clip")
+        self._lib = L.lib()
+        self._reader = reader
+        self._base = reader._buf.obj                                   # the bytes object behind the memoryview
+        off, size = reader._frames[reader._next if reader._next < len(reader._frames) else 0]
+        self._info = (C.c_int32 * 8)()
+        first = (C.c_char * size).from_buffer_copy(reader._buf[off:off + size])
+        if self._lib.vbs_mjpeg_probe(first, size, self._info) != 0:
+            raise ValueError("JPEG variant outside the native decoder (baseline Huffman, 1 or 3 components, 4:4:4 / 4:2:2 / 4:2:0)")
+        if self._info[0] != reader.width or self._info[1] != reader.height:
+            raise ValueError("JPEG geometry differs from the AVI header")
+        self.batch = int(batch)
+        self.device = torch.device(device)
+        self.width, self.height = int(self._info[0]), int(self._info[1])
+        self._per, self._pl = int(self._info[6]), int(self._info[7])
+        self.threads = max(1, threads or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
+        pin = self.device.type == "cuda"
+        self._coef = [torch.empty((self.batch, self._per), dtype=torch.int16, pin_memory=pin) for _ in range(2)]
+        self._qt = [torch.empty((self.batch, 3, 64), dtype=torch.int16, pin_memory=pin) for _ in range(2)]
+        self._status = [np.zeros(self.batch, dtype=np.int32) for _ in range(2)]
+        self._count = [0, 0]
+        self._dcoef = torch.empty((self.batch, self._per), dtype=torch.int16, device=self.device)
+        self._dqt = torch.empty((self.batch, 3, 64), dtype=torch.int16, device=self.device)
+        self._planes = torch.empty((self.batch, self._pl), dtype=torch.uint8, device=self.device)
+        self._out = [torch.empty((self.batch, self.height, self.width, 3), dtype=torch.uint8, device=self.device) for _ in range(2)]
+
+    def entropy(self, slot: int, n: int | None = None) -> int:
+        """Host half for the reader's next up to `n` (default: batch) frames into `slot`.  Returns the count (0 at the end).
+        Safe on a helper thread: ctypes drops the GIL for the call and the C side starts its own threads."""
+        import ctypes as C
+        r = self._reader
+        m = max(0, min(self.batch if n is None else min(int(n), self.batch), len(r._frames) - r._next)) if r._ok else 0
+        self._count[slot] = m
+        if not m:
+            return 0
+        fr = r._frames[r._next:r._next + m]
+        r._next += m
+        offs = np.asarray([f[0] for f in fr], dtype=np.int64)
+        sizes = np.asarray([f[1] for f in fr], dtype=np.int32)
+        st = self._status[slot]
+        bad = self._lib.vbs_mjpeg_entropy_batch(self._base, offs.ctypes.data, sizes.ctypes.data, m, self._info,
+                                                self._coef[slot].data_ptr(), self._qt[slot].data_ptr(), st.ctypes.data, self.threads)
+        if bad:
+            i = int(np.flatnonzero(st[:m])[0])
+            raise IOError(f"Motion-JPEG frame {r._next - m + i}: corrupt or not of the clip's JPEG variant (status {int(st[i])})")
+        return m
+
+    def reconstruct(self, slot: int):
+        """Device half of what `entropy(slot)` left: -> uint8 [m, H, W, 3] BGR on the device (a view of the slot's buffer,
+        valid until the slot's next `reconstruct`), asynchronous on torch's current stream."""
+        import torch
+        m = self._count[slot]
+        out = self._out[slot]
+        if not m:
+            return out[:0]
+        self._dcoef[:m].copy_(self._coef[slot][:m], non_blocking=True)
+        self._dqt[:m].copy_(self._qt[slot][:m], non_blocking=True)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
+        rc = self._lib.vbs_mjpeg_reconstruct(self._dcoef.data_ptr(), self._dqt.data_ptr(), m, self._info, self._planes.data_ptr(),
+                                             out.data_ptr(), out.stride(0), out.stride(1), stream)
+        if rc != 0:
+            raise RuntimeError(f"vbs_mjpeg_reconstruct failed ({rc})")
+        return out[:m]
+
+
+def write_avi(path: str, frames: np.ndarray, fps: float = 30.0, codec: str = "MJPG", quality: int = 95, subsampling: int = 2,
+              **jpeg_options):
+    """frames uint8 [N,H,W,3] BGR or [N,H,W] gray -> AVI with one 'movi' list and an 'idx1' index.  `subsampling` (0 = 4:4:4,
+    1 = 4:2:2, 2 = 4:2:0) and further Pillow JPEG options (`restart_marker_rows`, `optimize` ...) apply to MJPG."""
     frames = np.asarray(frames)
     if frames.dtype != np.uint8 or frames.ndim not in (3, 4):
         raise ValueError("frames must be uint8 [N,H,W] or [N,H,W,3]")
@@ -198,7 +287,7 @@ def write_avi(path: str, frames: np.ndarray, fps: float = 30.0, codec: str = "MJ
         for fr in frames:
             im = Image.fromarray(fr if gray else np.ascontiguousarray(fr[:, :, ::-1]))
             bio = io.BytesIO()
-            im.save(bio, format="JPEG", quality=quality, subsampling=0 if gray else 2)
+            im.save(bio, format="JPEG", quality=quality, subsampling=0 if gray else subsampling, **jpeg_options)
             payloads.append(bio.getvalue())
         fourcc, bits = b"MJPG", 24
     else:
