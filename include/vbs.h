@@ -110,16 +110,22 @@ int vbs_set_option(vbs_handle* h, int option, int value);
  * int16 coefficients per frame, plane bytes per frame}; VBS_EINVAL for a stream this decoder does not take (progressive,
  * arithmetic, 12-bit, sampling other than 4:4:4 / 4:2:2 / 4:2:0 / gray): the caller then decodes with its own reader.
  * vbs_mjpeg_entropy_batch: Huffman-decodes n frames (buf + offs[i], sizes[i]; all of the probed geometry) on `threads` host
- * threads into coef [n][info[6]] (quantised blocks in natural order; HOST memory, e.g. page-locked) and qt [n][3][64];
- * status[i] per frame; returns the number of frames that failed.  vbs_mjpeg_reconstruct: DEVICE pointers coef / qt ->
+ * threads into the compact form the device half reads (HOST memory, e.g. page-locked): tab [n][info[6] / 64] one word per 8x8
+ * block (component after component, row-major over the padded block grid) = (first word of the block in ent, relative to the
+ * frame's) << 7 | count; count <= 32 entry words (natural-order position << 16 | quantised value as uint16), or 127 = a dense
+ * block of 64 int16; ent holds n * info[6] / 2 words, thread t packs its frames from word (its first frame) * info[6] / 2 on
+ * and reports (first word, words used) in regions[2 t], regions[2 t + 1] (2 * threads int64): only those spans, tab,
+ * frame_base [n] (a frame's first word) and qt [n][3][64] need to reach the device - typically a tenth of the pixels' bytes.
+ * status[i] per frame; returns the number of frames that failed.  vbs_mjpeg_reconstruct: DEVICE copies of those arrays ->
  * BGR frames `out` (byte strides out_frame / out_row), planes = device scratch of n * info[7] bytes; dequantisation, the
  * 8x8 "islow" inverse DCT, "fancy" chroma upsampling and the YCbCr -> RGB tables as published in libjpeg, so that the
  * frames equal a libjpeg(-turbo) decode bit for bit; asynchronous on `stream`. */
 int vbs_mjpeg_probe(const uint8_t* jpeg, int64_t size, int32_t* info);
 int vbs_mjpeg_entropy_batch(const uint8_t* buf, const int64_t* offs, const int32_t* sizes, int n, const int32_t* info,
-                            int16_t* coef, uint16_t* qt, int32_t* status, int threads);
-int vbs_mjpeg_reconstruct(const int16_t* coef, const uint16_t* qt, int n, const int32_t* info, uint8_t* planes, uint8_t* out,
-                          int64_t out_frame, int64_t out_row, void* stream);
+                            uint32_t* ent, uint32_t* tab, int64_t* frame_base, int64_t* regions, uint16_t* qt, int32_t* status,
+                            int threads);
+int vbs_mjpeg_reconstruct(const uint32_t* ent, const uint32_t* tab, const int64_t* frame_base, const uint16_t* qt, int n,
+                          const int32_t* info, uint8_t* planes, uint8_t* out, int64_t out_frame, int64_t out_row, void* stream);
 /* host-only helper: the 256-entry table that classifies a border pixel's 8-neighbourhood into the
  * number of CHAIN_APPROX_SIMPLE vertices it contributes (bit d of the index = neighbour in chain
  * direction d is foreground; 0=E,1=NE,2=N,...,7=SE). */

@@ -526,12 +526,31 @@ def test_mjpeg_entropy_decode_host_half(tmp_path):
         two = data + data                                             # two frames in one buffer, two threads
         offs = np.array([0, len(data)], dtype=np.int64)
         sizes = np.array([len(data)] * 2, dtype=np.int32)
-        coef = np.zeros((2, info[6]), np.int16)
+        nblk, cap = info[6] // 64, info[6] // 2
+        ent = np.zeros(2 * cap, np.uint32)
+        tab = np.zeros((2, nblk), np.uint32)
+        fb = np.zeros(2, np.int64)
+        reg = np.zeros(4, np.int64)
         qt = np.zeros((2, 3, 64), np.uint16)
         st = np.full(2, 99, np.int32)
-        assert lib.vbs_mjpeg_entropy_batch(two, offs.ctypes.data, sizes.ctypes.data, 2, info, coef.ctypes.data, qt.ctypes.data,
-                                           st.ctypes.data, 2) == 0
-        assert not st.any() and np.array_equal(coef[0], coef[1])
+        assert lib.vbs_mjpeg_entropy_batch(two, offs.ctypes.data, sizes.ctypes.data, 2, info, ent.ctypes.data, tab.ctypes.data,
+                                           fb.ctypes.data, reg.ctypes.data, qt.ctypes.data, st.ctypes.data, 2) == 0
+        assert not st.any() and list(fb) == [0, cap] and list(reg[::2]) == [0, cap] and 0 < reg[1] == reg[3] <= cap
+        coef = np.zeros((2, nblk, 64), np.int16)                      # the compact form, expanded as the device kernel does
+        dense_blocks = 0
+        for i in range(2):
+            for b in range(nblk):
+                start, cnt = int(fb[i]) + (int(tab[i, b]) >> 7), int(tab[i, b]) & 127
+                if cnt == 127:
+                    coef[i, b] = ent[start:start + 32].view(np.int16)
+                    dense_blocks += 1
+                else:
+                    assert cnt <= 32
+                    e = ent[start:start + cnt]
+                    assert len(set((e >> 16).tolist())) == cnt and ((e & 0xFFFF) != 0).all()
+                    coef[i, b, (e >> 16).astype(np.int64)] = (e & 0xFFFF).astype(np.uint16).view(np.int16)
+        assert np.array_equal(coef[0], coef[1]) and (dense_blocks > 0) == (opts.get("quality") == 100)
+        coef = coef.reshape(2, -1)
         blocks = coef[0].reshape(8, 11, 8, 8).astype(np.float64) * qt[0, 0].reshape(8, 8)
         pix = idctn(blocks, axes=(2, 3), norm="ortho") + 128.0
         pix = pix.transpose(0, 2, 1, 3).reshape(64, 88)[:61, :83]
@@ -547,5 +566,5 @@ def test_mjpeg_entropy_decode_host_half(tmp_path):
     st = np.zeros(1, np.int32)
     offs, sizes = np.zeros(1, np.int64), np.array([len(junk)], np.int32)
     lib.vbs_mjpeg_probe(data, len(data), info)
-    assert lib.vbs_mjpeg_entropy_batch(junk, offs.ctypes.data, sizes.ctypes.data, 1, info, coef.ctypes.data, qt.ctypes.data,
-                                       st.ctypes.data, 1) == 1 and st[0] != 0
+    assert lib.vbs_mjpeg_entropy_batch(junk, offs.ctypes.data, sizes.ctypes.data, 1, info, ent.ctypes.data, tab.ctypes.data,
+                                       fb.ctypes.data, reg.ctypes.data, qt.ctypes.data, st.ctypes.data, 1) == 1 and st[0] != 0

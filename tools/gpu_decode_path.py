@@ -61,7 +61,8 @@ with tempfile.TemporaryDirectory() as td:
                 dec.reconstruct(0)
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
-            print(f"native reconstruct (upload + IDCT + colour, device half): {20 * 64 / dt:.0f} frames/s", flush=True)
+            print(f"native reconstruct (upload + IDCT + colour, device half): {20 * 64 / dt:.0f} frames/s; "
+                  f"{dec.uploaded_bytes / (23 * 64) / 1024:.1f} KiB per frame uploaded ({640 * 480 * 3 / 1024:.0f} KiB of pixels)", flush=True)
             texts = {}
             for on_dev in (False, True):
                 for batch in (64, 256):

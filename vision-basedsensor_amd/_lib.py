@@ -90,8 +90,8 @@ def lib():
         "vbs_deviation_plane": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, f64, vp, vp, vp]),
         "vbs_format_csv": (i64, [vp, vp, vp, vp, i32, i64, vp, i64, i32]),
         "vbs_mjpeg_probe": (i32, [vp, i64, vp]),
-        "vbs_mjpeg_entropy_batch": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, i32]),
-        "vbs_mjpeg_reconstruct": (i32, [vp, vp, i32, vp, vp, vp, i64, i64, vp]),
+        "vbs_mjpeg_entropy_batch": (i32, [vp, vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, i32]),
+        "vbs_mjpeg_reconstruct": (i32, [vp, vp, vp, vp, i32, vp, vp, vp, i64, i64, vp]),
     }
     for name in SYMBOLS:
         fn = getattr(L, name)            # AttributeError here = stale library

@@ -195,9 +195,12 @@ inline int decode_sym(Bits& b, const Huff& t) {
 
 inline int extend(int v, int s) { return v < (1 << (s - 1)) ? v - (1 << s) + 1 : v; }
 
-// one frame's scan -> coefficient blocks in NATURAL order (quantised), component after component, blocks row-major over the
-// component's padded block grid
-int entropy(const Frame& f, int16_t* coef) {
+// One frame's scan -> its blocks in the COMPACT form the device half reads.  Per block (numbered component after component,
+// row-major over the component's padded block grid) one word in tab: (first word of the block in `ent`, relative to the
+// frame's first) << 7 | count.  count <= 32: that many entry words (natural-order position << 16 | quantised value as uint16);
+// count == 127: the block is dense, 64 int16 in natural order = 32 words.  A block never takes more than 32 words, so a frame
+// never takes more than half of info[6] words, whatever its content.
+int entropy(const Frame& f, uint32_t* ent, uint32_t* tab, int64_t* used) {
     const int hmax = f.hs[0], vmax = f.vs[0];
     const int mcux = (f.w + 8 * hmax - 1) / (8 * hmax), mcuy = (f.h + 8 * vmax - 1) / (8 * vmax);
     int bw[3], bh[3];
@@ -205,12 +208,13 @@ int entropy(const Frame& f, int16_t* coef) {
     for (int c = 0; c < f.ncomp; ++c) {
         bw[c] = mcux * f.hs[c]; bh[c] = mcuy * f.vs[c];
         base[c] = off;
-        off += (int64_t)bw[c] * bh[c] * 64;
+        off += (int64_t)bw[c] * bh[c];
     }
-    memset(coef, 0, (size_t)off * sizeof(int16_t));
     Bits b{f.scan, f.end};
     int pred[3] = {0, 0, 0};
     int todo = f.restart;
+    uint32_t at_word = 0;
+    uint32_t e[64];
     for (int my = 0; my < mcuy; ++my)
         for (int mx = 0; mx < mcux; ++mx) {
             if (f.restart && todo == 0) {                // expect RSTn: byte-align, skip the marker, reset
@@ -226,13 +230,14 @@ int entropy(const Frame& f, int16_t* coef) {
             for (int c = 0; c < f.ncomp; ++c)
                 for (int v = 0; v < f.vs[c]; ++v)
                     for (int hh = 0; hh < f.hs[c]; ++hh) {
-                        int16_t* blk = coef + base[c] + ((int64_t)(my * f.vs[c] + v) * bw[c] + mx * f.hs[c] + hh) * 64;
+                        const int64_t blk = base[c] + (int64_t)(my * f.vs[c] + v) * bw[c] + mx * f.hs[c] + hh;
+                        int cnt = 0;
                         int s = decode_sym(b, f.dc[f.td[c]]);
                         if (s < 0 || s > 11) return VBS_EINVAL;
                         if (b.cnt < 16) b.fill();
                         const int diff = s ? extend(b.get(s), s) : 0;
                         pred[c] += diff;
-                        blk[0] = (int16_t)pred[c];
+                        if (pred[c]) e[cnt++] = (uint32_t)(uint16_t)(int16_t)pred[c];
                         const Huff& at = f.ac[f.ta[c]];
                         for (int k = 1; k < 64;) {
                             const int rs = decode_sym(b, at);
@@ -245,12 +250,27 @@ int entropy(const Frame& f, int16_t* coef) {
                             k += r;
                             if (k > 63) return VBS_EINVAL;
                             if (b.cnt < 16) b.fill();
-                            blk[ZIGZAG[k]] = (int16_t)extend(b.get(sz), sz);
+                            const int val = extend(b.get(sz), sz);
+                            if (val) e[cnt++] = (uint32_t)ZIGZAG[k] << 16 | (uint32_t)(uint16_t)(int16_t)val;
                             ++k;
+                        }
+                        uint32_t* dst = ent + at_word;
+                        if (cnt <= 32) {
+                            for (int i = 0; i < cnt; ++i) dst[i] = e[i];
+                            tab[blk] = at_word << 7 | (uint32_t)cnt;
+                            at_word += cnt;
+                        } else {
+                            int16_t d[64];
+                            memset(d, 0, sizeof d);
+                            for (int i = 0; i < cnt; ++i) d[e[i] >> 16] = (int16_t)(uint16_t)(e[i] & 0xFFFF);
+                            memcpy(dst, d, sizeof d);
+                            tab[blk] = at_word << 7 | 127u;
+                            at_word += 32;
                         }
                     }
             if (f.restart) --todo;
         }
+    *used = at_word;
     return VBS_OK;
 }
 
@@ -298,26 +318,51 @@ __device__ __forceinline__ void idct8(const int (&in)[8], int (&out)[8], int shi
 }
 
 // One workgroup = 32 blocks of one component of one frame: 256 threads, thread = (block, column) in pass 1, (block, row) in
-// pass 2.  plane: [n][ph][pw] u8 (padded to whole blocks).
-__global__ __launch_bounds__(256) void k_jpeg_idct(const int16_t* __restrict__ coef, const unsigned short* __restrict__ qt,
-                                                  unsigned char* __restrict__ plane, int64_t coef_frame, int64_t coef_base, int qt_frame,
-                                                  int qt_index, int nblocks, int bw, int64_t plane_frame, int pw) {
+// pass 2.  The block's words (see `entropy`) are scattered, de-quantised, into LDS first.  plane: [n][ph][pw] u8 (whole blocks).
+__global__ __launch_bounds__(256) void k_jpeg_idct(const uint32_t* __restrict__ ent, const uint32_t* __restrict__ tab,
+                                                  const int64_t* __restrict__ frame_base, const unsigned short* __restrict__ qt,
+                                                  unsigned char* __restrict__ plane, int tab_frame, int tab_base, int qt_index,
+                                                  int nblocks, int bw, int64_t plane_frame, int pw) {
+    __shared__ int cf[32][65];
     __shared__ int ws[32][8][9];
     const int n = blockIdx.y;
     const int lb = threadIdx.x >> 3, k = threadIdx.x & 7;
     const int b = blockIdx.x * 32 + lb;
-    const unsigned short* q = qt + (int64_t)n * qt_frame + qt_index * 64;
-    if (b < nblocks) {
-        const int16_t* c = coef + (int64_t)n * coef_frame + coef_base + (int64_t)b * 64;
+    const unsigned short* q = qt + (int64_t)n * (3 * 64) + qt_index * 64;
+    const bool live = b < nblocks;
+    uint32_t word = 0;
+    if (live) word = tab[(int64_t)n * tab_frame + tab_base + b];
+    const uint32_t* src = ent + frame_base[n] + (word >> 7);
+    const int cnt = (int)(word & 127u);
+    if (live && cnt != 127) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) cf[lb][8 * r + k] = 0;
+    }
+    __syncthreads();
+    if (live) {
+        if (cnt == 127) {
+            const short* d = reinterpret_cast<const short*>(src);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) cf[lb][8 * r + k] = (int)d[8 * r + k] * (int)q[8 * r + k];
+        } else {
+            for (int j = k; j < cnt; j += 8) {
+                const uint32_t e = src[j];
+                const int pos = (int)(e >> 16) & 63;
+                cf[lb][pos] = (int)(short)(e & 0xFFFFu) * (int)q[pos];
+            }
+        }
+    }
+    __syncthreads();
+    if (live) {
         int in[8], out[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) in[r] = (int)c[8 * r + k] * (int)q[8 * r + k];
+        for (int r = 0; r < 8; ++r) in[r] = cf[lb][8 * r + k];
         idct8(in, out, 13 - 2);                          // columns: CONST_BITS - PASS1_BITS
 #pragma unroll
         for (int r = 0; r < 8; ++r) ws[lb][r][k] = out[r];
     }
     __syncthreads();
-    if (b < nblocks) {
+    if (live) {
         int in[8], out[8];
 #pragma unroll
         for (int cidx = 0; cidx < 8; ++cidx) in[cidx] = ws[lb][k][cidx];
@@ -397,35 +442,48 @@ extern "C" int vbs_mjpeg_probe(const uint8_t* jpeg, int64_t size, int32_t* info)
         coefs += blocks * 64;
         planes += blocks * 64;
     }
+    if (coefs / 2 >= ((int64_t)1 << 25)) return VBS_EINVAL;             // (a block's first word has 25 bits in its table word)
     info[0] = f.w; info[1] = f.h; info[2] = f.ncomp; info[3] = f.hs[0]; info[4] = f.vs[0]; info[5] = f.restart;
     info[6] = (int32_t)coefs; info[7] = (int32_t)planes;
     return VBS_OK;
 }
 
-// Entropy-decodes n frames (buf + offs[i], sizes[i]) on `threads` C++ threads into coef [n][info[6]] int16 and their
-// quantisation tables into qt [n][3][64] uint16 (natural order).  Every frame must have the geometry of `info` (vbs_mjpeg_probe
-// of the first); status[i] = VBS_OK or VBS_EINVAL per frame.  Returns the number of frames that failed.
+// Entropy-decodes n frames (buf + offs[i], sizes[i]) on `threads` C++ threads.  Every frame must have the geometry of `info`
+// (vbs_mjpeg_probe of the first).  ent: n * info[6] / 2 words; thread t packs its frames one after the other from word
+// (first frame of t) * info[6] / 2 on, and reports (first word, words used) in regions[2 t], regions[2 t + 1] - only those
+// spans need to reach the device.  tab [n][info[6] / 64], frame_base [n] (word index of a frame's first word in ent),
+// qt [n][3][64] (natural order), status[i] = VBS_OK or VBS_EINVAL.  Returns the number of frames that failed.
 extern "C" int vbs_mjpeg_entropy_batch(const uint8_t* buf, const int64_t* offs, const int32_t* sizes, int n, const int32_t* info,
-                                       int16_t* coef, uint16_t* qt, int32_t* status, int threads) {
-    if (!buf || !offs || !sizes || !info || !coef || !qt || !status || n < 0) return VBS_EINVAL;
-    const int64_t per = info[6];
-    auto work = [&](int t0, int t1) {
+                                       uint32_t* ent, uint32_t* tab, int64_t* frame_base, int64_t* regions, uint16_t* qt,
+                                       int32_t* status, int threads) {
+    if (!buf || !offs || !sizes || !info || !ent || !tab || !frame_base || !regions || !qt || !status || n < 0 || threads < 1)
+        return VBS_EINVAL;
+    const int64_t cap = info[6] / 2, nblk = info[6] / 64;
+    for (int t = 0; t < threads; ++t) regions[2 * t] = regions[2 * t + 1] = 0;
+    auto work = [&](int t, int t0, int t1) {
+        int64_t at = (int64_t)t0 * cap;
+        regions[2 * t] = at;
         for (int i = t0; i < t1; ++i) {
             Frame f;
             int rc = parse(buf + offs[i], sizes[i], &f);
             if (rc == VBS_OK && (f.w != info[0] || f.h != info[1] || f.ncomp != info[2] || f.hs[0] != info[3] || f.vs[0] != info[4]))
                 rc = VBS_EINVAL;
-            if (rc == VBS_OK) rc = entropy(f, coef + (int64_t)i * per);
-            if (rc == VBS_OK)
+            int64_t used = 0;
+            frame_base[i] = at;
+            if (rc == VBS_OK) rc = entropy(f, ent + at, tab + (int64_t)i * nblk, &used);
+            if (rc == VBS_OK) {
+                at += used;
                 for (int c = 0; c < 3; ++c) memcpy(qt + ((int64_t)i * 3 + c) * 64, f.qt[f.tq[c < f.ncomp ? c : 0]], 128);
+            }
             status[i] = rc;
         }
+        regions[2 * t + 1] = at - regions[2 * t];
     };
     const int nt = std::max(1, std::min(threads, n));
-    if (nt <= 1) work(0, n);
+    if (nt <= 1) work(0, 0, n);
     else {
         std::vector<std::thread> th;
-        for (int t = 0; t < nt; ++t) th.emplace_back(work, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));
+        for (int t = 0; t < nt; ++t) th.emplace_back(work, t, (int)((int64_t)n * t / nt), (int)((int64_t)n * (t + 1) / nt));
         for (auto& x : th) x.join();
     }
     int bad = 0;
@@ -433,26 +491,28 @@ extern "C" int vbs_mjpeg_entropy_batch(const uint8_t* buf, const int64_t* offs, 
     return bad;
 }
 
-// Device half: coef [n][info[6]] int16 and qt [n][3][64] uint16 (device pointers) -> BGR frames out [n] (out_frame / out_row
-// strides in bytes, 3 bytes per pixel); planes = scratch of n * info[7] bytes.  Asynchronous on `stream`.
-extern "C" int vbs_mjpeg_reconstruct(const int16_t* coef, const uint16_t* qt, int n, const int32_t* info, uint8_t* planes,
-                                     uint8_t* out, int64_t out_frame, int64_t out_row, void* stream) {
-    if (!coef || !qt || !info || !planes || !out || n < 0) return VBS_EINVAL;
+// Device half: ent / tab / frame_base / qt as vbs_mjpeg_entropy_batch left them (DEVICE copies) -> BGR frames out [n] (out_frame
+// / out_row strides in bytes, 3 bytes per pixel); planes = scratch of n * info[7] bytes.  Asynchronous on `stream`.
+extern "C" int vbs_mjpeg_reconstruct(const uint32_t* ent, const uint32_t* tab, const int64_t* frame_base, const uint16_t* qt, int n,
+                                     const int32_t* info, uint8_t* planes, uint8_t* out, int64_t out_frame, int64_t out_row,
+                                     void* stream) {
+    if (!ent || !tab || !frame_base || !qt || !info || !planes || !out || n < 0) return VBS_EINVAL;
     if (n == 0) return VBS_OK;
     hipStream_t s = (hipStream_t)stream;
     const int W = info[0], H = info[1], nc = info[2], hs = info[3], vs = info[4];
     const int mcux = (W + 8 * hs - 1) / (8 * hs), mcuy = (H + 8 * vs - 1) / (8 * vs);
     const int ybw = mcux * hs, ybh = mcuy * vs, cbw = mcux, cbh = mcuy;
     const int64_t yblocks = (int64_t)ybw * ybh, cblocks = (int64_t)cbw * cbh;
-    const int64_t coef_frame = info[6], plane_frame = info[7];
+    const int64_t plane_frame = info[7];
+    const int tab_frame = info[6] / 64;
     // planes of one frame: Y [8 ybh][8 ybw], then Cb, Cr [8 cbh][8 cbw]
-    hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)((yblocks + 31) / 32), n), dim3(256), 0, s, coef, qt, planes, coef_frame, (int64_t)0,
-                       3 * 64, 0, (int)yblocks, ybw, plane_frame, 8 * ybw);
+    hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)((yblocks + 31) / 32), n), dim3(256), 0, s, ent, tab, frame_base, qt, planes,
+                       tab_frame, 0, 0, (int)yblocks, ybw, plane_frame, 8 * ybw);
     if (nc == 3) {
-        hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)((cblocks + 31) / 32), n), dim3(256), 0, s, coef, qt, planes + yblocks * 64,
-                           coef_frame, yblocks * 64, 3 * 64, 1, (int)cblocks, cbw, plane_frame, 8 * cbw);
-        hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)((cblocks + 31) / 32), n), dim3(256), 0, s, coef, qt,
-                           planes + yblocks * 64 + cblocks * 64, coef_frame, yblocks * 64 + cblocks * 64, 3 * 64, 2, (int)cblocks, cbw,
+        hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)((cblocks + 31) / 32), n), dim3(256), 0, s, ent, tab, frame_base, qt,
+                           planes + yblocks * 64, tab_frame, (int)yblocks, 1, (int)cblocks, cbw, plane_frame, 8 * cbw);
+        hipLaunchKernelGGL(k_jpeg_idct, dim3((unsigned)((cblocks + 31) / 32), n), dim3(256), 0, s, ent, tab, frame_base, qt,
+                           planes + yblocks * 64 + cblocks * 64, tab_frame, (int)(yblocks + cblocks), 2, (int)cblocks, cbw,
                            plane_frame, 8 * cbw);
     }
     const int mode = nc == 1 ? 3 : (hs == 1 ? 0 : (vs == 1 ? 1 : 2));

@@ -187,10 +187,11 @@ class AviReader:
 
 class MjpegDeviceDecoder:
     """Native Motion-JPEG front end for an `AviReader` (csrc/host_mjpeg.hip): the Huffman entropy decode of a batch runs
-    on C++ threads (no GIL, no Python per frame) into page-locked int16 coefficients; de-quantisation, libjpeg's `islow`
-    inverse DCT, its "fancy" chroma upsampling and its fixed-point YCbCr -> RGB tables run as HIP kernels, so the pixels
-    are born in HBM and only ~1.0-1.5 bytes per pixel cross PCIe (int16 coefficients of the 4:2:0 / 4:2:2 planes).  The BGR
-    frames equal Pillow's / cv2's (libjpeg, default settings) bit for bit - tests/test_gpu_parity.py.
+    on C++ threads (no GIL, no Python per frame) into page-locked buffers, as the non-zero quantised coefficients of every 8x8
+    block; de-quantisation, libjpeg's `islow` inverse DCT, its "fancy" chroma upsampling and its fixed-point YCbCr -> RGB
+    tables run as HIP kernels, so the pixels are born in HBM and only the non-zero coefficients cross PCIe (about a tenth of
+    the pixels' bytes for a quality-70 sensor frame, never more than 1.5 bytes per pixel).  The BGR frames equal Pillow's /
+    cv2's (libjpeg, default settings) bit for bit - tests/test_gpu_parity.py.
 
     Baseline sequential 8-bit JPEG with 1 (gray) or 3 components, luma sampling 1x1 / 2x1 / 2x2, chroma 1x1, Huffman tables
     in every frame: what cameras' MJPG streams, `cv2.VideoWriter('MJPG')` and Pillow write.  Anything else (progressive,
@@ -224,19 +225,27 @@ class MjpegDeviceDecoder:
         self._per, self._pl = int(self._info[6]), int(self._info[7])
         self.threads = max(1, threads or min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)))
         pin = self.device.type == "cuda"
-        self._coef = [torch.empty((self.batch, self._per), dtype=torch.int16, pin_memory=pin) for _ in range(2)]
+        self._cap, self._nblk = self._per // 2, self._per // 64
+        # host side, two slots: entry words (never more than half the dense coefficients' bytes; typically a few percent of
+        # them are used), the per-block table, frames' first words, tables, status, the spans the threads filled
+        self._ent = [torch.empty(self.batch * self._cap, dtype=torch.int32, pin_memory=pin) for _ in range(2)]
+        self._tab = [torch.empty((self.batch, self._nblk), dtype=torch.int32, pin_memory=pin) for _ in range(2)]
+        self._fb = [torch.empty(self.batch, dtype=torch.int64, pin_memory=pin) for _ in range(2)]
         self._qt = [torch.empty((self.batch, 3, 64), dtype=torch.int16, pin_memory=pin) for _ in range(2)]
         self._status = [np.zeros(self.batch, dtype=np.int32) for _ in range(2)]
+        self._regions = [np.zeros(2 * self.threads, dtype=np.int64) for _ in range(2)]
         self._count = [0, 0]
-        self._dcoef = torch.empty((self.batch, self._per), dtype=torch.int16, device=self.device)
+        self._dent = torch.empty(self.batch * self._cap, dtype=torch.int32, device=self.device)
+        self._dtab = torch.empty((self.batch, self._nblk), dtype=torch.int32, device=self.device)
+        self._dfb = torch.empty(self.batch, dtype=torch.int64, device=self.device)
         self._dqt = torch.empty((self.batch, 3, 64), dtype=torch.int16, device=self.device)
         self._planes = torch.empty((self.batch, self._pl), dtype=torch.uint8, device=self.device)
         self._out = [torch.empty((self.batch, self.height, self.width, 3), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self.uploaded_bytes = 0                                        # what crossed to the device so far (all batches)
 
     def entropy(self, slot: int, n: int | None = None) -> int:
         """Host half for the reader's next up to `n` (default: batch) frames into `slot`.  Returns the count (0 at the end).
         Safe on a helper thread: ctypes drops the GIL for the call and the C side starts its own threads."""
-        import ctypes as C
         r = self._reader
         m = max(0, min(self.batch if n is None else min(int(n), self.batch), len(r._frames) - r._next)) if r._ok else 0
         self._count[slot] = m
@@ -248,7 +257,11 @@ class MjpegDeviceDecoder:
         sizes = np.asarray([f[1] for f in fr], dtype=np.int32)
         st = self._status[slot]
         bad = self._lib.vbs_mjpeg_entropy_batch(self._base, offs.ctypes.data, sizes.ctypes.data, m, self._info,
-                                                self._coef[slot].data_ptr(), self._qt[slot].data_ptr(), st.ctypes.data, self.threads)
+                                                self._ent[slot].data_ptr(), self._tab[slot].data_ptr(), self._fb[slot].data_ptr(),
+                                                self._regions[slot].ctypes.data, self._qt[slot].data_ptr(), st.ctypes.data,
+                                                self.threads)
+        if bad < 0:
+            raise RuntimeError(f"vbs_mjpeg_entropy_batch failed ({bad})")
         if bad:
             i = int(np.flatnonzero(st[:m])[0])
             raise IOError(f"Motion-JPEG frame {r._next - m + i}: corrupt or not of the clip's JPEG variant (status {int(st[i])})")
@@ -262,11 +275,19 @@ class MjpegDeviceDecoder:
         out = self._out[slot]
         if not m:
             return out[:0]
-        self._dcoef[:m].copy_(self._coef[slot][:m], non_blocking=True)
+        ent, reg = self._ent[slot], self._regions[slot]
+        for t in range(self.threads):                                  # only the words the host threads wrote
+            a, u = int(reg[2 * t]), int(reg[2 * t + 1])
+            if u:
+                self._dent[a:a + u].copy_(ent[a:a + u], non_blocking=True)
+                self.uploaded_bytes += 4 * u
+        self._dtab[:m].copy_(self._tab[slot][:m], non_blocking=True)
+        self._dfb[:m].copy_(self._fb[slot][:m], non_blocking=True)
         self._dqt[:m].copy_(self._qt[slot][:m], non_blocking=True)
+        self.uploaded_bytes += m * (4 * self._nblk + 8 + 384)
         stream = torch.cuda.current_stream(self.device).cuda_stream if self.device.type == "cuda" else 0
-        rc = self._lib.vbs_mjpeg_reconstruct(self._dcoef.data_ptr(), self._dqt.data_ptr(), m, self._info, self._planes.data_ptr(),
-                                             out.data_ptr(), out.stride(0), out.stride(1), stream)
+        rc = self._lib.vbs_mjpeg_reconstruct(self._dent.data_ptr(), self._dtab.data_ptr(), self._dfb.data_ptr(), self._dqt.data_ptr(), m,
+                                             self._info, self._planes.data_ptr(), out.data_ptr(), out.stride(0), out.stride(1), stream)
         if rc != 0:
             raise RuntimeError(f"vbs_mjpeg_reconstruct failed ({rc})")
         return out[:m]
