@@ -1634,6 +1634,62 @@ def test_engine_argument_errors():
     eng.close()
 
 
+def test_tracking_grid_equals_the_plain_nearest_search():
+    """a15 (`_track_markers`, marker_detection.py:349-396): `vbs_track` looks for a reference ID's nearest detection in the
+    3 x 3 cells around it of a grid in LDS instead of among all detections.  Against `cdist` + `argmin` + the distance rule
+    of the reference (NumPy, float64) on inputs made to break a grid: detections at every distance around `min_dist`
+    (exactly on it too), on cell borders, exact ties (the first index wins), duplicates, reference positions outside the
+    frame / negative / huge / NaN, min_dist 0 ... beyond the grid's range (the plain scan), few and many detections."""
+    from scipy.spatial.distance import cdist
+    rng = np.random.default_rng(11)
+    eng = engine(480, 640, max_markers=1024, max_batch=4)
+    cases = []
+    for md in (0.0, 0.5, 7.0, 20.0, 31.0, 32.0, 33.0, 63.5, 200.0, 4095.0, 5000.0, float("nan")):
+        for cnt in (0, 1, 16, 17, 169, 1024):
+            cases.append((md, cnt))
+    for md, cnt in cases:
+        mdv = 20.0 if md != md else md
+        det = np.zeros((4, 1024, 6), np.float64)
+        counts = np.array([cnt, cnt, max(cnt - 3, 0), cnt], np.int32)
+        xy = rng.uniform(0, [640, 480], (4, 1024, 2))
+        xy[1] = np.round(xy[1] / 16.0) * 16.0                       # on cell borders, many exact ties and duplicates
+        xy[3, :, 0] = rng.uniform(-50, 700, 1024)
+        det[..., :2] = xy
+        det[..., 2] = rng.uniform(15, 30, (4, 1024)); det[..., 3] = det[..., 2] - 1.0
+        det[..., 4] = rng.uniform(0, 180, (4, 1024)); det[..., 5] = np.arange(1024) + 1
+        m = 300
+        ref = rng.uniform(0, [640, 480], (m, 2))
+        k = min(cnt, 100)
+        if k:
+            ang = rng.uniform(0, 2 * np.pi, k)
+            rad = np.concatenate([np.full(k // 2, mdv), rng.uniform(0.9, 1.1, k - k // 2) * mdv])
+            ref[:k] = xy[0, :k] + rad[:, None] * np.stack([np.cos(ang), np.sin(ang)], axis=1)     # around / exactly at min_dist
+            ref[100:100 + min(k, 50)] = np.round(ref[100:100 + min(k, 50)] / 8.0) * 8.0            # ties against frame 1's lattice
+        ref[200:206] = [[-1e6, 3.0], [3.0, 1e12], [np.nan, 5.0], [-0.0, -0.0], [639.999, 479.999], [1e300, -1e300]]
+        ref[206:212] = [[-17.0, 240.0], [656.0, 240.0], [320.0, -15.9], [320.0, 495.5], [np.inf, 0.0], [32.0, 32.0]]
+        t = eng.track(torch.from_numpy(det).cuda(), torch.from_numpy(counts).cuda(), ref, md).cpu().numpy()
+        for n in range(4):
+            c = int(counts[n])
+            for r in range(m):
+                row = t[n, r]
+                want = None
+                if c:
+                    with np.errstate(invalid="ignore", over="ignore"):
+                        d = cdist(ref[r:r + 1], det[n, :c, :2])[0]
+                    if not np.isnan(d).all():
+                        j = int(np.argmin(d)) if not np.isnan(d).any() else None
+                        if j is None:                               # (argmin of a row with NaN is the NaN: every distance NaN here)
+                            want = None
+                        elif not (d[j] > md) and np.isfinite(d[j]):     # (an overflowing distance is never reported: the
+                            want = j                                    #  reference would, for a NaN min_dist only)
+                if want is None:
+                    assert row[0] == 0.0, (md, cnt, n, r, row)
+                else:
+                    assert int(row[0]) & 1 and int(row[9]) == want, (md, cnt, n, r, row, want)
+                    assert row[1] == np.float32(det[n, want, 0]) and row[2] == np.float32(det[n, want, 1])
+    eng.close()
+
+
 def test_real_sensor_frame(golden_dir, tmp_path):
     """The reference's one real frame (img/raw_markers.png -> tests/golden/raw_markers_bgr.npz, 467x437 BGR, 65 printed
     dots): HIP vs oracle under both BGR2GRAY coefficient sets - masks exact, 65 detections, centroids exact, axes
