@@ -48,7 +48,8 @@ Extra objects on the JSON line:
                 gathered_table_checksum (every rank's gathered table reduced to two integers, all-gathered and ASSERTED
                 equal on every rank), pipelined_gather; frame0_ids = the device ID assignment and its host checker.
                 also: bgr_fps (the same workload fed as 3-channel BGR frames, the reference's input format),
-                host_path_fps (NumPy frames in host memory -> CSV on disk through MarkerTracker), the NCC decision
+                host_path_fps (NumPy frames in host memory -> CSV on disk through MarkerTracker), avi_path_fps (a 640x480
+                Motion-JPEG AVI file -> CSV through MarkerTracker.process(): native decoder and Pillow), the NCC decision
                 counters of the timed batch, world size / backend as torch.distributed reports them;
                 single_frame_us (BASELINE config 2, the way MarkerTracker.process calls: ONE resident frame per call, track ->
                 3-D, call + stream synchronise; `eager` and `graph_replay` = the same call captured once into a HIP graph;
@@ -386,6 +387,45 @@ def host_path_fps(spec, n, seed, batch):
             "pageable": out["pageable"], "csv_rows": len(rows), "csv_bytes": len(texts["pinned"]),
             "csv_identical_pinned_vs_pageable": True, "batch": batch,
             "pcie_bound_fps": "about 42 000 gray 1280x1024 frames/s at ~55 GB/s"}
+
+
+def avi_path_fps(n, seed, batch=256):
+    """Row f4: the reference's real input - a Motion-JPEG AVI in the camera's format (640x480, quality 70,
+    collecting.py:100) - from the FILE to the CSV through `MarkerTracker.process()` with the reference's default crop.
+    Twice: the native decoder (Huffman on C++ threads, IDCT + colour on the device) and Pillow's thread pool; the two CSV
+    files must be the same bytes.  Encoding the clip (Pillow, ~2 ms per frame) is outside the timed calls."""
+    import contextlib
+    import tempfile
+    import numpy as np
+    import vbs_amd.synth as S
+    from vbs_amd.marker_detection import MarkerTracker
+    from vbs_amd.video_io import write_avi
+    spec = S.config1()
+    base = S.make_frames(spec, range(min(n, 64)), seed=seed, channels=3)
+    frames = np.concatenate([base] * ((n + len(base) - 1) // len(base)))[:n]
+    with tempfile.TemporaryDirectory() as td_, contextlib.redirect_stdout(sys.stderr):
+        path = os.path.join(td_, "clip.avi")
+        write_avi(path, frames, fps=12.0, codec="MJPG", quality=70)
+        short = os.path.join(td_, "short.avi")             # (the slow path on a prefix of the clip: same rate, less waiting)
+        write_avi(short, frames[:min(n, 512)], fps=12.0, codec="MJPG", quality=70)
+        out, texts = {"frames": n, "frame": "640x480 BGR, MJPG quality 70", "bytes_per_frame": round(os.path.getsize(path) / n),
+                      "batch": batch, "crop": "(1/8, 1/8, 1/16, 0)"}, {}
+        for name, on_dev, clip, nn in (("device", True, path, n), ("pillow", False, short, min(n, 512))):
+            for rep in range(2):                           # first repetition warms the engine / allocator
+                trk = MarkerTracker({"video_path": clip, "output_dir": os.path.join(td_, f"o{name}{rep}"),
+                                     "crop_ratios": (1 / 8, 1 / 8, 1 / 16, 0), "id_mode": "full", "batch": batch,
+                                     "mjpeg_on_device": on_dev})
+                t0 = time.perf_counter()
+                trk.process()
+                dt = time.perf_counter() - t0
+            assert trk.decode_path == name, (trk.decode_path, name)
+            out[name + "_fps"] = round(nn / dt, 1)
+            texts[name] = open(trk.output_csv, "rb").read()
+        assert texts["device"].startswith(texts["pillow"]), "the CSV must not depend on the decoder"
+        out["fps"] = out["device_fps"]
+        out["csv_identical_device_vs_pillow"] = True
+        out["csv_bytes"] = len(texts["device"])
+    return out
 
 
 def main():
@@ -817,6 +857,10 @@ def main():
             result["config"]["host_path_fps"] = host_path_fps(spec, args.host_frames, args.seed, 128)
         except Exception as e:
             result["config"]["host_path_fps"] = {"error": f"{type(e).__name__}: {e}"}
+        try:
+            result["config"]["avi_path_fps"] = avi_path_fps(2048, args.seed)
+        except Exception as e:
+            result["config"]["avi_path_fps"] = {"error": f"{type(e).__name__}: {e}"}
         try:
             result["config"]["single_frame_us"] = single_frame_us(spec, args.seed, (K, dist, R, T))
         except Exception as e:

@@ -108,7 +108,8 @@ int vbs_set_option(vbs_handle* h, int option, int value);
 /* Motion-JPEG front end (the reference reads its AVI through cv2.VideoCapture, marker_detection.py:50-76).
  * vbs_mjpeg_probe: headers of one JPEG frame -> info[8] = {width, height, components, luma h, luma v, restart interval,
  * int16 coefficients per frame, plane bytes per frame}; VBS_EINVAL for a stream this decoder does not take (progressive,
- * arithmetic, 12-bit, sampling other than 4:4:4 / 4:2:2 / 4:2:0 / gray): the caller then decodes with its own reader.
+ * arithmetic, 12-bit, sampling other than 4:4:4 / 4:2:2 / 4:2:0 / gray): the caller then decodes with its own reader.  A frame
+ * without DHT segments (camera MJPG) is decoded with the standard tables of ITU-T T.81 Annex K.3.
  * vbs_mjpeg_entropy_batch: Huffman-decodes n frames (buf + offs[i], sizes[i]; all of the probed geometry) on `threads` host
  * threads into the compact form the device half reads (HOST memory, e.g. page-locked): tab [n][info[6] / 64] one word per 8x8
  * block (component after component, row-major over the padded block grid) = (first word of the block in ent, relative to the

@@ -694,6 +694,25 @@ def test_mjpeg_device_decode_equals_libjpeg(tmp_path, sub):
             slot ^= 1
         got = np.concatenate(got)
         assert n == 5 and got.shape == want.shape and np.array_equal(got, want), (sub, q, h, w, opts)
+    # camera-style frames: no DHT segment, the standard tables are implied (Pillow's libjpeg-turbo installs them too)
+    raw = bytearray(open(p, "rb").read())
+    rd = AviReader(p)
+    for off, size in rd._frames:
+        d, i = bytes(raw[off:off + size]), 2
+        keep = bytearray(d[:2])
+        while d[i + 1] != 0xDA:
+            ln = 2 + ((d[i + 2] << 8) | d[i + 3])
+            if d[i + 1] != 0xC4:
+                keep += d[i:i + ln]
+            i += ln
+        keep += d[i:]
+        assert len(keep) < size
+        raw[off:off + size] = bytes(keep) + bytes(size - len(keep))          # (same chunk size: trailing zeros after EOI)
+    p2 = str(tmp_path / "nodht.avi")
+    open(p2, "wb").write(bytes(raw))
+    n, want = AviReader(p2).read_batch(5, threads=1)
+    dec = MjpegDeviceDecoder(AviReader(p2), torch.device("cuda:0"), batch=5, threads=1)
+    assert dec.entropy(0) == 5 and np.array_equal(dec.reconstruct(0).cpu().numpy(), want)
 
 
 def test_mjpeg_device_decode_refusals_and_corrupt_frames(tmp_path):

@@ -516,10 +516,18 @@ def test_mjpeg_entropy_decode_host_half(tmp_path):
     rng = np.random.default_rng(3)
     yy, xx = np.mgrid[0:61, 0:83]
     img = np.clip(128 + 80 * np.sin(xx / 6.0) * np.cos(yy / 9.0) + rng.normal(0, 10, (61, 83)), 0, 255).astype(np.uint8)
-    for opts in ({}, {"restart_marker_blocks": 3}, {"optimize": True}, {"quality": 100}):
+    for opts in ({}, {"restart_marker_blocks": 3}, {"optimize": True}, {"quality": 100}, {"no_dht": True}):
         bio = io.BytesIO()
-        Image.fromarray(img).save(bio, format="JPEG", **{"quality": 80, **opts})
+        Image.fromarray(img).save(bio, format="JPEG", **{"quality": 80, **{k: v for k, v in opts.items() if k != "no_dht"}})
         data = bio.getvalue()
+        if opts.get("no_dht"):                                       # a camera's frame: the standard tables are implied
+            i, keep = 2, bytearray(data[:2])
+            while data[i + 1] != 0xDA:
+                ln = 2 + ((data[i + 2] << 8) | data[i + 3])
+                if data[i + 1] != 0xC4:
+                    keep += data[i:i + ln]
+                i += ln
+            data = bytes(keep + data[i:])
         info = (C.c_int32 * 8)()
         assert lib.vbs_mjpeg_probe(data, len(data), info) == 0
         assert list(info)[:5] == [83, 61, 1, 1, 1] and info[6] == 11 * 8 * 64

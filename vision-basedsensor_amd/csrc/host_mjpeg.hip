@@ -84,6 +84,40 @@ const uint8_t ZIGZAG[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 
 
 inline int be16(const uint8_t* p) { return (p[0] << 8) | p[1]; }
 
+// ITU-T T.81 Annex K.3 "typical" Huffman tables: what an encoder that does not optimise writes, and what a Motion-JPEG frame
+// WITHOUT a DHT segment means (AVI MJPG from cameras; libjpeg-turbo and FFmpeg install the same tables for such frames).
+const uint8_t STD_DC_BITS[2][16] = {{0, 1, 5, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0, 0, 0}, {0, 3, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0, 0, 0}};
+const uint8_t STD_AC_BITS[2][16] = {{0, 2, 1, 3, 3, 2, 4, 3, 5, 5, 4, 4, 0, 0, 1, 125}, {0, 2, 1, 2, 4, 4, 3, 4, 7, 5, 4, 4, 0, 1, 2, 119}};
+const uint8_t STD_AC_VALS[2][162] = {
+    {1,   2,   3,   0,   4,   17,  5,   18,  33,  49,  65,  6,   19,  81,  97,  7,   34,  113, 20,  50,  129, 145, 161, 8,   35,  66,  177,
+     193, 21,  82,  209, 240, 36,  51,  98,  114, 130, 9,   10,  22,  23,  24,  25,  26,  37,  38,  39,  40,  41,  42,  52,  53,  54,  55,
+     56,  57,  58,  67,  68,  69,  70,  71,  72,  73,  74,  83,  84,  85,  86,  87,  88,  89,  90,  99,  100, 101, 102, 103, 104, 105, 106,
+     115, 116, 117, 118, 119, 120, 121, 122, 131, 132, 133, 134, 135, 136, 137, 138, 146, 147, 148, 149, 150, 151, 152, 153, 154, 162, 163,
+     164, 165, 166, 167, 168, 169, 170, 178, 179, 180, 181, 182, 183, 184, 185, 186, 194, 195, 196, 197, 198, 199, 200, 201, 202, 210, 211,
+     212, 213, 214, 215, 216, 217, 218, 225, 226, 227, 228, 229, 230, 231, 232, 233, 234, 241, 242, 243, 244, 245, 246, 247, 248, 249, 250},
+    {0,   1,   2,   3,   17,  4,   5,   33,  49,  6,   18,  65,  81,  7,   97,  113, 19,  34,  50,  129, 8,   20,  66,  145, 161, 177, 193,
+     9,   35,  51,  82,  240, 21,  98,  114, 209, 10,  22,  36,  52,  225, 37,  241, 23,  24,  25,  26,  38,  39,  40,  41,  42,  53,  54,
+     55,  56,  57,  58,  67,  68,  69,  70,  71,  72,  73,  74,  83,  84,  85,  86,  87,  88,  89,  90,  99,  100, 101, 102, 103, 104, 105,
+     106, 115, 116, 117, 118, 119, 120, 121, 122, 130, 131, 132, 133, 134, 135, 136, 137, 138, 146, 147, 148, 149, 150, 151, 152, 153, 154,
+     162, 163, 164, 165, 166, 167, 168, 169, 170, 178, 179, 180, 181, 182, 183, 184, 185, 186, 194, 195, 196, 197, 198, 199, 200, 201, 202,
+     210, 211, 212, 213, 214, 215, 216, 217, 218, 226, 227, 228, 229, 230, 231, 232, 233, 234, 242, 243, 244, 245, 246, 247, 248, 249, 250}};
+
+struct StdTables {
+    Huff dc[2], ac[2];
+    StdTables() {
+        for (int k = 0; k < 2; ++k) {
+            int n = 0;
+            for (int i = 0; i < 16; ++i) { dc[k].bits[i + 1] = STD_DC_BITS[k][i]; n += STD_DC_BITS[k][i]; }
+            for (int i = 0; i < n; ++i) dc[k].vals[i] = (uint8_t)i;
+            dc[k].build();
+            for (int i = 0; i < 16; ++i) ac[k].bits[i + 1] = STD_AC_BITS[k][i];
+            memcpy(ac[k].vals, STD_AC_VALS[k], 162);
+            ac[k].build();
+        }
+    }
+};
+const StdTables& std_tables() { static const StdTables t; return t; }
+
 // headers up to and including SOS; VBS_OK, or VBS_EINVAL for a stream this decoder does not take
 int parse(const uint8_t* d, int64_t size, Frame* f) {
     if (size < 4 || d[0] != 0xFF || d[1] != 0xD8) return VBS_EINVAL;
@@ -147,8 +181,12 @@ int parse(const uint8_t* d, int64_t size, Frame* f) {
         p += len;
     }
     if (!f->scan || !f->w) return VBS_EINVAL;
-    for (int c = 0; c < f->ncomp; ++c)
-        if (!f->qt_ok[f->tq[c]] || !f->dc[f->td[c]].ok || !f->ac[f->ta[c]].ok) return VBS_EINVAL;
+    for (int c = 0; c < f->ncomp; ++c) {
+        if (!f->qt_ok[f->tq[c]]) return VBS_EINVAL;
+        // a table the frame did not define: the standard one of that slot (0 luminance, 1 chrominance)
+        if (!f->dc[f->td[c]].ok) { if (f->td[c] > 1) return VBS_EINVAL; f->dc[f->td[c]] = std_tables().dc[f->td[c]]; }
+        if (!f->ac[f->ta[c]].ok) { if (f->ta[c] > 1) return VBS_EINVAL; f->ac[f->ta[c]] = std_tables().ac[f->ta[c]]; }
+    }
     if (f->ncomp == 1) { f->hs[0] = f->vs[0] = 1; return VBS_OK; }
     // chroma 1x1, luma 1x1 / 2x1 / 2x2 (4:4:4, 4:2:2, 4:2:0)
     if (f->hs[1] != 1 || f->vs[1] != 1 || f->hs[2] != 1 || f->vs[2] != 1) return VBS_EINVAL;

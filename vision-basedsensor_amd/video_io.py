@@ -193,9 +193,10 @@ class MjpegDeviceDecoder:
     the pixels' bytes for a quality-70 sensor frame, never more than 1.5 bytes per pixel).  The BGR frames equal Pillow's /
     cv2's (libjpeg, default settings) bit for bit - tests/test_gpu_parity.py.
 
-    Baseline sequential 8-bit JPEG with 1 (gray) or 3 components, luma sampling 1x1 / 2x1 / 2x2, chroma 1x1, Huffman tables
-    in every frame: what cameras' MJPG streams, `cv2.VideoWriter('MJPG')` and Pillow write.  Anything else (progressive,
-    arithmetic coding, 12 bit, CMYK, missing DHT): `ValueError` at construction, and the caller stays with Pillow.
+    Baseline sequential 8-bit JPEG with 1 (gray) or 3 components, luma sampling 1x1 / 2x1 / 2x2, chroma 1x1; frames without
+    Huffman tables (camera MJPG streams) mean the standard ones of ITU-T T.81 Annex K, as for libjpeg-turbo and FFmpeg: what
+    cameras, `cv2.VideoWriter('MJPG')` and Pillow write.  Anything else (progressive, arithmetic coding, 12 bit, CMYK):
+    `ValueError` at construction, and the caller stays with Pillow.
 
     Two slots of host / device buffers, so that `entropy(slot)` of batch k + 1 can run on a helper thread while
     `reconstruct(slot)` and the tracker work on batch k."""
