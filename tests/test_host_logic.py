@@ -576,3 +576,71 @@ def test_mjpeg_entropy_decode_host_half(tmp_path):
     lib.vbs_mjpeg_probe(data, len(data), info)
     assert lib.vbs_mjpeg_entropy_batch(junk, offs.ctypes.data, sizes.ctypes.data, 1, info, ent.ctypes.data, tab.ctypes.data,
                                        fb.ctypes.data, reg.ctypes.data, qt.ctypes.data, st.ctypes.data, 1) == 1 and st[0] != 0
+
+
+def test_mjpeg_host_half_survives_corrupt_streams():
+    """f4(c): the entropy decoder reads bytes a camera or a disk produced.  Valid frames with random bytes overwritten (headers,
+    tables, scan), cut short, or with an over-subscribed Huffman table must come back as a status - or as a well-formed
+    block table when the damage still parses - never as a write past the buffers (guard words behind every output)."""
+    import ctypes as C
+    import io
+    from PIL import Image
+    from vbs_amd import _lib as L
+    lib = L.lib()
+    rng = np.random.default_rng(5)
+    yy, xx = np.mgrid[0:40, 0:56]
+    img = np.clip(np.stack([128 + 90 * np.sin(xx / 5.0), 128 + 90 * np.cos(yy / 4.0), 3.0 * (xx + yy)], axis=2)
+                  + rng.normal(0, 15, (40, 56, 3)), 0, 255).astype(np.uint8)
+    streams = []
+    for opts in (dict(subsampling=2), dict(subsampling=0), dict(subsampling=1, restart_marker_blocks=2), dict(gray=True)):
+        bio = io.BytesIO()
+        im = Image.fromarray(img[:, :, 0] if opts.pop("gray", False) else img)
+        im.save(bio, format="JPEG", quality=85, **opts)
+        streams.append(bio.getvalue())
+    GUARD = 0xA5A5A5A5
+    checked = parsed = 0
+    for base in streams:
+        info = (C.c_int32 * 8)()
+        assert lib.vbs_mjpeg_probe(base, len(base), info) == 0
+        cap, nblk = info[6] // 2, info[6] // 64
+        sos = base.index(b"\xff\xda")
+        for it in range(700):
+            d = bytearray(base)
+            kind = it % 5
+            if kind == 0:                                           # bytes anywhere
+                for _ in range(int(rng.integers(1, 12))):
+                    d[int(rng.integers(2, len(d)))] = int(rng.integers(0, 256))
+            elif kind == 1:                                         # bytes in the headers and tables
+                for _ in range(int(rng.integers(1, 6))):
+                    d[int(rng.integers(2, sos + 12))] = int(rng.integers(0, 256))
+            elif kind == 2:                                         # cut short
+                d = d[:int(rng.integers(2, len(d)))]
+            elif kind == 3:                                         # markers sprayed into the scan
+                for _ in range(int(rng.integers(1, 5))):
+                    k = int(rng.integers(sos, len(d) - 1))
+                    d[k] = 0xFF
+                    d[k + 1] = int(rng.choice([0x00, 0xD0, 0xD3, 0xD9, 0xC4, 0xFF]))
+            else:                                                   # an over-subscribed code-length histogram in a DHT
+                k = bytes(d).index(b"\xff\xc4") + 5
+                d[k + int(rng.integers(0, 4))] = int(rng.integers(3, 256))
+            d = bytes(d)
+            ent = np.full(cap + 64, GUARD, np.uint32)
+            tab = np.full(nblk + 16, GUARD, np.uint32)
+            fb = np.zeros(1, np.int64)
+            reg = np.zeros(2, np.int64)
+            qt = np.zeros((1, 3, 64), np.uint16)
+            st = np.zeros(1, np.int32)
+            offs, sizes = np.zeros(1, np.int64), np.array([len(d)], np.int32)
+            bad = lib.vbs_mjpeg_entropy_batch(d, offs.ctypes.data, sizes.ctypes.data, 1, info, ent.ctypes.data, tab.ctypes.data,
+                                              fb.ctypes.data, reg.ctypes.data, qt.ctypes.data, st.ctypes.data, 1)
+            assert bad in (0, 1) and (bad == 1) == (st[0] != 0)
+            assert (ent[cap:] == GUARD).all() and (tab[nblk:] == GUARD).all()
+            checked += 1
+            if bad == 0:
+                parsed += 1
+                cnt, start = tab[:nblk] & 127, tab[:nblk] >> 7
+                assert ((cnt <= 32) | (cnt == 127)).all()
+                words = np.where(cnt == 127, 32, cnt)
+                assert (start + words <= reg[1]).all() and 0 <= reg[1] <= cap and reg[0] == 0
+            lib.vbs_mjpeg_probe(d, len(d), (C.c_int32 * 8)())
+    assert checked == 2800 and 200 < parsed < 2700                  # both outcomes occur

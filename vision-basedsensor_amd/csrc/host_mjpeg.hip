@@ -37,11 +37,14 @@ struct Huff {
         const int n = k;
         k = 0;
         int si = huffsize[0];
+        bool valid = true;
         while (huffsize[k]) {
             while (huffsize[k] == si) huffcode[k++] = (uint16_t)code++;
-            code <<= 1;
+            if (code > (1 << si)) valid = false;        // more codes of this length than there are (a corrupt DHT): refused,
+            code <<= 1;                                  // as libjpeg does - the look-ahead table below is indexed by the codes
             ++si;
         }
+        if (!valid) { ok = false; return; }
         int p = 0;
         for (int l = 1; l <= 16; ++l) {
             if (bits[l]) {
@@ -69,7 +72,7 @@ struct Huff {
 
 struct Frame {
     int w = 0, h = 0, ncomp = 0;
-    int hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0};
+    int hs[3] = {1, 1, 1}, vs[3] = {1, 1, 1}, tq[3] = {0, 0, 0}, td[3] = {0, 0, 0}, ta[3] = {0, 0, 0}, id[3] = {0, 0, 0};
     uint16_t qt[4][64];
     bool qt_ok[4] = {false, false, false, false};
     Huff dc[4], ac[4];
@@ -138,7 +141,7 @@ int parse(const uint8_t* d, int64_t size, Frame* f) {
             f->h = be16(s + 1); f->w = be16(s + 3); f->ncomp = s[5];
             if ((f->ncomp != 1 && f->ncomp != 3) || n < 6 + 3 * f->ncomp || f->w < 1 || f->h < 1) return VBS_EINVAL;
             for (int c = 0; c < f->ncomp; ++c) {
-                f->hs[c] = s[7 + 3 * c] >> 4; f->vs[c] = s[7 + 3 * c] & 15; f->tq[c] = s[8 + 3 * c] & 3;
+                f->id[c] = s[6 + 3 * c]; f->hs[c] = s[7 + 3 * c] >> 4; f->vs[c] = s[7 + 3 * c] & 15; f->tq[c] = s[8 + 3 * c] & 3;
             }
         } else if (m >= 0xC2 && m <= 0xCF && m != 0xC4 && m != 0xC8 && m != 0xCC) {
             return VBS_EINVAL;                           // progressive, lossless, arithmetic
@@ -154,6 +157,7 @@ int parse(const uint8_t* d, int64_t size, Frame* f) {
                 if (cnt > 256 || q + 17 + cnt > n) return VBS_EINVAL;
                 memcpy(t.vals, s + q + 17, cnt);
                 t.build();
+                if (!t.ok) return VBS_EINVAL;
                 q += 17 + cnt;
             }
         } else if (m == 0xDB) {
@@ -171,7 +175,10 @@ int parse(const uint8_t* d, int64_t size, Frame* f) {
             f->restart = be16(s);
         } else if (m == 0xDA) {
             if (n < 1 || s[0] != f->ncomp || n < 1 + 2 * f->ncomp + 3) return VBS_EINVAL;
-            for (int c = 0; c < f->ncomp; ++c) { f->td[c] = s[2 + 2 * c] >> 4; f->ta[c] = s[2 + 2 * c] & 15; }
+            for (int c = 0; c < f->ncomp; ++c) {
+                f->td[c] = s[2 + 2 * c] >> 4; f->ta[c] = s[2 + 2 * c] & 15;
+                if (f->td[c] > 3 || f->ta[c] > 3 || s[1 + 2 * c] != f->id[c]) return VBS_EINVAL;   // (one interleaved scan, frame order)
+            }
             const uint8_t* t = s + 1 + 2 * f->ncomp;
             if (t[0] != 0 || t[1] != 63 || t[2] != 0) return VBS_EINVAL;
             f->scan = d + p + len;
