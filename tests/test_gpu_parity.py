@@ -674,8 +674,8 @@ def test_mjpeg_device_decode_equals_libjpeg(tmp_path, sub):
     against Pillow's libjpeg on the same chunks, bit for bit in every BGR byte: chroma 4:4:4 / 4:2:2 / 4:2:0 and gray,
     qualities 35-100 (quality 100 = all-ones tables: the widest coefficient range), image sizes that are not multiples of
     the MCU (the partial last MCU row / column, chroma upsampling at the padded edge), restart intervals, optimised
-    Huffman tables, batches that do not divide the clip.  cv2 - the reference's decoder - is the same libjpeg family with the
-    same defaults (islow IDCT, fancy upsampling)."""
+    Huffman tables, batches that do not divide the clip.  (libjpeg with its defaults - islow IDCT, fancy upsampling - is what
+    cv2.imdecode and OpenCV's own MJPEG reader use; cv2.VideoCapture's FFmpeg backend has its own IDCT: unpinned.)"""
     pytest.importorskip("PIL")
     from vbs_amd.video_io import AviReader, MjpegDeviceDecoder, write_avi
     gray = sub == "gray"

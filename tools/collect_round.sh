@@ -16,7 +16,7 @@ echo "bench c5 / bgr / c1 / real done"
 timeout -k 10 300 python tools/gpu_stage_phase.py 512 c3 > $OUT/${TAG}_stage_phase_timing_c3.log 2>&1
 timeout -k 10 300 python tools/gpu_ncc_phase.py 512 > $OUT/${TAG}_ncc_phase_timing.log 2>&1
 timeout -k 10 120 python tools/gpu_single_frame.py > $OUT/${TAG}_single_frame.log 2>&1
-timeout -k 10 300 python tools/gpu_decode_path.py 1024 > $OUT/${TAG}_decode_path.log 2>&1
+timeout -k 10 300 python tools/gpu_decode_path.py 2048 > $OUT/${TAG}_decode_path.log 2>&1
 echo "phases / single frame / decode done"
 timeout -k 10 900 bash profiles/collect.sh $TAG 512 > $OUT/collect_$TAG.log 2>&1
 echo "collect done"

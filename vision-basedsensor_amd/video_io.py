@@ -2,8 +2,8 @@
 
 The sensor's camera is opened with FOURCC MJPG (`Vedio_Capture/collecting.py:100`) and its recordings are AVI files,
 which the reference hands to `cv2.VideoCapture`.  This module reads that container itself: a sequential walk of the
-RIFF 'movi' list, every 'NNdc' / 'NNdb' chunk one frame — Motion-JPEG frames are decoded with Pillow (libjpeg, the
-same decoder family cv2 uses), uncompressed DIB frames (24-bit BGR or 8-bit gray, bottom-up) are reshaped.  The
+RIFF 'movi' list, every 'NNdc' / 'NNdb' chunk one frame — Motion-JPEG frames are decoded natively (MjpegDeviceDecoder) or
+with Pillow (libjpeg: what cv2.imdecode and OpenCV's own MJPEG reader use; its FFmpeg backend has another IDCT), uncompressed DIB frames (24-bit BGR or 8-bit gray, bottom-up) are reshaped.  The
 reader mimics the four `cv2.VideoCapture` calls the reference makes (`isOpened`, `get`, `read`, `release`) and
 returns BGR frames like cv2 does.  Decoding happens on the host: it is outside the benchmarked path and bounds only
 the real-world end-to-end rate.  Other codecs (XVID, H.264 ...) need a real decoder: IOError, as `cv2` absent did.
@@ -190,8 +190,8 @@ class MjpegDeviceDecoder:
     on C++ threads (no GIL, no Python per frame) into page-locked buffers, as the non-zero quantised coefficients of every 8x8
     block; de-quantisation, libjpeg's `islow` inverse DCT, its "fancy" chroma upsampling and its fixed-point YCbCr -> RGB
     tables run as HIP kernels, so the pixels are born in HBM and only the non-zero coefficients cross PCIe (about a tenth of
-    the pixels' bytes for a quality-70 sensor frame, never more than 1.5 bytes per pixel).  The BGR frames equal Pillow's /
-    cv2's (libjpeg, default settings) bit for bit - tests/test_gpu_parity.py.
+    the pixels' bytes for a quality-70 sensor frame, never more than 1.5 bytes per pixel).  The BGR frames equal Pillow's
+    (libjpeg-turbo, default settings: islow IDCT, fancy upsampling) bit for bit - tests/test_gpu_parity.py.
 
     Baseline sequential 8-bit JPEG with 1 (gray) or 3 components, luma sampling 1x1 / 2x1 / 2x2, chroma 1x1; frames without
     Huffman tables (camera MJPG streams) mean the standard ones of ITU-T T.81 Annex K, as for libjpeg-turbo and FFmpeg: what
