@@ -2,11 +2,13 @@
 
 The sensor's camera is opened with FOURCC MJPG (`Vedio_Capture/collecting.py:100`) and its recordings are AVI files,
 which the reference hands to `cv2.VideoCapture`.  This module reads that container itself: a sequential walk of the
-RIFF 'movi' list, every 'NNdc' / 'NNdb' chunk one frame — Motion-JPEG frames are decoded natively (MjpegDeviceDecoder) or
-with Pillow (libjpeg: what cv2.imdecode and OpenCV's own MJPEG reader use; its FFmpeg backend has another IDCT), uncompressed DIB frames (24-bit BGR or 8-bit gray, bottom-up) are reshaped.  The
-reader mimics the four `cv2.VideoCapture` calls the reference makes (`isOpened`, `get`, `read`, `release`) and
-returns BGR frames like cv2 does.  Decoding happens on the host: it is outside the benchmarked path and bounds only
-the real-world end-to-end rate.  Other codecs (XVID, H.264 ...) need a real decoder: IOError, as `cv2` absent did.
+RIFF 'movi' list, every 'NNdc' / 'NNdb' chunk one frame.  Motion-JPEG frames are decoded natively (`MjpegDeviceDecoder`:
+Huffman on C++ threads, IDCT / upsampling / colour on the device) or with Pillow (libjpeg: what cv2.imdecode and OpenCV's
+own MJPEG reader use; cv2's FFmpeg backend has another IDCT); uncompressed DIB frames (24-bit BGR or 8-bit gray, bottom-up)
+are reshaped.  The reader mimics the four `cv2.VideoCapture` calls the reference makes (`isOpened`, `get`, `read`,
+`release`) and returns BGR frames like cv2 does.  Decoding is outside the benchmarked path (frames resident in HBM); it
+bounds the real-world rate from a file: 50 k frames/s natively, 3.3 k through Pillow (640x480).  Other codecs (XVID,
+H.264 ...) need a real decoder: IOError, as `cv2` absent did.
 
 `write_avi` is the matching minimal writer (MJPG or uncompressed), used by the tests to make fixtures on the fly.
 """
