@@ -644,3 +644,31 @@ def test_mjpeg_host_half_survives_corrupt_streams():
                 assert (start + words <= reg[1]).all() and 0 <= reg[1] <= cap and reg[0] == 0
             lib.vbs_mjpeg_probe(d, len(d), (C.c_int32 * 8)())
     assert checked == 2800 and 200 < parsed < 2700                  # both outcomes occur
+
+
+def test_mjpeg_decoder_class_host_half_without_a_gpu(tmp_path):
+    """`video_io.MjpegDeviceDecoder` on the CPU device (host buffers only): batches that do not divide the clip, the
+    refusals (`ValueError`: the tracker then stays with Pillow), a frame without a header as an `IOError` that names it."""
+    from vbs_amd.video_io import AviReader, MjpegDeviceDecoder, write_avi
+    spec = S.config1()
+    frames = S.make_frames(spec, range(7), seed=2, channels=3)
+    p = str(tmp_path / "clip.avi")
+    write_avi(p, frames, quality=70)
+    dec = MjpegDeviceDecoder(AviReader(p), "cpu", batch=3, threads=2)
+    assert (dec.width, dec.height) == (spec.width, spec.height)
+    assert [dec.entropy(0), dec.entropy(1), dec.entropy(0), dec.entropy(1)] == [3, 3, 1, 0]
+    assert int(dec._regions[0][1]) > 0 and int(dec._fb[0][0]) == 0
+    for bad_kind in ("raw", "progressive"):
+        q = str(tmp_path / f"{bad_kind}.avi")
+        write_avi(q, frames[:2], **({"codec": "RAW"} if bad_kind == "raw" else {"progressive": True}))
+        with pytest.raises(ValueError):
+            MjpegDeviceDecoder(AviReader(q), "cpu", batch=2)
+    b = bytearray(open(p, "rb").read())
+    off, size = AviReader(p)._frames[4]
+    b[off:off + 4] = bytes(4)
+    q = str(tmp_path / "bad.avi")
+    open(q, "wb").write(bytes(b))
+    dec = MjpegDeviceDecoder(AviReader(q), "cpu", batch=4, threads=3)
+    assert dec.entropy(0) == 4
+    with pytest.raises(IOError, match="frame 4"):
+        dec.entropy(1)
