@@ -26,6 +26,9 @@ struct Huff {
     uint16_t mincode[17];
     // 9-bit look-ahead: (length << 8) | symbol, 0 = longer than 9 bits
     uint16_t look[512];
+    // AC tables: a code AND the value bits behind it, where both fit the 9 bits: value << 16 | run << 8 | bits consumed
+    // (0 = not this way); most coefficients of a camera frame are such short ones
+    int32_t fast[512];
     bool ok = false;
     void build() {
         int k = 0, code = 0;
@@ -66,6 +69,16 @@ struct Huff {
                 const int first = huffcode[p] << (9 - l);
                 for (int c = 0; c < (1 << (9 - l)); ++c) look[first + c] = (uint16_t)((l << 8) | vals[p]);
             }
+        for (int i = 0; i < 512; ++i) {
+            fast[i] = 0;
+            const int e = look[i];
+            if (!e) continue;
+            const int len = e >> 8, sym = e & 255, run = sym >> 4, sz = sym & 15;
+            if (sz == 0 || len + sz > 9) continue;
+            int v = (i >> (9 - len - sz)) & ((1 << sz) - 1);
+            if (v < (1 << (sz - 1))) v -= (1 << sz) - 1;
+            fast[i] = (int32_t)((uint32_t)v << 16 | (uint32_t)run << 8 | (uint32_t)(len + sz));
+        }
         ok = n > 0;
     }
 };
@@ -208,6 +221,22 @@ struct Bits {
     int cnt = 0;
     bool marker = false;                                 // a marker was met: only zeros follow
     inline void fill() {
+        if (!marker && end - p >= 8) {                   // eight bytes at once when none of them is 0xFF (stuffing, markers)
+            uint64_t v;
+            memcpy(&v, p, 8);
+            v = __builtin_bswap64(v);
+            const uint64_t x = ~v;
+            if (!((x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull)) {
+                const int nb = (64 - cnt) >> 3;          // whole bytes that fit (cnt <= 56: at least one)
+                if (nb > 0) {
+                    const uint64_t top = nb == 8 ? v : (v >> (64 - 8 * nb)) << (64 - 8 * nb);
+                    acc |= cnt ? top >> cnt : top;
+                    cnt += 8 * nb;
+                    p += nb;
+                }
+                return;
+            }
+        }
         while (cnt <= 56) {
             int b = 0;
             if (!marker && p < end) {
@@ -276,6 +305,7 @@ int entropy(const Frame& f, uint32_t* ent, uint32_t* tab, int64_t* used) {
                 for (int v = 0; v < f.vs[c]; ++v)
                     for (int hh = 0; hh < f.hs[c]; ++hh) {
                         const int64_t blk = base[c] + (int64_t)(my * f.vs[c] + v) * bw[c] + mx * f.hs[c] + hh;
+                        uint32_t* dst = ent + at_word;   // (entries straight to their place: at most 64, 32 words are left)
                         int cnt = 0;
                         int s = decode_sym(b, f.dc[f.td[c]]);
                         if (s < 0 || s > 11) return VBS_EINVAL;
@@ -285,6 +315,16 @@ int entropy(const Frame& f, uint32_t* ent, uint32_t* tab, int64_t* used) {
                         if (pred[c]) e[cnt++] = (uint32_t)(uint16_t)(int16_t)pred[c];
                         const Huff& at = f.ac[f.ta[c]];
                         for (int k = 1; k < 64;) {
+                            if (b.cnt < 32) b.fill();    // a code (<= 16 bits) and its value bits (<= 15)
+                            const int32_t fa = at.fast[b.peek(9)];
+                            if (fa) {                    // code + value within the nine bits
+                                k += (fa >> 8) & 15;
+                                if (k > 63) return VBS_EINVAL;
+                                b.skip(fa & 255);
+                                e[cnt++] = (uint32_t)ZIGZAG[k] << 16 | (uint32_t)(uint16_t)(int16_t)(fa >> 16);
+                                ++k;
+                                continue;
+                            }
                             const int rs = decode_sym(b, at);
                             if (rs < 0) return VBS_EINVAL;
                             const int r = rs >> 4, sz = rs & 15;
@@ -294,12 +334,10 @@ int entropy(const Frame& f, uint32_t* ent, uint32_t* tab, int64_t* used) {
                             }
                             k += r;
                             if (k > 63) return VBS_EINVAL;
-                            if (b.cnt < 16) b.fill();
                             const int val = extend(b.get(sz), sz);
                             if (val) e[cnt++] = (uint32_t)ZIGZAG[k] << 16 | (uint32_t)(uint16_t)(int16_t)val;
                             ++k;
                         }
-                        uint32_t* dst = ent + at_word;
                         if (cnt <= 32) {
                             for (int i = 0; i < cnt; ++i) dst[i] = e[i];
                             tab[blk] = at_word << 7 | (uint32_t)cnt;
