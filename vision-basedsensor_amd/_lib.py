@@ -52,6 +52,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise VbsError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
                        f"g.build()'` (hipcc, gfx950). There is no CPU fallback.")
+    # torch first: it brings its own HIP runtime (libamdhip64 of the same soname), and the library must bind to THAT copy.
+    # Loaded the other way round - this library before torch - the process holds two runtimes and the second one to
+    # initialise fails (hipSetDevice: seen with `python __graft_entry__.py --smoke`, where build() loads the library first).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f64 = C.c_void_p, C.c_int, C.c_int64, C.c_double
     cam_p = C.POINTER(Camera)
