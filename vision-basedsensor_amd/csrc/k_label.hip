@@ -1291,7 +1291,8 @@ __global__ __launch_bounds__(256) void k_finalize_track(const u32* __restrict__ 
                                                         float* __restrict__ table, int do3d, CamD cam, double min_size) {
     finalize_frame(blockIdx.x, ncomp_all, band_sums, area_first, area_sums, probe_all, fstat, ell_all, det64, cnt64, det32, cnt32,
                    H, W, WW, maxm, 0, force_seq);
-    __threadfence();                                     // (the frame's detections and count, written by this workgroup)
+    // (the frame's detections and count were written by THIS workgroup: the barrier's workgroup-scope release / acquire is
+    //  all their readers need - an agent-scope fence here writes back and invalidates the XCD's L2 for nothing)
     __syncthreads();
     track_frame(blockIdx.x, det64, cnt64, maxm, ref_xy, m_ref, min_dist, table, do3d, cam, min_size);
 }
