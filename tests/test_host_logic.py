@@ -672,3 +672,28 @@ def test_mjpeg_decoder_class_host_half_without_a_gpu(tmp_path):
     assert dec.entropy(0) == 4
     with pytest.raises(IOError, match="frame 4"):
         dec.entropy(1)
+
+
+def test_avi_reader_follows_opendml_continuation_chunks(tmp_path):
+    """A recording beyond 1 GB continues in 'AVIX' RIFF chunks (OpenDML; what cv2.VideoWriter writes): the reader walks
+    every one of them, on a memory-mapped file; the frames are those of the same clip written as one chunk."""
+    from vbs_amd.video_io import AviReader, MjpegDeviceDecoder, write_avi, CAP_PROP_FRAME_COUNT
+    spec = S.config1()
+    frames = S.make_frames(spec, range(7), seed=4, channels=3)
+    one, split = str(tmp_path / "one.avi"), str(tmp_path / "split.avi")
+    write_avi(one, frames, quality=80)
+    write_avi(split, frames, quality=80, riff_frames=3)
+    assert open(split, "rb").read().count(b"AVIX") == 2
+    a, b = AviReader(one), AviReader(split)
+    assert a.get(CAP_PROP_FRAME_COUNT) == b.get(CAP_PROP_FRAME_COUNT) == 7
+    na, fa = a.read_batch(7, threads=1)
+    nb, fb = b.read_batch(7, threads=2)
+    assert na == nb == 7 and np.array_equal(fa, fb)
+    dec = MjpegDeviceDecoder(AviReader(split), "cpu", batch=7, threads=2)      # the native decoder reads the mapping in place
+    assert dec.entropy(0) == 7
+    for rd in (a, b):
+        rd.release()
+        assert not rd.isOpened() and rd.read() == (False, None)
+    assert not AviReader(str(tmp_path / "missing.avi")).isOpened()
+    open(str(tmp_path / "empty.avi"), "wb").close()
+    assert not AviReader(str(tmp_path / "empty.avi")).isOpened()

@@ -15,6 +15,7 @@ H.264 ...) need a real decoder: IOError, as `cv2` absent did.
 from __future__ import annotations
 
 import io
+import os
 import struct
 
 import numpy as np
@@ -37,29 +38,43 @@ class AviReader:
 
     def __init__(self, path: str):
         self._ok = False
+        self._buf = memoryview(b"")
+        self._map = None
         self.width = self.height = 0
         self.fps = 0.0
         self._frames = []            # (offset, size) of every video chunk
         self._next = 0
         self._codec = b""
         self._bits = 24
+        # The file is mapped, not read: a long recording is gigabytes, and only the chunk headers (here) and one batch of
+        # frames at a time (the decoders) are ever touched.  (A private copy-on-write mapping: nothing writes to it, but a
+        # read-only one cannot hand its address to the native decoder through ctypes.)
         try:
+            import mmap
             with open(path, "rb") as f:
-                self._buf = memoryview(f.read())
-        except OSError:
+                if os.fstat(f.fileno()).st_size == 0:
+                    return
+                self._map = mmap.mmap(f.fileno(), 0, access=mmap.ACCESS_COPY)
+            self._buf = memoryview(self._map)
+        except (OSError, ValueError):
             return
         b = self._buf
         if len(b) < 12 or bytes(b[0:4]) != b"RIFF" or bytes(b[8:12]) != b"AVI ":
             return
-        riff_end = min(len(b), 8 + struct.unpack_from("<I", b, 4)[0])
-        for cc, ds, size in _chunks(b, 12, riff_end):
-            if cc != b"LIST":
-                continue
-            kind = bytes(b[ds:ds + 4])
-            if kind == b"hdrl":
-                self._parse_hdrl(ds + 4, ds + size)
-            elif kind == b"movi":
-                self._scan_movi(ds + 4, min(ds + size, len(b)))
+        # OpenDML: a file beyond 1 GB continues in further RIFF chunks of form 'AVIX', each with its own 'movi' list
+        pos = 0
+        while pos + 12 <= len(b) and bytes(b[pos:pos + 4]) == b"RIFF" and bytes(b[pos + 8:pos + 12]) in (b"AVI ", b"AVIX"):
+            rsize = struct.unpack_from("<I", b, pos + 4)[0]
+            riff_end = min(len(b), pos + 8 + rsize)
+            for cc, ds, size in _chunks(b, pos + 12, riff_end):
+                if cc != b"LIST":
+                    continue
+                kind = bytes(b[ds:ds + 4])
+                if kind == b"hdrl" and pos == 0:
+                    self._parse_hdrl(ds + 4, ds + size)
+                elif kind == b"movi":
+                    self._scan_movi(ds + 4, min(ds + size, len(b)))
+            pos = riff_end + (rsize & 1)
         self._ok = bool(self._frames) and self.width > 0 and self.height > 0 and \
             self._codec.upper() in (b"MJPG", b"\x00\x00\x00\x00", b"DIB ", b"RAW ")
 
@@ -182,7 +197,8 @@ class AviReader:
         if pool is not None:
             pool.shutdown(wait=False)
             self._pool = None
-        self._buf = memoryview(b"")
+        self._buf = memoryview(b"")                       # (the mapping itself goes with its last user: a decoder may hold it)
+        self._map = None
         self._frames = []
         self._ok = False
 
@@ -214,7 +230,8 @@ class MjpegDeviceDecoder:
             raise ValueError("not a Motion-JPEG clip")
         self._lib = L.lib()
         self._reader = reader
-        self._base = reader._buf.obj                                   # the bytes object behind the memoryview
+        self._keep = reader._buf.obj                                   # the mapping behind the memoryview, kept alive here
+        self._base = C.addressof(C.c_char.from_buffer(self._keep))
         off, size = reader._frames[reader._next if reader._next < len(reader._frames) else 0]
         self._info = (C.c_int32 * 8)()
         first = (C.c_char * size).from_buffer_copy(reader._buf[off:off + size])
@@ -297,9 +314,10 @@ class MjpegDeviceDecoder:
 
 
 def write_avi(path: str, frames: np.ndarray, fps: float = 30.0, codec: str = "MJPG", quality: int = 95, subsampling: int = 2,
-              **jpeg_options):
+              riff_frames: int = 0, **jpeg_options):
     """frames uint8 [N,H,W,3] BGR or [N,H,W] gray -> AVI with one 'movi' list and an 'idx1' index.  `subsampling` (0 = 4:4:4,
-    1 = 4:2:2, 2 = 4:2:0) and further Pillow JPEG options (`restart_marker_rows`, `optimize` ...) apply to MJPG."""
+    1 = 4:2:2, 2 = 4:2:0) and further Pillow JPEG options (`restart_marker_rows`, `optimize` ...) apply to MJPG.  `riff_frames`
+    > 0 continues the file after that many frames in 'AVIX' RIFF chunks, the way OpenDML writers split files beyond 1 GB."""
     frames = np.asarray(frames)
     if frames.dtype != np.uint8 or frames.ndim not in (3, 4):
         raise ValueError("frames must be uint8 [N,H,W] or [N,H,W,3]")
@@ -339,8 +357,9 @@ def write_avi(path: str, frames: np.ndarray, fps: float = 30.0, codec: str = "MJ
     if bits == 8:
         strf += b"".join(struct.pack("<4B", i, i, i, 0) for i in range(256))
     hdrl = lst(b"hdrl", chunk(b"avih", avih) + lst(b"strl", chunk(b"strh", strh) + chunk(b"strf", strf)))
+    first = payloads[:riff_frames] if riff_frames > 0 else payloads
     movi_body, index, off = b"", b"", 4
-    for p in payloads:
+    for p in first:
         index += tag + struct.pack("<III", 0x10, off, len(p))
         c = chunk(tag, p)
         movi_body += c
@@ -348,3 +367,6 @@ def write_avi(path: str, frames: np.ndarray, fps: float = 30.0, codec: str = "MJ
     body = b"AVI " + hdrl + lst(b"movi", movi_body) + chunk(b"idx1", index)
     with open(path, "wb") as f:
         f.write(b"RIFF" + struct.pack("<I", len(body)) + body)
+        for k in range(len(first), len(payloads), max(riff_frames, 1)):       # OpenDML continuation chunks
+            ext = b"AVIX" + lst(b"movi", b"".join(chunk(tag, p) for p in payloads[k:k + riff_frames]))
+            f.write(b"RIFF" + struct.pack("<I", len(ext)) + ext)
