@@ -374,8 +374,8 @@ class MarkerTracker:
                 dev = torch.device(self.config.get("device") or "cuda:0")
                 if dev.type == "cuda":
                     dec = MjpegDeviceDecoder(self.cap, dev, batch, self.config.get("decode_threads"))
-            except ValueError:                              # a JPEG variant outside the native decoder: Pillow
-                dec = None
+            except (ValueError, MemoryError):               # a JPEG variant outside the native decoder, or no room for its
+                dec = None                                  # page-locked buffers: Pillow, as before
         self.decode_path = "device" if dec is not None else "pillow"
         if dec is not None:
             def ahead_of(slot): return dec.entropy(slot)
