@@ -15,7 +15,7 @@ ref = torch.from_numpy(S.dot_truth(spec, 0, [0])[0][:, :2].copy()).cuda() if has
 
 
 def run(engs, streams, reps):
-    parts = torch.chunk(ft, len(engs))
+    parts = [ft[i::1][0:0] for i in range(0)] or list(torch.chunk(ft[:(ft.shape[0] // (len(engs) * batch)) * len(engs) * batch], len(engs)))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
@@ -28,18 +28,21 @@ def run(engs, streams, reps):
     return (time.perf_counter() - t0) / reps, outs
 
 
-for k in (1, 2, 1, 2, 4):
+from vbs_amd import _lib as L
+for k in (1, 2, 3, 4, 6, 2, 3):
     engs = [Engine(spec.height, spec.width, max_markers=512, max_batch=batch) for _ in range(k)]
+    for e in engs:
+        e.set_option(L.OPT_PASS_STREAMS, 1)             # (one stream per handle here: k handles = k streams)
     streams = [torch.cuda.Stream() for _ in range(k)]
     run(engs, streams, 1)
     dt, outs = run(engs, streams, 4)
     cnt = torch.cat([o[2] for o in outs])
-    print(f"{k} stream(s): {n / dt:10.0f} frames/s  {dt * 1e6 / n:.3f} us/frame  counts {int(cnt.min())}..{int(cnt.max())}", flush=True)
+    nn = int(cnt.numel())
+    print(f"{k} stream(s): {nn / dt:10.0f} frames/s  {dt * 1e6 / nn:.3f} us/frame  ({nn} frames) counts {int(cnt.min())}..{int(cnt.max())}", flush=True)
     for e in engs:
         e.close()
 
 # the library's own form: VBS_OPT_PASS_STREAMS = 1 | 2 on one handle (odd internal passes on a second workspace and stream)
-from vbs_amd import _lib as L
 eng = Engine(spec.height, spec.width, max_markers=512, max_batch=batch)
 for ps in (1, 2, 1, 2):
     eng.set_option(L.OPT_PASS_STREAMS, ps)
