@@ -191,6 +191,10 @@ class MarkerTracker:
             self.height, self.width = int(data.shape[1]), int(data.shape[2])
         else:
             try:
+                # config["video_reader"] = "native": the package's own reader (and with it the device-side Motion-JPEG
+                # decode) also where OpenCV is installed; the default keeps the reference's cv2.VideoCapture when there is one
+                if self.config.get("video_reader", "auto") == "native":
+                    raise ImportError("the package's own reader was asked for")
                 import cv2
                 self.cap = cv2.VideoCapture(path)
                 props = (cv2.CAP_PROP_FPS, cv2.CAP_PROP_FRAME_WIDTH, cv2.CAP_PROP_FRAME_HEIGHT)
