@@ -579,7 +579,7 @@ extern "C" int vbs_mjpeg_entropy_batch(const uint8_t* buf, const int64_t* offs, 
 extern "C" int vbs_mjpeg_reconstruct(const uint32_t* ent, const uint32_t* tab, const int64_t* frame_base, const uint16_t* qt, int n,
                                      const int32_t* info, uint8_t* planes, uint8_t* out, int64_t out_frame, int64_t out_row,
                                      void* stream) {
-    if (!ent || !tab || !frame_base || !qt || !info || !planes || !out || n < 0) return VBS_EINVAL;
+    if (!ent || !tab || !frame_base || !qt || !info || !planes || !out || n < 0 || n > 65535) return VBS_EINVAL;   // (frames = a grid dimension)
     if (n == 0) return VBS_OK;
     hipStream_t s = (hipStream_t)stream;
     const int W = info[0], H = info[1], nc = info[2], hs = info[3], vs = info[4];
