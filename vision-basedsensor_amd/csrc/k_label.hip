@@ -1097,9 +1097,11 @@ __device__ __forceinline__ void finalize_frame(int n, const u32* __restrict__ nc
                                                int H, int W, int WW, int maxm, int stop, int force_seq) {
     __shared__ double bx[1024], by[1024];
     __shared__ u8 unmatched[1024];
-    __shared__ int best_of[1024], claim[1024], wsum[4];
-    __shared__ double thr_s[1024];
-    __shared__ u64 best_d[1024];
+    __shared__ int claim[1024], wsum[4];
+    // per opened component (at most CCL_OPEN_COMPS = 512 of them: k_stage, k_stage_lat and k_label all stop there)
+    __shared__ int best_of[CCL_OPEN_COMPS];
+    __shared__ double thr_s[CCL_OPEN_COMPS], ecx_s[CCL_OPEN_COMPS], ecy_s[CCL_OPEN_COMPS];   // (:219) threshold, ellipse centre
+    __shared__ u64 best_d[CCL_OPEN_COMPS];
     __shared__ int dup_s;
     const int tid = threadIdx.x;
     int status = (int)fstat[n * 8 + 2];
@@ -1107,7 +1109,7 @@ __device__ __forceinline__ void finalize_frame(int n, const u32* __restrict__ nc
         if (tid == 0) { cnt64[n] = status; if (cnt32) cnt32[n] = status; }
         return;
     }
-    const int nb_ = (int)ncomp_all[n * 2 + 0], na = (int)ncomp_all[n * 2 + 1];
+    const int nb_ = min((int)ncomp_all[n * 2 + 0], 1024), na = min((int)ncomp_all[n * 2 + 1], CCL_OPEN_COMPS);   // (never past the tables)
     const u64* bs = band_sums + (int64_t)n * maxm * 4;
     for (int i = tid; i < nb_; i += blockDim.x) {
         double c = (double)bs[i * 4 + 0];
@@ -1146,6 +1148,7 @@ __device__ __forceinline__ void finalize_frame(int n, const u32* __restrict__ nc
             if (!(minor < 5.0)) thr = (minor / 10.0) * (minor / 10.0);     // (:219)
         }
         thr_s[c] = thr;
+        ecx_s[c] = e[0]; ecy_s[c] = e[1];               // (the matching below reads the centres a few times: not from memory)
         best_d[c] = ~0ull;
         best_of[c] = 0x7FFFFFFF;
     }
@@ -1165,8 +1168,7 @@ __device__ __forceinline__ void finalize_frame(int n, const u32* __restrict__ nc
                 if (seen) continue;
                 const double thr = thr_s[cid];
                 if (!(thr >= 0.0)) continue;
-                const double* e = ell + cid * 8;
-                const double dx = cx - e[0], dy = cy - e[1], d = dx * dx + dy * dy;
+                const double dx = cx - ecx_s[cid], dy = cy - ecy_s[cid], d = dx * dx + dy * dy;
                 if (!(d < thr) || !inside_polygon(pr, cx, cy, cid)) continue;
                 const u64 key = (u64)__double_as_longlong(d);
                 if (pass == 0) atomicMin(&best_d[cid], key);
