@@ -283,8 +283,9 @@ static void clear_pass(vbs_handle* h, int nb, hipStream_t s) {
         launch_fill(h->lat_hdr, 0u, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + 4 + (size_t)h->maxb + (size_t)nb * 8, s);
         h->pass_cleared = true;
     } else {
-        launch_fill(h->fstat, 0u, (size_t)nb * 8, s);
-        h->pass_cleared = false;
+        // (the slow counter and the frames' flags lie right in front of the statistics: launch_labelling's fill with this one)
+        launch_fill(h->slow_total, 0u, (size_t)4 + (size_t)h->maxb + (size_t)nb * 8, s);
+        h->pass_cleared = true;
     }
 }
 
@@ -756,6 +757,7 @@ extern "C" int vbs_track_to_3d(vbs_handle* h, const uint8_t* frames, int n, int 
         if ((rc = gp.release(k)) != VBS_OK) return join(gp.fail(rc));
         launch_labelling(hh, nb, ss);
         if (table && nb <= hh->lat_frames)               // a few frames: detections and tracking rows in one launch
+                                                         // (for a batch pass the one launch measured nothing: 282.1 k against 283.1 k frames/s)
             launch_finalize_track(hh, nb, det ? det + (size_t)off * h->maxm * VBS_DET_COLS : nullptr, counts ? counts + off : nullptr,
                                   ref_xy, m_ref, min_dist, table + (size_t)off * m_ref * VBS_TABLE_COLS, cam, min_marker_size_px, ss);
         else {
