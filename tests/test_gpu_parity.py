@@ -673,13 +673,15 @@ def test_mjpeg_device_decode_equals_libjpeg(tmp_path, sub):
     """f4(c): the native Motion-JPEG decoder (`vbs_mjpeg_entropy_batch` on the host + `vbs_mjpeg_reconstruct` on the device)
     against Pillow's libjpeg on the same chunks, bit for bit in every BGR byte: chroma 4:4:4 / 4:2:2 / 4:2:0 and gray,
     qualities 35-100 (quality 100 = all-ones tables: the widest coefficient range), image sizes that are not multiples of
-    the MCU (the partial last MCU row / column, chroma upsampling at the padded edge), restart intervals, optimised
+    the MCU (the partial last MCU row / column, chroma upsampling at the padded edge), images a few pixels wide (libjpeg
+    replicates a chroma plane of one or two samples instead of interpolating it), restart intervals, optimised
     Huffman tables, batches that do not divide the clip.  (libjpeg with its defaults - islow IDCT, fancy upsampling - is what
     cv2.imdecode and OpenCV's own MJPEG reader use; cv2.VideoCapture's FFmpeg backend has its own IDCT: unpinned.)"""
     pytest.importorskip("PIL")
     from vbs_amd.video_io import AviReader, MjpegDeviceDecoder, write_avi
     gray = sub == "gray"
     cases = [(q, hw, {}) for q in (35, 75, 95, 100) for hw in ((48, 80), (61, 83), (17, 9))]
+    cases += [(q, (h, w), {}) for q in (10, 90) for h in (1, 2, 5, 33) for w in (1, 2, 3, 4, 5)]   # (chroma <= 2 samples wide: replicated)
     cases += [(75, (61, 83), o) for o in (dict(restart_marker_rows=1), dict(restart_marker_blocks=3), dict(optimize=True))]
     cases += [(70, (480, 640), {})]
     for q, (h, w), opts in cases:

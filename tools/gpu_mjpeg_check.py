@@ -27,9 +27,59 @@ def frames_for(h, w, n, seed, gray):
     return np.stack(out)
 
 
+def random_cases(n, seed):
+    """n random clips: size 1..260 per side, quality 1..100, any sampling, content from flat to noise, random Pillow options"""
+    rng = np.random.default_rng(seed)
+    dev = torch.device("cuda:0")
+    bad = 0
+    for it in range(n):
+        h, w = int(rng.integers(1, 261)), int(rng.integers(1, 261))
+        sub = [0, 1, 2, "gray"][int(rng.integers(0, 4))]
+        q = int(rng.integers(1, 101))
+        kind = int(rng.integers(0, 5))
+        gray = sub == "gray"
+        shape = (3, h, w) if gray else (3, h, w, 3)
+        if kind == 0:
+            fr = rng.integers(0, 256, shape).astype(np.uint8)
+        elif kind == 1:
+            fr = np.full(shape, int(rng.integers(0, 256)), np.uint8)
+        elif kind == 2:
+            fr = (np.indices(shape)[2] * 255 // max(w - 1, 1)).astype(np.uint8)
+        elif kind == 3:
+            fr = (rng.integers(0, 2, shape) * 255).astype(np.uint8)
+        else:
+            fr = frames_for(max(h, 8), max(w, 8), 3, it, gray)[:, :h, :w]
+        opts = {}
+        if rng.integers(0, 4) == 0:
+            opts["restart_marker_blocks"] = int(rng.integers(1, 9))
+        if rng.integers(0, 4) == 0:
+            opts["optimize"] = True
+        with tempfile.TemporaryDirectory() as td:
+            p = os.path.join(td, "a.avi")
+            try:
+                V.write_avi(p, np.ascontiguousarray(fr), quality=q, subsampling=0 if gray else sub, **opts)
+            except OSError:                                 # (Pillow's encoder gives up on some option mixes: not a case)
+                continue
+            n_, want = V.AviReader(p).read_batch(3, threads=1)
+            dec = V.MjpegDeviceDecoder(V.AviReader(p), dev, batch=2, threads=2)
+            got, slot = [], 0
+            while dec.entropy(slot):
+                got.append(dec.reconstruct(slot).cpu().numpy().copy())
+                slot ^= 1
+            got = np.concatenate(got)
+        ok = got.shape == want.shape and np.array_equal(got, want)
+        bad += not ok
+        if not ok or it % 50 == 0:
+            print(f"random case {it}: {h}x{w} sub={sub} q={q} kind={kind} {opts}: {'OK' if ok else 'DIFF'}", flush=True)
+    print("random cases:", n, "bad:", bad, flush=True)
+    return bad
+
+
 def main():
     dev = torch.device("cuda:0")
     bad = 0
+    if len(sys.argv) > 2 and sys.argv[1] == "--random":
+        return 1 if random_cases(int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0) else 0
     cases = list(itertools.product((0, 1, 2, "gray"), (35, 75, 95, 100), ((48, 80), (61, 83), (480, 640), (17, 9))))
     extra = [dict(restart_marker_rows=1), dict(restart_marker_blocks=3), dict(optimize=True)]
     for sub, q, (h, w) in cases:

@@ -493,6 +493,10 @@ __global__ __launch_bounds__(256) void k_jpeg_color(const unsigned char* __restr
     int Cb, Cr;
     if (mode == 0) {
         Cb = cb[(int64_t)y * cpw + x]; Cr = cr[(int64_t)y * cpw + x];
+    } else if (cw <= 2) {
+        // jdsample.c takes the "fancy" upsamplers only for components more than two samples wide; narrower ones are replicated
+        const int64_t at = (int64_t)(mode == 2 ? y >> 1 : y) * cpw + (x >> 1);
+        Cb = cb[at]; Cr = cr[at];
     } else if (mode == 1) {
         Cb = h2v1(cb + (int64_t)y * cpw, cw, x); Cr = h2v1(cr + (int64_t)y * cpw, cw, x);
     } else {
