@@ -263,7 +263,11 @@ class Engine:
         table = table.contiguous()
         n, m = table.shape[0], table.shape[1]
         a, b = (0, n) if frame_range is None else (int(frame_range[0]), int(frame_range[1]))
+        if not (0 <= a <= b <= n):
+            raise ValueError(f"frame_range {frame_range} outside the table's {n} frames")
         disp = torch.empty((b - a, m, L.DISP_COLS), dtype=torch.float32, device=self.device)
+        if a == b:                                       # (a rank whose shard is empty: nothing to emit, no null pointer to pass)
+            return disp
         with torch.cuda.device(self.device):
             self._check(self.lib.vbs_displacement_range(self._h, _ptr(table), n, m, int(warmup_frames),
                                                         float(min_marker_size_px), float(max_displacement), a, b,
