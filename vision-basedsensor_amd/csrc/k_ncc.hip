@@ -280,6 +280,23 @@ template <int L> struct NccLit;
 template <> struct NccLit<80> { static constexpr float kc = 163.84f, ks2 = 547.2815085234848f, K1 = 3502601.654550303f; };
 template <> struct NccLit<33> { static constexpr float kc = 962.8797061524332f, ks2 = 6956.564407359948f, K1 = 7575698.639614983f; };
 
+// k_ncc_mfma's explicit kernel arguments as the kernarg segment lays them out (every argument at its natural alignment, in
+// order).  The rare paths (drain, the counters at the end) read what they need from there at the moment they need it: an
+// argument the compiler has loaded at the top of the kernel stays in scalar registers across the step loop, and this kernel
+// spills scalars into vector lanes that every step then reads back (small branch: ~60 v_readlane per step).
+struct NccKArgs {
+    const u64* bits; const double* rx; const double* ry; const uint4* wfrag; const double* tab; const float2* rowf;
+    u64* mbits; u8* mask_u8; u32* fstat; u64* tot;
+    int H, W, WW, tiles_per_seg, dbg_arg; float rel_arg;
+    NccConst nc;
+};
+typedef __attribute__((address_space(4))) const NccKArgs NccKArgsC;
+__device__ __forceinline__ NccKArgsC* ncc_kargs() {
+    NccKArgsC* p = (NccKArgsC*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));                          // opaque: its loads cannot be hoisted out of the rare path
+    return p;
+}
+
 template <int L, int LO, bool U8OUT>                    // U8OUT: also the uint8 mask of the staged API
 __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bits, const double* __restrict__ rx,
                                                      const double* __restrict__ ry, const uint4* __restrict__ wfrag,
@@ -491,8 +508,25 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
     };
     auto drain = [&]() {
         __builtin_amdgcn_s_waitcnt(0x0F70);              // the plain stores of these rows are out before the atomics
-        const double* cgd = tab + VBS_NCC_MAXL;
-        u32* mb32 = reinterpret_cast<u32*>(mbits) + (int64_t)n * H * WW * 2;
+        // Small branch: everything this path needs beyond the loop's own values comes from the kernel arguments AGAIN (see
+        // NccKArgs): 92 -> 8 spilled scalars, ~60 -> 2 v_readlane per step.  The large branch keeps the values it has: there
+        // the same change made the allocator spill MORE (64 -> 115 v_readlane in the loop and a vector register to scratch).
+        constexpr bool RELOAD = L < 64;
+        const double *d_tab, *d_rx, *d_ry; u64* d_mbits; u8* d_mask_u8; int d_H, d_W, d_WW;
+        double d_nc_tbar, d_nc_inv_l2, d_nc_thr2, d_nc_T2, d_mu; const u64* d_fbits;
+        if constexpr (RELOAD) {
+            NccKArgsC* ka = ncc_kargs();
+            d_tab = ka->tab; d_rx = ka->rx; d_ry = ka->ry; d_mbits = ka->mbits; d_mask_u8 = ka->mask_u8;
+            d_H = ka->H; d_W = ka->W; d_WW = ka->WW;
+            d_nc_tbar = ka->nc.tbar; d_nc_inv_l2 = ka->nc.inv_l2; d_nc_thr2 = ka->nc.thr2; d_nc_T2 = ka->nc.T2;
+            d_mu = (double)(255ull * (u64)ka->fstat[n * 8 + 0]) / (double)((int64_t)d_H * d_W);
+            d_fbits = ka->bits + (int64_t)n * d_H * d_WW;
+        } else {
+            d_tab = tab; d_rx = rx; d_ry = ry; d_mbits = mbits; d_mask_u8 = mask_u8; d_H = H; d_W = W; d_WW = WW;
+            d_nc_tbar = nc.tbar; d_nc_inv_l2 = nc.inv_l2; d_nc_thr2 = nc.thr2; d_nc_T2 = nc.T2; d_mu = mu; d_fbits = fbits;
+        }
+        const double* cgd = d_tab + VBS_NCC_MAXL;
+        u32* mb32 = reinterpret_cast<u32*>(d_mbits) + (int64_t)n * d_H * d_WW * 2;
         for (int e = 0; e < ecnt; ++e) {
             const int yo = (int)__builtin_amdgcn_readfirstlane((int)sm.elist[wave][e][0]);
 #pragma unroll 1
@@ -508,7 +542,7 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
 #pragma unroll
                     for (int k = 0; k < (L + 63) / 64; ++k) {
                         const int i = lane + 64 * k, yy = y + LO + i;
-                        hv[k] = (i < L && yy >= 0 && yy < H) ? ncc_row_exact<L, LO>(fbits + (int64_t)yy * WW, WW, xe, cgd, &cnt) : 0.0;
+                        hv[k] = (i < L && yy >= 0 && yy < d_H) ? ncc_row_exact<L, LO>(d_fbits + (int64_t)yy * d_WW, d_WW, xe, cgd, &cnt) : 0.0;
                     }
 #pragma unroll
                     for (int off = 32; off >= 1; off >>= 1) cnt += (u32)__shfl_xor((int)cnt, off);
@@ -520,24 +554,24 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
                         for (int i = 64 * k; i < min(L, 64 * k + 64); ++i) {
                             const u64 hb = (u64)(u32)__builtin_amdgcn_readlane((int)hl, i - 64 * k) |
                                            ((u64)(u32)__builtin_amdgcn_readlane((int)hh, i - 64 * k) << 32);
-                            Ge = __builtin_fma(tab[i], __longlong_as_double((long long)hb), Ge);
+                            Ge = __builtin_fma(d_tab[i], __longlong_as_double((long long)hb), Ge);
                         }
                     }
-                    int ny = min(y + HI, H - 1) - max(y + LO, 0) + 1;
-                    int nx = min(xe + HI, W - 1) - max(xe + LO, 0) + 1;
-                    double nn = (double)(ny * nx), sum_t = ry[y] * rx[xe];
+                    int ny = min(y + HI, d_H - 1) - max(y + LO, 0) + 1;
+                    int nx = min(xe + HI, d_W - 1) - max(xe + LO, 0) + 1;
+                    double nn = (double)(ny * nx), sum_t = d_ry[y] * d_rx[xe];
                     double sum_I = 255.0 * (double)cnt;
-                    double rest = -nc.tbar * sum_I - mu * (sum_t - nn * nc.tbar);
-                    double s1 = sum_I - nn * mu;
-                    double s2 = 255.0 * sum_I - 2.0 * mu * sum_I + nn * mu * mu;
-                    double var = s2 - s1 * s1 * nc.inv_l2;
-                    double rhs = nc.thr2 * var * nc.T2;
+                    double rest = -d_nc_tbar * sum_I - d_mu * (sum_t - nn * d_nc_tbar);
+                    double s1 = sum_I - nn * d_mu;
+                    double s2 = 255.0 * sum_I - 2.0 * d_mu * sum_I + nn * d_mu * d_mu;
+                    double var = s2 - s1 * s1 * d_nc_inv_l2;
+                    double rhs = d_nc_thr2 * var * d_nc_T2;
                     double num = 255.0 * Ge + rest;
                     const int flags = __builtin_amdgcn_readfirstlane((var > 0.0 ? 1 : 0) | ((var > 0.0 && num > 0.0 && num * num > rhs) ? 2 : 0) |
                                                                      ((var > 1e-6 && num > 0.0 && fabs(num * num - rhs) <= 1e-9 * rhs) ? 4 : 0));
                     if ((flags & 2) && lane == 0) {
-                        atomicOr(&mb32[(u32)__mul24(y, 2 * WW) + (u32)(xe >> 5)], 1u << (xe & 31));
-                        if (U8OUT) mask_u8[((int64_t)n * H + y) * W + xe] = 1;
+                        atomicOr(&mb32[(u32)__mul24(y, 2 * d_WW) + (u32)(xe >> 5)], 1u << (xe & 31));
+                        if (U8OUT) d_mask_u8[((int64_t)n * d_H + y) * d_W + xe] = 1;
                     }
                     if (flags & 1) { nexact++; if (flags & 4) amb++; }
                 }
@@ -799,11 +833,15 @@ __global__ __launch_bounds__(256, 4) void k_ncc_mfma(const u64* __restrict__ bit
             if (ecnt) drain();
         }
     }
-    if (lane == 0) {                                     // (wave-uniform counters; per frame and the handle's running totals)
-        if (amb) { atomicAdd(&fstat[n * 8 + 1], amb); atomicAdd(&tot[0], (u64)amb); }
-        if (nexact) { atomicAdd(&fstat[n * 8 + 3], nexact); atomicAdd(&tot[1], (u64)nexact); }
+    {
+        u32* fstat_ = fstat; u64* tot_ = tot;
+        if constexpr (L < 64) { NccKArgsC* ka = ncc_kargs(); fstat_ = ka->fstat; tot_ = ka->tot; }      // (see drain)
+        if (lane == 0) {                                 // (wave-uniform counters; per frame and the handle's running totals)
+            if (amb) { atomicAdd(&fstat_[n * 8 + 1], amb); atomicAdd(&tot_[0], (u64)amb); }
+            if (nexact) { atomicAdd(&fstat_[n * 8 + 3], nexact); atomicAdd(&tot_[1], (u64)nexact); }
+        }
+        if (tid == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) atomicAdd(&tot_[2], (u64)gridDim.z);  // frames
     }
-    if (tid == 0 && (blockIdx.x | blockIdx.y | blockIdx.z) == 0) atomicAdd(&tot[2], (u64)gridDim.z);      // frames
 }
 #undef wide
 
