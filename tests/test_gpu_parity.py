@@ -1127,6 +1127,87 @@ def test_fused_stage_equals_separate_kernels():
         eng.close()
 
 
+def test_stage_256_threads_equals_768(golden_dir):
+    """Small frames (the reference's 480x450 crop, 640x480) label a frame with the 256-thread instance of k_stage (tiles of
+    15-20 rows, three workgroups per CU, smaller tables) instead of the 768-thread one (tiles of 5-7 rows under 13 / 10 rows
+    of halo).  VBS_OPT_STAGE_IMPL = 3 keeps 768: every per-component table, detection row and count identical - marker
+    frames, the reference's real frame, ragged blobs, and the adverse patterns that overflow the (smaller) tables and go to
+    the general kernel from either shape."""
+    from vbs_amd.engine import Engine
+
+    def both(eng, run, n):
+        out = []
+        eng.set_option(L.OPT_LATENCY_FRAMES, 0)              # the batch kernel also for these few frames
+        for impl in (0, 3):
+            eng.set_option(L.OPT_STAGE_IMPL, impl)
+            res = run()
+            torch.cuda.synchronize()
+            out.append((res, eng.stage_tables(n)))
+        eng.set_option(L.OPT_STAGE_IMPL, 0)
+        eng.set_option(L.OPT_LATENCY_FRAMES, 24)
+        return out
+
+    def same_tables(t0, t1):
+        for i in range(t0["ncomp"].shape[0]):
+            nb, na = (int(v) for v in t0["ncomp"][i])
+            assert (nb, na) == tuple(int(v) for v in t1["ncomp"][i]), i
+            assert np.array_equal(t0["band_sums"][i][:nb, :3], t1["band_sums"][i][:nb, :3]), i
+            assert np.array_equal(t0["area_first"][i][:na], t1["area_first"][i][:na]), i
+            assert np.array_equal(t0["area_sums"][i][:na, :15], t1["area_sums"][i][:na, :15]), i
+            assert np.array_equal(t0["probe"][i][:nb], t1["probe"][i][:nb]), i
+
+    spec = S.config1()
+    for crop, n in ((None, 6), ((15, 465, 80, 560), 5), ((0, 300, 0, 640), 3), ((0, 480, 0, 250), 3)):
+        ft = S.make_frames_torch(spec, range(n), seed=4, device="cuda")
+        if crop:
+            ft = ft[:, crop[0]:crop[1], crop[2]:crop[3]]
+        eng = Engine(ft.shape[1], ft.shape[2], max_markers=512, max_batch=n)
+        ((_, d0, c0), t0), ((_, d1, c1), t1) = both(eng, lambda: eng.track_to_3d(ft, want_det=True), n)
+        assert int(t0["slow"].sum()) == 0 and int(t1["slow"].sum()) == 0, (crop, t0["slow"], t1["slow"])
+        same_tables(t0, t1)
+        assert torch.equal(c0, c1) and torch.equal(d0, d1) and int(c0.min()) > 0
+        eng.close()
+    # the reference's real frame, as it comes (467x437) and put back into the 480x450 crop frame it was cut from
+    bgr = np.load(os.path.join(golden_dir, "raw_markers_bgr.npz"))["bgr"]
+    full = np.zeros((450, 480, 3), np.uint8); full[6:6 + bgr.shape[0], 6:6 + bgr.shape[1]] = bgr
+    for img in (bgr, full):
+        ft = torch.from_numpy(np.stack([np.roll(img, (dy, dx), (0, 1)) for dy, dx in ((0, 0), (2, -3), (-1, 1), (3, 3))])).cuda()
+        eng = Engine(img.shape[0], img.shape[1], max_markers=1024, max_batch=4)
+        ((_, d0, c0), t0), ((_, d1, c1), t1) = both(eng, lambda: eng.track_to_3d(ft, want_det=True), 4)
+        # (the bare still stays on the fast path; pasted onto black its cut edge makes holes in some shifts: general kernel, from
+        #  either shape alike)
+        assert np.array_equal(t0["slow"], t1["slow"]) and (img is full or int(t0["slow"].sum()) == 0), (img.shape, t0["slow"], t1["slow"])
+        keep = t0["slow"] == 0
+        same_tables({k: v[keep] for k, v in t0.items()}, {k: v[keep] for k, v in t1.items()})
+        assert torch.equal(c0, c1) and torch.equal(d0, d1) and int(c0[1]) == 65
+        eng.close()
+    rng = np.random.default_rng(13)
+    for (h, w) in ((450, 480), (480, 640), (300, 200)):
+        n = 6
+        mask = np.zeros((n, h, w), np.uint8); area = np.zeros((n, h, w), np.uint8)
+        yy, xx = np.mgrid[0:h, 0:w]
+        for f in range(n):
+            for _ in range(int(rng.integers(3, 14))):
+                cx, cy = rng.uniform(0, w), rng.uniform(0, h)
+                a, b, th = rng.uniform(4, 22), rng.uniform(4, 22), rng.uniform(0, np.pi)
+                u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th); v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+                area[f][(u / a) ** 2 + (v / b) ** 2 <= 1] = 255
+                mask[f][(u / (0.7 * a)) ** 2 + (v / (0.7 * b)) ** 2 <= 1] = 1
+        pats = [np.ones((h, w), bool), (xx // 64) % 2 == 0, (yy // 8) % 2 == 0, ((xx // 8) + (yy // 8)) % 2 == 0,
+                rng.random((h, w)) < 0.5, ((xx % 12) < 6) & ((yy % 97) > 5)]
+        area = np.concatenate([area, np.stack([(p * 255).astype(np.uint8) for p in pats])])
+        mask = np.concatenate([mask, np.stack([p.astype(np.uint8) for p in pats])])
+        n = area.shape[0]
+        eng = Engine(h, w, max_markers=1024, max_batch=n)
+        mt, at = torch.from_numpy(mask).cuda(), torch.from_numpy(area).cuda()
+        ((d0, c0), t0), ((d1, c1), t1) = both(eng, lambda: eng.marker_center(mt, at), n)
+        assert torch.equal(c0, c1) and torch.equal(d0, d1), (h, w, c0.tolist(), c1.tolist())
+        keep = (t0["slow"] == 0) & (t1["slow"] == 0)          # frames neither shape handed to the general kernel
+        assert int(keep[:6].sum()) > 0, (h, w, t0["slow"], t1["slow"])
+        same_tables({k: v[keep] for k, v in t0.items()}, {k: v[keep] for k, v in t1.items()})
+        eng.close()
+
+
 def test_latency_stage_equals_the_batch_stage():
     """A pass of a few frames labels every frame with SEVERAL workgroups (k_stage_lat: tiles of ~8 rows, the shared tables
     in global memory, the last workgroup of a frame to arrive resolves it) instead of one (k_stage).  VBS_OPT_LATENCY_FRAMES = 32

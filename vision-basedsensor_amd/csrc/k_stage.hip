@@ -34,6 +34,7 @@
 // says why): k_morph and k_label (k_label.hip) redo them.
 #include "stage_common.h"
 
+#define ST_NT_SMALL 256           // small frames: four waves, THREE workgroups per CU (see stage_threads)
 #define ST_NT 768                  // threads per frame: 12 waves, three per SIMD, so that a thread may use 168 registers
 
 struct StageGeom {
@@ -44,7 +45,8 @@ struct StageGeom {
     int stop;                       // debug builds: leave after phase `stop`
 };
 
-// exclusive prefix sum over the ST_NT threads; tmp holds >= 17 words
+// exclusive prefix sum over the NT threads; tmp holds >= 17 words
+template <int NT>
 __device__ __forceinline__ u32 st_scan(u32 v, u32* tmp, u32* total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     u32 inc = v;
@@ -56,15 +58,15 @@ __device__ __forceinline__ u32 st_scan(u32 v, u32* tmp, u32* total) {
     if (lane == 63) tmp[wave] = inc;
     __syncthreads();
     if (wave == 0) {
-        const u32 t = lane < ST_NT / 64 ? tmp[lane] : 0u;
+        const u32 t = lane < NT / 64 ? tmp[lane] : 0u;
         u32 ti = t;
 #pragma unroll
-        for (int d = 1; d < ST_NT / 64; d <<= 1) {
+        for (int d = 1; d < NT / 64; d <<= 1) {
             const u32 o = __shfl_up(ti, d);
             if (lane >= d) ti += o;
         }
-        if (lane < ST_NT / 64) tmp[lane] = ti - t;
-        if (lane == ST_NT / 64 - 1) tmp[16] = ti;
+        if (lane < NT / 64) tmp[lane] = ti - t;
+        if (lane == NT / 64 - 1) tmp[16] = ti;
     }
     __syncthreads();
     const u32 ex = inc - v + tmp[wave];
@@ -77,13 +79,14 @@ __device__ __forceinline__ u32 st_scan(u32 v, u32* tmp, u32* total) {
 // entry becomes the number of its root (bit 15 marks the root), comp_pos[c] = first pixel of component c in raster order
 // (minimum over its segments' first pixels), cidmap[c] = rank of that pixel = the component's id.  Workgroup-uniform
 // return: components, or NONE32 when there are more than `limit`.
+template <int NT>
 __device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nseg, const unsigned short* rec_sid,
                                            const u32* rec_pos, u32 nrec, const u32* seg_pos, u32* comp_pos,
                                            unsigned short* cidmap, u32* tmp, u32 limit, const PairQ& Q) {
     const int tid = threadIdx.x;
     {
         const int np = min(*Q.n, Q.cap);
-        for (int i = tid; i < np; i += ST_NT) { const u32 pr = Q.q[i]; ccl_union(P, pr >> 16, pr & 0xFFFFu); }
+        for (int i = tid; i < np; i += NT) { const u32 pr = Q.q[i]; ccl_union(P, pr >> 16, pr & 0xFFFFu); }
     }
     __syncthreads();
     for (u32 i = 0; i < nseg; ++i) {                     // flatten (no halving: a late store must be a root)
@@ -95,7 +98,7 @@ __device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nse
     u32 nroot = 0;
     for (u32 i = 0; i < nseg; ++i) nroot += (P[sbase + i] == sbase + i);
     u32 ncomp;
-    u32 c0 = st_scan(nroot, tmp, &ncomp);
+    u32 c0 = st_scan<NT>(nroot, tmp, &ncomp);
     if (ncomp > limit) return NONE32;
     for (u32 i = 0; i < nseg; ++i)
         if (P[sbase + i] == sbase + i) { comp_pos[c0] = NONE32; P[sbase + i] = (unsigned short)(0x8000u | c0++); }
@@ -106,9 +109,9 @@ __device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nse
     }
     __syncthreads();
     if (seg_pos) { for (u32 i = 0; i < nseg; ++i) atomicMin(&comp_pos[P[sbase + i] & 0x7FFFu], seg_pos[sbase + i]); }
-    else { for (u32 r = tid; r < nrec; r += ST_NT) atomicMin(&comp_pos[P[rec_sid[r]] & 0x7FFFu], rec_pos[r]); }
+    else { for (u32 r = tid; r < nrec; r += NT) atomicMin(&comp_pos[P[rec_sid[r]] & 0x7FFFu], rec_pos[r]); }
     __syncthreads();
-    for (u32 c = tid; c < ncomp; c += ST_NT) {           // rank by first pixel (positions are distinct)
+    for (u32 c = tid; c < ncomp; c += NT) {           // rank by first pixel (positions are distinct)
         const u32 p = comp_pos[c];
         u32 rank = 0;
         for (u32 q = 0; q < ncomp; ++q) rank += comp_pos[q] < p;
@@ -118,22 +121,22 @@ __device__ __forceinline__ u32 seg_resolve(unsigned short* P, u32 sbase, u32 nse
     return ncomp;
 }
 
-template <int NS>
-__global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask_all, const u64* __restrict__ area_all,
+template <int NS, int NT>
+__global__ __launch_bounds__(NT, 3) void k_stage(const u64* __restrict__ mask_all, const u64* __restrict__ area_all,
                                                     u32* __restrict__ ncomp_all, u64* __restrict__ band_sums,
                                                     u32* __restrict__ area_first, i64* __restrict__ area_sums,
                                                     unsigned short* __restrict__ probe_all, u32* __restrict__ fstat,
                                                     u32* __restrict__ slow_flag, u32* __restrict__ slow_total,
                                                     u32* __restrict__ mrec_all, StageGeom geo) {
     extern __shared__ __align__(16) unsigned char smem[];
-    unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [8 ST_NT] segment parents
+    unsigned short* P = reinterpret_cast<unsigned short*>(smem);                          // [8 NT] segment parents
     unsigned char* recb = smem + geo.off_rec;                                            // segment records
     unsigned char* botb = smem + geo.off_bot;                                            // last-row slots | component tables
     PairQ Q;
     Q.q = reinterpret_cast<u32*>(smem + geo.off_pq);                                      // [pq_cap]
     Q.cap = (int)geo.pq_cap;
-    u32* mb_cnt = reinterpret_cast<u32*>(smem + geo.off_mb);                              // [ST_NT] probe requests
-    u32* mb_req = mb_cnt + ST_NT;                                                         // [ST_NT][ST_MB_CAP]
+    u32* mb_cnt = reinterpret_cast<u32*>(smem + geo.off_mb);                              // [NT] probe requests
+    u32* mb_req = mb_cnt + NT;                                                         // [NT][ST_MB_CAP]
     u32* tmp = reinterpret_cast<u32*>(smem + geo.off_tmp);                                // [32]
     int* misc = reinterpret_cast<int*>(tmp + 32);                                         // [16]
     const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -156,7 +159,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
     u32* rec_cnt = rec_pos + rec_cap;
     u32* rec_sx = rec_cnt + rec_cap;
     u32* rec_sy = rec_sx + rec_cap;
-    u32* seg_pos = reinterpret_cast<u32*>(recb);                                          // [8 ST_NT] opened mask: first pixel by segment id
+    u32* seg_pos = reinterpret_cast<u32*>(recb);                                          // [8 NT] opened mask: first pixel by segment id
     // last-row slots of every tile; the component tables take their place once the tiles are linked
     u64* bot_mask = reinterpret_cast<u64*>(botb);                                         // [K][NBW]
     unsigned short* bot_sid = reinterpret_cast<unsigned short*>(botb + (size_t)8 * SG_KB * NBW);   // [K][NBW]
@@ -301,7 +304,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         __syncthreads();
         if (geo.stop == 3) return;
         const u32 nrec = (u32)misc[4];
-        const u32 ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, nullptr, comp_pos, cidmap, tmp,
+        const u32 ncomp = seg_resolve<NT>(P, sbase, min(nseg, (u32)SG_SEGMAX), rec_sid, rec_pos, nrec, nullptr, comp_pos, cidmap, tmp,
                                       min((u32)maxm, 1024u), Q);
         if (misc[5] > Q.cap) { hand_on(SLOW_PAIRS); return; }
         if (ncomp == NONE32) { hand_on(SLOW_NCOMP); return; }
@@ -310,9 +313,9 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         u32* acnt = reinterpret_cast<u32*>(accb);                                        // [maxm]
         u64* asx = reinterpret_cast<u64*>(accb + 8 * ((maxm + 1) / 2));                   // [maxm]
         u64* asy = asx + maxm;                                                           // [maxm]
-        for (u32 c = tid; c < ncomp; c += ST_NT) { acnt[c] = 0; asx[c] = 0; asy[c] = 0; }
+        for (u32 c = tid; c < ncomp; c += NT) { acnt[c] = 0; asx[c] = 0; asy[c] = 0; }
         __syncthreads();
-        for (u32 r = tid; r < nrec; r += ST_NT) {
+        for (u32 r = tid; r < nrec; r += NT) {
             const u32 cid = cidmap[P[rec_sid[r]] & 0x7FFFu];
             atomicAdd(&acnt[cid], rec_cnt[r]); atomicAdd(&asx[cid], (u64)rec_sx[r]); atomicAdd(&asy[cid], (u64)rec_sy[r]);
         }
@@ -320,7 +323,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         // the sums go out; the probe requests (2x2 pixel cell around every centroid) go to the threads that own the pixels
         u64* bs = band_sums + (int64_t)n * maxm * 4;
         unsigned short* pr = probe_all + (int64_t)n * maxm * 4;
-        for (u32 c = tid; c < ncomp; c += ST_NT) {
+        for (u32 c = tid; c < ncomp; c += NT) {
             const u32 cn_ = acnt[c];
             const u64 sx = asx[c], sy_ = asy[c];
             bs[c * 4 + 0] = cn_; bs[c * 4 + 1] = sx; bs[c * 4 + 2] = sy_;
@@ -574,7 +577,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
         }
         __syncthreads();
         if (geo.stop == 13) return;
-        ncomp = seg_resolve(P, sbase, min(nseg, (u32)SG_SEGMAX), nullptr, nullptr, 0, seg_pos, comp_pos, cidmap, tmp,
+        ncomp = seg_resolve<NT>(P, sbase, min(nseg, (u32)SG_SEGMAX), nullptr, nullptr, 0, seg_pos, comp_pos, cidmap, tmp,
                             min((u32)maxm, (u32)CCL_OPEN_COMPS), Q);
         if (misc[5] > Q.cap) { hand_on(16u + SLOW_PAIRS); return; }
         if (ncomp == NONE32) { hand_on(16u + SLOW_NCOMP); return; }
@@ -589,7 +592,7 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
     u64* acc = reinterpret_cast<u64*>(accb + 4 * CCL_OPEN_COMPS);                         // [mom_comps][NMOM]
     {
         u32* first = area_first + (int64_t)n * maxm;
-        for (u32 c = tid; c < ncomp; c += ST_NT) {
+        for (u32 c = tid; c < ncomp; c += NT) {
             const u32 pos = comp_pos[c], cid = cidmap[c], py = pos / (u32)W;
             anchor[cid] = (py << 16) | (pos - py * (u32)W);
             first[cid] = pos;
@@ -600,9 +603,9 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
     const u32 nmrec = (u32)misc[7];
     for (u32 c0 = 0; c0 < ncomp; c0 += geo.mom_comps) {
         const u32 nc = min(geo.mom_comps, ncomp - c0);
-        for (u32 c = tid; c < nc * NMOM; c += ST_NT) acc[c] = 0;
+        for (u32 c = tid; c < nc * NMOM; c += NT) acc[c] = 0;
         __syncthreads();
-        for (u32 r = tid; r < nmrec; r += ST_NT) {
+        for (u32 r = tid; r < nmrec; r += NT) {
             const uint4* src = reinterpret_cast<const uint4*>(mrec + (size_t)r * 16);
             const uint4 w0 = src[0], w1 = src[1], w2 = src[2], w3 = src[3];
             const u32 s = w0.x, cid = (u32)cidmap[P[s] & 0x7FFFu] - c0;
@@ -620,11 +623,11 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
                 if (o[q]) atomicAdd(&a[q], (u64)o[q]);
         }
         __syncthreads();
-        for (u32 c = tid; c < nc * NMOM; c += ST_NT) as[(c0 + c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
+        for (u32 c = tid; c < nc * NMOM; c += NT) as[(c0 + c / NMOM) * VBS_AREA_SUMS + (c % NMOM)] = (i64)acc[c];
         __syncthreads();
     }
     // ---- probes: segment -> component ----------------------------------------------------------------------------------
-    for (u32 e = tid; e < nband * 4; e += ST_NT) {
+    for (u32 e = tid; e < nband * 4; e += NT) {
         const u32 v = pr[e];
         if (v != NONE16) pr[e] = cidmap[P[v] & 0x7FFFu];
     }
@@ -632,29 +635,45 @@ __global__ __launch_bounds__(ST_NT, 3) void k_stage(const u64* __restrict__ mask
 }
 
 // ---- host side ----------------------------------------------------------------------------------------------------
+// Threads per frame.  768 (12 waves: one workgroup per CU at three waves per SIMD) is the shape of a large frame.  A small
+// one (the reference's 480x450 crop: 8 words wide) gives a 768-thread workgroup tiles of 5 rows that each walk 13 / 10 rows of
+// halo as well: 18 row steps for 5 rows.  256 threads (four waves, one per SIMD; THREE workgroups per CU, so still three
+// waves per SIMD, with the tables of a small frame cut to fit three in the LDS) have tiles of 15 rows: 28 steps for 15,
+// 0.52 x the thread-steps per frame: k_stage 0.236 -> 0.183 us per 480x450 frame.  (384 threads, two workgroups per CU, were
+// measured SLOWER than 768, 0.279: six waves do not spread evenly over four SIMDs.)  A frame that needs more than the
+// smaller tables hold takes the general kernels, like any frame beyond the large ones; a handle whose max_markers makes
+// the tables too large for three workgroups (1024) keeps 768.  VBS_OPT_STAGE_IMPL = 3 keeps 768 everywhere (test hook: the
+// two shapes must agree bit for bit).
+static int stage_threads(const vbs_handle* h) {
+    if (h->stage_impl == 3 || h->bp.ns != 8) return ST_NT;
+    const int G = 64 / h->WW, R768 = (h->H + (ST_NT / 64) * G - 1) / ((ST_NT / 64) * G);
+    return R768 <= 8 ? ST_NT_SMALL : ST_NT;
+}
+
 // false = geometry outside the fused path (the round-2 kernels take it)
-static bool stage_geom(const vbs_handle* h, StageGeom* g, size_t* lds_bytes) {
+static bool stage_geom(const vbs_handle* h, StageGeom* g, size_t* lds_bytes, int nt) {
     if (h->W > 4096 || h->H > 2048 || h->maxm > 1024) return false;
-    const int G = 64 / h->WW, NB = (ST_NT / 64) * G;     // (WW <= 64: vbs_create)
+    const int G = 64 / h->WW, NB = (nt / 64) * G;        // (WW <= 64: vbs_create)
     const int R = (h->H + NB - 1) / NB;
     if (R > 128 || R < 1) return false;                  // (row bit masks; int32 moments about the tile's centre)
     g->H = h->H; g->W = h->W; g->WW = h->WW; g->G = G; g->NB = NB; g->R = R; g->maxm = h->maxm;
     g->stop = VBS_KNOB("VBS_STAGE_STOP");
     const size_t NBW = (size_t)NB * h->WW;
     auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
-    // table sizes (one workgroup per CU: the whole LDS is there to be used)
-    g->rec_cap = (u32)SG_REC;
-    g->pq_cap = (u32)SG_PQ;
-    g->mom_comps = (u32)CCL_MOM_COMPS;
-    const size_t par = up16((size_t)ST_NT * SG_SEGMAX * 2);
+    // table sizes.  768 threads: one workgroup per CU, the whole LDS is there to be used.  256: three per CU
+    const bool half = nt < ST_NT;
+    g->rec_cap = (u32)(half ? 768 : SG_REC);
+    g->pq_cap = (u32)(half ? 1536 : SG_PQ);
+    g->mom_comps = (u32)(half ? CCL_MOM_COMPS / 4 : CCL_MOM_COMPS);
+    const size_t par = up16((size_t)nt * SG_SEGMAX * 2);
     size_t rec = up16((size_t)g->rec_cap * 18);
-    if (rec < (size_t)ST_NT * SG_SEGMAX * 4) rec = (size_t)ST_NT * SG_SEGMAX * 4;     // (the opened mask's first-pixel table)
+    if (rec < (size_t)nt * SG_SEGMAX * 4) rec = (size_t)nt * SG_SEGMAX * 4;           // (the opened mask's first-pixel table)
     const size_t bot = up16((size_t)SG_KB * NBW * 10);
     const size_t acc_band = up16((size_t)(8 * ((h->maxm + 1) / 2)) + 16 * (size_t)h->maxm);
     const size_t acc_open = up16((size_t)4 * CCL_OPEN_COMPS + (size_t)g->mom_comps * NMOM * 8);
     const size_t comp = 4096 + 2048 + (acc_band > acc_open ? acc_band : acc_open);
     const size_t botc = bot > comp ? bot : comp;
-    const size_t pq = (size_t)g->pq_cap * 4, mb = (size_t)ST_NT * 4 * (1 + ST_MB_CAP), misc = 32 * 4 + 16 * 4;
+    const size_t pq = (size_t)g->pq_cap * 4, mb = (size_t)nt * 4 * (1 + ST_MB_CAP), misc = 32 * 4 + 16 * 4;
     g->off_rec = (u32)par;
     g->off_bot = (u32)(par + rec);
     g->off_pq = (u32)(par + rec + botc);
@@ -666,27 +685,28 @@ static bool stage_geom(const vbs_handle* h, StageGeom* g, size_t* lds_bytes) {
     // tiles of 5 rows, ~650 records against the 437 its slice holds) have their own buffer (vbs_create: stage_mrec)
     g->mrec_stride = h->stage_mrec ? 16u * (u32)SG_REC : 2u * (u32)h->H * (u32)h->WW;
     g->mrec_cap = g->mrec_stride / 16u < (u32)SG_REC ? g->mrec_stride / 16u : (u32)SG_REC;
-    return *lds_bytes <= 160 * 1024;
+    return *lds_bytes <= (size_t)(half ? 160 * 1024 / 3 - 256 : 160 * 1024);
 }
 
 bool stage_supported(const vbs_handle* h) {
     StageGeom g;
     size_t lds;
-    return stage_geom(h, &g, &lds);
+    return stage_geom(h, &g, &lds, ST_NT);
 }
 
-template <int NS>
+template <int NS, int NT>
 static bool stage_launch_t(vbs_handle* h, int nb, const StageGeom& g, size_t lds, hipStream_t s) {
-    if (lds > h->stage_lds_set) {
-        // (both instances: a handle runs only one of them)
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage<NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    size_t& set = h->stage_lds_set[NT == ST_NT ? 0 : 1];
+    if (lds > set) {
+        // (per thread count; of the NS instances a handle runs only one)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage<NS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess) {
             (void)hipGetLastError();
             return false;
         }
-        h->stage_lds_set = lds;
+        set = lds;
     }
-    VBS_LAUNCH(h, s, "k_stage", (k_stage<NS>), dim3(nb), dim3(ST_NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
+    VBS_LAUNCH(h, s, "k_stage", (k_stage<NS, NT>), dim3(nb), dim3(NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
                h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, h->slow_total,
                h->stage_mrec ? h->stage_mrec : h->wbase, g);
     return true;
@@ -696,6 +716,7 @@ static bool stage_launch_t(vbs_handle* h, int nb, const StageGeom& g, size_t lds
 bool launch_stage(vbs_handle* h, int nb, hipStream_t s) {
     StageGeom g;
     size_t lds = 0;
-    if (!stage_geom(h, &g, &lds)) return false;
-    return h->bp.ns == 14 ? stage_launch_t<14>(h, nb, g, lds, s) : stage_launch_t<8>(h, nb, g, lds, s);
+    if (stage_threads(h) < ST_NT && stage_geom(h, &g, &lds, ST_NT_SMALL) && stage_launch_t<8, ST_NT_SMALL>(h, nb, g, lds, s)) return true;
+    if (!stage_geom(h, &g, &lds, ST_NT)) return false;
+    return h->bp.ns == 14 ? stage_launch_t<14, ST_NT>(h, nb, g, lds, s) : stage_launch_t<8, ST_NT>(h, nb, g, lds, s);
 }
