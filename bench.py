@@ -434,7 +434,8 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
-    ap.add_argument("--batch", type=int, default=512, help="frames per internal pass (workspace size): 256 / 512 / 1024 / 2048 ran at 270.5 / 274.1 / 277.9 / 278.8 k frames/s in one sweep (tools/batch_sweep.sh) - within the run-to-run noise of the 512 line, which all profiles are taken at")
+    ap.add_argument("--stage-impl", type=int, default=0, help="VBS_OPT_STAGE_IMPL for the timed engine (A/B of the labelling kernel's shapes: 3 = 768 threads per frame always, 4 = 256 wherever the geometry allows; results identical)")
+    ap.add_argument("--batch", type=int, default=1536, help="frames per internal pass (workspace size).  1536 = six frames per CU for the labelling kernel's 256-thread instance (three workgroups per CU): 512 / 768 / 1024 / 1536 / 2048 ran at 290.6 / 291.4 / 293.1 / 294.0 / 292.7 k frames/s in one sweep (profiles/r5o_stage256_large_ab3.log); rounds 2-5 quoted 512")
     ap.add_argument("--roofline-frames", type=int, default=1024)
     ap.add_argument("--pass-streams", type=int, default=2, choices=[1, 2],
                     help="VBS_OPT_PASS_STREAMS: 2 = odd internal passes on a second workspace and stream (the library's default)")
@@ -528,6 +529,8 @@ def main():
     cam = L.make_camera(K, dist, R, T, 2.0)
     eng = Engine(H, W, max_markers={"c3": 512, "c5": 1024, "c1": 256, "real": 256}[args.workload], max_batch=args.batch, device=local_rank)
     eng.set_option(L.OPT_PASS_STREAMS, args.pass_streams)
+    if args.stage_impl:
+        eng.set_option(L.OPT_STAGE_IMPL, args.stage_impl)
 
     # synthetic frames of this rank's contiguous block, rendered on the device (same bytes as NumPy)
     a, b = D.shard_bounds(n_total, world, rank)
@@ -746,7 +749,7 @@ def main():
         #     SIMDs' cycles in which k_stage issues a vector instruction, from the newest committed SQ counters.
         result["roofline"]["measured_in_this_run"] = True
         if world == 1 and args.workload in ("c3", "c5") and not args.no_extras:
-            live, why = _band_stage_live(args.workload)
+            live, why = _band_stage_live(args.workload, frames=min(args.batch, 2048))
             if live:
                 band_us = float(live[10])
                 result["roofline"]["band_stage"] = {
@@ -757,7 +760,7 @@ def main():
                     "opened_half_us_per_frame": round(max(float(live[0]) - band_us, 0.0), 4),
                     "measured_in_this_run": True,
                     "how": "child process (fresh interpreter) of this run: tools/gpu_stage_phase.py, libvbs_dbg.so, VBS_STAGE_STOP=10 "
-                           "(the kernel returns once the band half's sums are out) and 0 (whole kernel), 512 frames per launch, "
+                           "(the kernel returns once the band half's sums are out) and 0 (whole kernel), min(batch, 2048) frames per launch, "
                            "HIP events"}
             else:
                 result["roofline"]["band_stage"] = {"measured_in_this_run": False, "error": why}

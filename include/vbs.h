@@ -83,7 +83,8 @@ int vbs_version(void);
  * labelling / sums of `_marker_center` (:170-196) in the fused kernel (k_stage.hip) where the frame geometry allows it,
  * 1 always runs the separate kernels (k_morph + k_ccl) that other geometries take, 2 labels EVERY frame with the general
  * kernel (k_morph + k_label: what a frame with holes / beyond the fast path's tables takes), 3 is 0 with the fused kernel
- * at 768 threads per frame whatever the frame's height (small frames otherwise take its 256-thread instance).  VBS_OPT_BLUR_IMPL (test hook /
+ * at 768 threads per frame always, 4 is 0 with its 256-thread instance wherever the geometry allows (by itself the kernel
+ * takes 256 threads for small frames and for passes of >= 512 large ones, 768 otherwise).  VBS_OPT_BLUR_IMPL (test hook /
  * fallback, results identical): 0 (default) runs the two GaussianBlurs (:118-129) on 16-column strips (k_blur16) where the
  * frame allows it (large branch, width >= 240 and a multiple of 8, rows that load as aligned dwords), 1 always runs the 32-column
  * kernel (k_blur_mfma) that every other frame takes.  VBS_OPT_PASS_STREAMS (tuning, results identical): 2 (default) lets

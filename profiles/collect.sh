@@ -10,7 +10,7 @@ TAG=${1:-r2}
 FR=${2:-512}
 OUT=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --frames 1024 --steps 2 --warmup 1 --no-cpu-baseline --no-extras --pass-streams 1 > $OUT/prof_$TAG.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$TAG -- python3 $GRAFT_REPO_ROOT/bench.py --frames $FR --batch $FR --steps 2 --warmup 1 --no-cpu-baseline --no-extras --pass-streams 1 > $OUT/prof_$TAG.log 2>&1
 echo "collected stats $TAG"
 STAGE='k_stage|k_morph|k_ccl|k_label|k_finalize'
 for WL in c3 c5; do

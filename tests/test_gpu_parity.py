@@ -1130,7 +1130,8 @@ def test_fused_stage_equals_separate_kernels():
 def test_stage_256_threads_equals_768(golden_dir):
     """Small frames (the reference's 480x450 crop, 640x480) label a frame with the 256-thread instance of k_stage (tiles of
     15-20 rows, three workgroups per CU, smaller tables) instead of the 768-thread one (tiles of 5-7 rows under 13 / 10 rows
-    of halo).  VBS_OPT_STAGE_IMPL = 3 keeps 768: every per-component table, detection row and count identical - marker
+    of halo); so does a pass of >= 512 large frames (tiles of 86 rows at 1280x1024), here forced for a few frames with
+    VBS_OPT_STAGE_IMPL = 4.  VBS_OPT_STAGE_IMPL = 3 keeps 768: every per-component table, detection row and count identical - marker
     frames, the reference's real frame, ragged blobs, and the adverse patterns that overflow the (smaller) tables and go to
     the general kernel from either shape."""
     from vbs_amd.engine import Engine
@@ -1138,7 +1139,7 @@ def test_stage_256_threads_equals_768(golden_dir):
     def both(eng, run, n):
         out = []
         eng.set_option(L.OPT_LATENCY_FRAMES, 0)              # the batch kernel also for these few frames
-        for impl in (0, 3):
+        for impl in (4, 3):                                  # (4: 256 threads also for a pass of a few LARGE frames)
             eng.set_option(L.OPT_STAGE_IMPL, impl)
             res = run()
             torch.cuda.synchronize()
@@ -1156,8 +1157,9 @@ def test_stage_256_threads_equals_768(golden_dir):
             assert np.array_equal(t0["area_sums"][i][:na, :15], t1["area_sums"][i][:na, :15]), i
             assert np.array_equal(t0["probe"][i][:nb], t1["probe"][i][:nb]), i
 
-    spec = S.config1()
-    for crop, n in ((None, 6), ((15, 465, 80, 560), 5), ((0, 300, 0, 640), 3), ((0, 480, 0, 250), 3)):
+    for tag, crop, n in (("c1", None, 6), ("c1", (15, 465, 80, 560), 5), ("c1", (0, 300, 0, 640), 3), ("c1", (0, 480, 0, 250), 3),
+                         ("c2", None, 3), ("c2", (64, 1024, 160, 1120), 2), ("c2", (0, 700, 100, 1000), 2)):
+        spec = {"c1": S.config1, "c2": S.config2}[tag]()
         ft = S.make_frames_torch(spec, range(n), seed=4, device="cuda")
         if crop:
             ft = ft[:, crop[0]:crop[1], crop[2]:crop[3]]
@@ -1182,7 +1184,7 @@ def test_stage_256_threads_equals_768(golden_dir):
         assert torch.equal(c0, c1) and torch.equal(d0, d1) and int(c0[1]) == 65
         eng.close()
     rng = np.random.default_rng(13)
-    for (h, w) in ((450, 480), (480, 640), (300, 200)):
+    for (h, w) in ((450, 480), (480, 640), (300, 200), (1024, 1280), (700, 900)):
         n = 6
         mask = np.zeros((n, h, w), np.uint8); area = np.zeros((n, h, w), np.uint8)
         yy, xx = np.mgrid[0:h, 0:w]

@@ -279,7 +279,7 @@ static int need_gray(vbs_handle* h, int planes, hipStream_t s) {
 static void clear_pass(vbs_handle* h, int nb, hipStream_t s) {
     h->last_ws = h; h->last_nb = nb;                     // every pass entry point records itself (vbs_track_to_3d names the
                                                          // workspace of ITS last pass afterwards): vbs_frame_stats / vbs_stage_tables
-    if (nb <= h->lat_frames && (h->stage_impl == 0 || h->stage_impl == 3) && nb <= h->lat_slots) {
+    if (nb <= h->lat_frames && (h->stage_impl == 0 || h->stage_impl >= 3) && nb <= h->lat_slots) {
         launch_fill(h->lat_hdr, 0u, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + 4 + (size_t)h->maxb + (size_t)nb * 8, s);
         h->pass_cleared = true;
     } else {
@@ -468,7 +468,7 @@ extern "C" int vbs_set_option(vbs_handle* h, int option, int value) {
             h->ncc_margin_ppm = value;
             return VBS_OK;
         case VBS_OPT_STAGE_IMPL:
-            if (value < 0 || value > 3) break;
+            if (value < 0 || value > 4) break;
             h->stage_impl = value;
             return VBS_OK;
         case VBS_OPT_LATENCY_FRAMES:

@@ -109,7 +109,7 @@ struct vbs_handle {
     u32* slow_total;   // [1]  frames of this pass the fused kernel handed on (lets the general kernels leave at once)
     u32* slow_flag;    // [maxb]  non-zero = the fast labelling path handed the frame on (the value says why)
     size_t stage_lds_set[2] = {0, 0}, ccl_lds_set[2] = {0, 0};   // dynamic LDS declared for k_stage / k_ccl<0|1> through this handle
-    int stage_impl = 0;             // vbs_set_option(VBS_OPT_STAGE_IMPL): 0 fused k_stage, 1 the round-2 kernels (k_morph + k_ccl), 2 k_label for every frame, 3 fused at 768 threads
+    int stage_impl = 0;             // vbs_set_option(VBS_OPT_STAGE_IMPL): 0 fused k_stage, 1 the round-2 kernels (k_morph + k_ccl), 2 k_label for every frame, 3 / 4 fused at 768 / 256 threads
     int gray_bits = 15;             // BGR2GRAY fixed-point coefficient set: 15 (OpenCV 4) | 14 (OpenCV <= 3.4.1)
     bool force_seq_match = false;   // vbs_set_option(VBS_OPT_FORCE_SEQ_MATCH)
     bool gray_side = false;         // vbs_set_option(VBS_OPT_GRAY_SIDE_STREAM)

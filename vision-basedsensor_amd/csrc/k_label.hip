@@ -891,7 +891,7 @@ bool launch_stage_lat(vbs_handle* h, int nb, hipStream_t s);   // k_stage_lat.hi
 // k_morph over every frame, k_ccl<0|1>, the general kernel over what those hand on.
 void launch_labelling(vbs_handle* h, int nb, hipStream_t s) {
     // a pass of a few frames (MarkerTracker.process: ONE) spreads each frame over several workgroups: k_stage_lat.hip
-    const bool fused = h->stage_impl == 0 || h->stage_impl == 3;
+    const bool fused = h->stage_impl == 0 || h->stage_impl >= 3;
     const bool lat = fused && nb <= h->lat_frames && nb <= h->lat_slots;
     if (h->pass_cleared) h->pass_cleared = false;        // (detect_pass cleared them with the frame statistics: one launch less)
     else if (lat) launch_fill(h->lat_hdr, 0u, (size_t)VBS_LAT_MAXN * VBS_LAT_HDR + nb + 4, s);     // its headers, the counter and the flags

@@ -644,10 +644,16 @@ __global__ __launch_bounds__(NT, 3) void k_stage(const u64* __restrict__ mask_al
 // smaller tables hold takes the general kernels, like any frame beyond the large ones; a handle whose max_markers makes
 // the tables too large for three workgroups (1024) keeps 768.  VBS_OPT_STAGE_IMPL = 3 keeps 768 everywhere (test hook: the
 // two shapes must agree bit for bit).
-static int stage_threads(const vbs_handle* h) {
-    if (h->stage_impl == 3 || h->bp.ns != 8) return ST_NT;
+static int stage_threads(const vbs_handle* h, int nb) {
+    if (h->stage_impl == 3) return ST_NT;
     const int G = 64 / h->WW, R768 = (h->H + (ST_NT / 64) * G - 1) / ((ST_NT / 64) * G);
-    return R768 <= 8 ? ST_NT_SMALL : ST_NT;
+    if (h->bp.ns == 8) return R768 <= 8 ? ST_NT_SMALL : ST_NT;
+    // large frames: 256 threads have tiles of 86 rows at 1280x1024 - 99 row steps for 86 rows against 42 for 29, 0.78 x the
+    // thread-steps: k_stage 0.76 -> 0.685 us per frame once a pass brings three frames per CU (768 frames).  At 512 frames
+    // the kernel alone is slower (0.79: two workgroups = two waves per SIMD) and the call still faster (286 k against 280 k
+    // frames/s): the slots it leaves free take the other pass stream's kernels.  Below that a frame on 768 threads is done
+    // sooner (42 steps against 99).  VBS_OPT_STAGE_IMPL = 4: 256 for any pass (test hook).
+    return (h->stage_impl == 4 || nb >= 512) ? ST_NT_SMALL : ST_NT;
 }
 
 // false = geometry outside the fused path (the round-2 kernels take it)
@@ -696,7 +702,7 @@ bool stage_supported(const vbs_handle* h) {
 
 template <int NS, int NT>
 static bool stage_launch_t(vbs_handle* h, int nb, const StageGeom& g, size_t lds, hipStream_t s) {
-    size_t& set = h->stage_lds_set[NT == ST_NT ? 0 : 1];
+    size_t& set = h->stage_lds_set[NT == ST_NT ? 0 : 1];     // (of the NS instances a handle runs only one)
     if (lds > set) {
         // (per thread count; of the NS instances a handle runs only one)
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_stage<NS, NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -716,7 +722,8 @@ static bool stage_launch_t(vbs_handle* h, int nb, const StageGeom& g, size_t lds
 bool launch_stage(vbs_handle* h, int nb, hipStream_t s) {
     StageGeom g;
     size_t lds = 0;
-    if (stage_threads(h) < ST_NT && stage_geom(h, &g, &lds, ST_NT_SMALL) && stage_launch_t<8, ST_NT_SMALL>(h, nb, g, lds, s)) return true;
+    if (stage_threads(h, nb) < ST_NT && stage_geom(h, &g, &lds, ST_NT_SMALL) &&
+        (h->bp.ns == 14 ? stage_launch_t<14, ST_NT_SMALL>(h, nb, g, lds, s) : stage_launch_t<8, ST_NT_SMALL>(h, nb, g, lds, s))) return true;
     if (!stage_geom(h, &g, &lds, ST_NT)) return false;
     return h->bp.ns == 14 ? stage_launch_t<14, ST_NT>(h, nb, g, lds, s) : stage_launch_t<8, ST_NT>(h, nb, g, lds, s);
 }
