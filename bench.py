@@ -436,7 +436,7 @@ def main():
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--stage-impl", type=int, default=0, help="VBS_OPT_STAGE_IMPL for the timed engine (A/B of the labelling kernel's shapes: 3 = 768 threads per frame always, 4 = 256 wherever the geometry allows; results identical)")
     ap.add_argument("--batch", type=int, default=1536, help="frames per internal pass (workspace size).  1536 = six frames per CU for the labelling kernel's 256-thread instance (three workgroups per CU): 512 / 768 / 1024 / 1536 / 2048 ran at 290.6 / 291.4 / 293.1 / 294.0 / 292.7 k frames/s in one sweep (profiles/r5o_stage256_large_ab3.log); rounds 2-5 quoted 512")
-    ap.add_argument("--roofline-frames", type=int, default=1024)
+    ap.add_argument("--roofline-frames", type=int, default=0, help="frames of the per-kernel leg; 0 = two internal passes (2 x --batch): every kernel is timed at the pass size of the timed region")
     ap.add_argument("--pass-streams", type=int, default=2, choices=[1, 2],
                     help="VBS_OPT_PASS_STREAMS: 2 = odd internal passes on a second workspace and stream (the library's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -709,7 +709,7 @@ def main():
 
     # ---- live per-kernel timing + the threshold+CCL roofline (rank 0; other ranks idle at the barrier) ----
     if rank == 0:
-        nk = min(args.roofline_frames, n_local)
+        nk = min(args.roofline_frames or 2 * args.batch, n_local)
         eng.profile(True)                                                    # (passes on ONE stream from here on)
         eng.track_to_3d(frames[:nk], xy, 20.0, cam, 5.0)                     # warm-up in the profiled configuration,
         torch.cuda.synchronize()
