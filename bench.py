@@ -66,7 +66,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E peak (MI355X_MICROARCH.md)
-STAGE = ("k_stage", "k_morph", "k_ccl_band", "k_ccl_open", "k_slow_list", "k_label", "k_label_fill", "k_label_redo", "k_probe_slow",
+STAGE = ("k_stage", "k_stage_retry", "k_morph", "k_ccl_band", "k_ccl_open", "k_slow_list", "k_label", "k_label_fill", "k_label_redo", "k_probe_slow",
          "k_finalize")
 
 

@@ -1169,6 +1169,17 @@ def test_stage_256_threads_equals_768(golden_dir):
         same_tables(t0, t1)
         assert torch.equal(c0, c1) and torch.equal(d0, d1) and int(c0.min()) > 0
         eng.close()
+    # a dense layout (17 x 17 dots at a pitch of 56 px: more segments per 86-row tile and more records than the 256-thread
+    # instance holds): its frames get a second chance on 768 threads IN THE SAME PASS instead of the general kernels - not one
+    # frame handed on, the same tables
+    spec = S.grid_spec(1280, 1024, 17, 56, 30, name="dense", noise_sigma=2.0)
+    ft = S.make_frames_torch(spec, range(3), seed=1, device="cuda")
+    eng = Engine(1024, 1280, max_markers=512, max_batch=3)
+    ((_, d0, c0), t0), ((_, d1, c1), t1) = both(eng, lambda: eng.track_to_3d(ft, want_det=True), 3)
+    assert int(t0["slow"].sum()) == 0 and int(t1["slow"].sum()) == 0, (t0["slow"], t1["slow"])
+    same_tables(t0, t1)
+    assert torch.equal(c0, c1) and torch.equal(d0, d1) and int(c0.min()) == 289
+    eng.close()
     # the reference's real frame, as it comes (467x437) and put back into the 480x450 crop frame it was cut from
     bgr = np.load(os.path.join(golden_dir, "raw_markers_bgr.npz"))["bgr"]
     full = np.zeros((450, 480, 3), np.uint8); full[6:6 + bgr.shape[0], 6:6 + bgr.shape[1]] = bgr

@@ -43,6 +43,7 @@ struct StageGeom {
     u32 mrec_cap, mrec_stride;      // moment records per frame (global scratch), dwords between two frames' records
     u32 rec_cap, pq_cap, mom_comps; // LDS table sizes: band records, queued pairs, components per moment pass
     int stop;                       // debug builds: leave after phase `stop`
+    int retry;                      // 1: the second chance of the frames the 256-thread instance could not hold (launch_stage)
 };
 
 // exclusive prefix sum over the NT threads; tmp holds >= 17 words
@@ -169,6 +170,17 @@ __global__ __launch_bounds__(NT, 3) void k_stage(const u64* __restrict__ mask_al
     auto hand_on = [&](u32 why) {                        // (called by every thread, workgroup-uniformly)
         if (tid == 0) { slow_flag[n] = why; atomicAdd(slow_total, 1u); }
     };
+    if (geo.retry) {
+        // The launch behind the 256-thread instance: only the frames that one handed on because ITS tables or its taller
+        // tiles could not hold them (slots, segments, records, pairs, mailbox) - this instance has smaller tiles and tables
+        // 2.7 x as large; it takes the frame's flag back and labels it, or hands it on itself.  Nothing to do on marker
+        // frames of the usual density: the workgroups leave at once.
+        if (*slow_total == 0u) return;
+        const u32 f = slow_flag[n];
+        if (f != SLOW_SLOTS && f != SLOW_SEGS && f != SLOW_RECS && f != SLOW_PAIRS && f != SLOW_MAILBOX) return;
+        __syncthreads();                                 // (every thread has read the flag)
+        if (tid == 0) { slow_flag[n] = 0u; atomicSub(slow_total, 1u); }
+    }
     __syncthreads();
 
     // ================================ band plane ====================================================================
@@ -664,6 +676,7 @@ static bool stage_geom(const vbs_handle* h, StageGeom* g, size_t* lds_bytes, int
     if (R > 128 || R < 1) return false;                  // (row bit masks; int32 moments about the tile's centre)
     g->H = h->H; g->W = h->W; g->WW = h->WW; g->G = G; g->NB = NB; g->R = R; g->maxm = h->maxm;
     g->stop = VBS_KNOB("VBS_STAGE_STOP");
+    g->retry = 0;
     const size_t NBW = (size_t)NB * h->WW;
     auto up16 = [](size_t x) { return (x + 15) / 16 * 16; };
     // table sizes.  768 threads: one workgroup per CU, the whole LDS is there to be used.  256: three per CU
@@ -712,7 +725,7 @@ static bool stage_launch_t(vbs_handle* h, int nb, const StageGeom& g, size_t lds
         }
         set = lds;
     }
-    VBS_LAUNCH(h, s, "k_stage", (k_stage<NS, NT>), dim3(nb), dim3(NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
+    VBS_LAUNCH(h, s, g.retry ? "k_stage_retry" : "k_stage", (k_stage<NS, NT>), dim3(nb), dim3(NT), lds, s, h->mask_bits, h->area_bits, h->ncomp,
                h->band_sums, h->area_first, h->area_sums, h->probe, h->fstat, h->slow_flag, h->slow_total,
                h->stage_mrec ? h->stage_mrec : h->wbase, g);
     return true;
@@ -723,7 +736,16 @@ bool launch_stage(vbs_handle* h, int nb, hipStream_t s) {
     StageGeom g;
     size_t lds = 0;
     if (stage_threads(h, nb) < ST_NT && stage_geom(h, &g, &lds, ST_NT_SMALL) &&
-        (h->bp.ns == 14 ? stage_launch_t<14, ST_NT_SMALL>(h, nb, g, lds, s) : stage_launch_t<8, ST_NT_SMALL>(h, nb, g, lds, s))) return true;
+        (h->bp.ns == 14 ? stage_launch_t<14, ST_NT_SMALL>(h, nb, g, lds, s) : stage_launch_t<8, ST_NT_SMALL>(h, nb, g, lds, s))) {
+        // Its taller tiles and smaller tables give out earlier on dense layouts (17 x 17 dots at a pitch of 56 px in 1280x1024:
+        // every frame); those frames get a second chance on 768 threads before the general kernels (11.1 -> 4.7 us per frame
+        // there; a launch of workgroups that leave at once otherwise).
+        if (stage_geom(h, &g, &lds, ST_NT)) {
+            g.retry = 1;
+            (void)(h->bp.ns == 14 ? stage_launch_t<14, ST_NT>(h, nb, g, lds, s) : stage_launch_t<8, ST_NT>(h, nb, g, lds, s));
+        }
+        return true;
+    }
     if (!stage_geom(h, &g, &lds, ST_NT)) return false;
     return h->bp.ns == 14 ? stage_launch_t<14, ST_NT>(h, nb, g, lds, s) : stage_launch_t<8, ST_NT>(h, nb, g, lds, s);
 }
