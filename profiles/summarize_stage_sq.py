@@ -15,13 +15,32 @@ def kname(s):
     return k.split("<")[0]
 
 
+class RetryNamer:
+    """`k_stage<.., 768>` dispatched right behind a `k_stage<.., 256>` is the second-chance launch (workgroups that leave at once on
+    marker frames): its own name, so that "the last launch of k_stage" stays the one that did the work."""
+    def __init__(self):
+        self.small = -2
+
+    def __call__(self, row):
+        name, did = row["Kernel_Name"], int(row["Dispatch_Id"])
+        k = kname(name)
+        if k == "k_stage":
+            inst = name.split("(")[0]
+            if ", 256>" in inst:
+                self.small = did
+            elif did == self.small + 1:
+                return "k_stage_retry"
+        return k
+
+
 sq = {}
 for p in "abc":
     f = sorted(glob.glob(os.path.join(G, f"pmc_st_{p}_{tag}/**/*counter_collection.csv"), recursive=True))
     if not f:
         continue
-    for r in csv.DictReader(open(f[-1])):
-        sq.setdefault(kname(r["Kernel_Name"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])       # last launch wins
+    namer = RetryNamer()
+    for r in sorted(csv.DictReader(open(f[-1])), key=lambda r: int(r["Dispatch_Id"])):
+        sq.setdefault(namer(r), {})[r["Counter_Name"]] = float(r["Counter_Value"])       # last launch wins
 for k, c in sq.items():
     w = c.get("SQ_WAVE_CYCLES")
     if w:
