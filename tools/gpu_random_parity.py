@@ -2,8 +2,9 @@
 128, height >= 64), dot grid (count, pitch, diameter), noise, gray or BGR, a random crop - through the HIP path (masks of
 _find_markers, detections of the fused track path, a batch of 3 frames and one frame per call) against oracle/stages.py:
 masks bit-exact, the same detections in the same order with bit-exact centroids, axes within 1e-3 px.
-usage: gpu_random_parity.py [cases=40] [seed=0] [latency_frames=24]   (0: the batch of 3 goes through the BATCH labelling kernel
-k_stage - its 256-thread instance on small frames - instead of k_stage_lat)"""
+usage: gpu_random_parity.py [cases=40] [seed=0] [latency_frames=24] [stage_impl=0]   (latency_frames 0: the batch of 3 goes through
+the BATCH labelling kernel k_stage - its 256-thread instance on small frames - instead of k_stage_lat; stage_impl 4: 256 threads
+also on large frames, as passes of >= 512 frames run them)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -41,6 +42,8 @@ for it in range(cases):
         if len(sys.argv) > 3:
             from vbs_amd import _lib as L
             eng.set_option(L.OPT_LATENCY_FRAMES, int(sys.argv[3]))
+            if len(sys.argv) > 4:
+                eng.set_option(L.OPT_STAGE_IMPL, int(sys.argv[4]))
         ft = torch.from_numpy(frames).cuda()[:, t:b, l:r]
         mask, area = eng.find_markers(ft)
         _, det, counts = eng.track_to_3d(ft, None, want_det=True)
