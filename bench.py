@@ -431,8 +431,8 @@ def avi_path_fps(n, seed, batch=256):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=4096, help="frames per GPU per step")
     ap.add_argument("--stage-impl", type=int, default=0, help="VBS_OPT_STAGE_IMPL for the timed engine (A/B of the labelling kernel's shapes: 3 = 768 threads per frame always, 4 = 256 wherever the geometry allows; results identical)")
     ap.add_argument("--batch", type=int, default=1536, help="frames per internal pass (workspace size).  1536 = six frames per CU for the labelling kernel's 256-thread instance (three workgroups per CU): 512 / 768 / 1024 / 1536 / 2048 ran at 290.6 / 291.4 / 293.1 / 294.0 / 292.7 k frames/s in one sweep (profiles/r5o_stage256_large_ab3.log); rounds 2-5 quoted 512")
